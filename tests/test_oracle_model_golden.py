@@ -1,0 +1,96 @@
+"""CPU: the functional oracle network (oracle/model.py, oracle/step.py) reproduces the golden vectors
+captured from the reference's models/ + modules/ + segmentation_module.py (ABN = BatchNorm2d +
+leaky_relu stand-in) and from the hand-composed UCD step."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, sample_idx
+from oracle import model as OM
+from oracle import step as OS
+from ucd_amd import synth
+from ucd_amd.backbone import net_resnet101
+from ucd_amd.blocks import DeeplabV3, ResidualBlock
+from oracle_shims import ShimABN, build_cpu_net
+
+
+def test_blocks_and_head_match_reference():
+    g = load_golden("model_blocks.npz")
+    from functools import partial
+    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    # parameter dicts with the reference's key names come from the product's module tree (names only)
+    blk = ResidualBlock(32, (16, 16, 64), norm_act=norm, stride=2, dilation=1)
+    blk2 = ResidualBlock(64, (16, 16, 64), norm_act=norm, stride=1, dilation=2)
+    P1 = {"b." + k: v for k, v in synth.fill_state_dict(blk.state_dict(), 11).items()}
+    P2 = {"b." + k: v for k, v in synth.fill_state_dict(blk2.state_dict(), 12).items()}
+    x = synth.t_normal(400, (3, 32, 13, 13), stream=1)
+    for mode in ("train", "eval"):
+        y = OM.residual_block(x, P1, "b", 2, 1, mode == "train")
+        y = OM.residual_block(y, P2, "b", 1, 2, mode == "train")
+        np.testing.assert_allclose(y.numpy(), g[f"block_{mode}"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(P1["b.convs.bn1.running_mean"].numpy(), g["block_rm_after"], rtol=1e-6, atol=1e-7)
+
+    head = DeeplabV3(48, 24, 16, norm_act=norm, out_stride=16, pooling_size=4)
+    Ph = {"head." + k: v for k, v in synth.fill_state_dict(head.state_dict(), 13).items()}
+    xh = synth.t_normal(401, (2, 48, 7, 9), stream=1)
+    np.testing.assert_allclose(OM.deeplab_head(xh, Ph, True, pooling_size=4).numpy(), g["head_train"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(OM.deeplab_head(xh, Ph, False, pooling_size=4).numpy(), g["head_eval"], rtol=1e-5, atol=1e-5)
+
+
+def _student_teacher_params(seed=42):
+    teacher = build_cpu_net([16])
+    student = build_cpu_net([16, 5])
+    sd = synth.fill_state_dict(teacher.state_dict(), seed)
+    Pt = OS.make_params(sd, requires_grad=False)
+    st = {k: v.clone() for k, v in student.state_dict().items()}
+    st.update({k: v.clone() for k, v in sd.items()})
+    Ps = OS.make_params(st)
+    OM.init_new_classifier(Ps, 2, 5)
+    return Ps, Pt
+
+
+def test_full_network_matches_reference():
+    g = load_golden("model_full.npz")
+    Ps, Pt = _student_teacher_params()
+    img = synth.images(500, 2, 65)
+    with torch.no_grad():
+        lt, ft = OM.segmentation_forward(img, Pt, 1, training=False)
+        np.testing.assert_allclose(ft["sem"].numpy(), g["teacher_sem"], rtol=2e-4, atol=2e-4)
+        assert lt.double().abs().sum().item() == pytest.approx(float(g["teacher_logits_abs"]), rel=1e-4)
+        assert ft["pre_logits"].double().abs().sum().item() == pytest.approx(float(g["teacher_pl_abs"]), rel=1e-4)
+        assert ft["body"].double().abs().sum().item() == pytest.approx(float(g["teacher_body_abs"]), rel=1e-4)
+        ls_eval, fs_eval = OM.segmentation_forward(img, Ps, 2, training=False)
+        np.testing.assert_allclose(fs_eval["sem"].numpy(), g["student_eval_sem"], rtol=2e-4, atol=2e-4)
+        ls, fs = OM.segmentation_forward(img, Ps, 2, training=True)
+    np.testing.assert_allclose(fs["sem"].numpy(), g["student_train_sem"], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(ls.flatten()[g["sample_idx"]].numpy(), g["student_train_logits_sample"], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(Ps["cls.1.bias"].detach().numpy(), g["new_head_bias"], rtol=1e-6)
+    assert Ps["cls.0.bias"][0].item() == pytest.approx(float(g["head0_bias0"]), rel=1e-6)
+
+
+def test_ucd_step_matches_reference():
+    g = load_golden("ucd_step.npz")
+    Ps, Pt = _student_teacher_params()
+    img = synth.images(501, 2, 129)
+    labels = synth.seg_labels(501, 2, 129, 129, range(16, 21))
+    r = OS.ucd_losses(Ps, Pt, img, labels, [16, 5])
+    assert r["A"] == int(g["A"]) and r["C"] == int(g["C"])
+    assert r["ce"].item() == pytest.approx(float(g["ce"]), rel=1e-4)
+    assert r["con"].item() == pytest.approx(float(g["con"]), rel=1e-4)
+    assert r["loss"].item() == pytest.approx(float(g["loss"]), rel=1e-4)
+    assert r["lkd"].item() == pytest.approx(float(g["lkd"]), rel=1e-4)
+    (r["loss"] + r["lkd"]).backward()
+    names = [k.split("::")[1] for k in g if k.startswith("grad_abs::")]
+    for n in names:
+        gr = Ps[n].grad
+        assert gr.double().abs().sum().item() == pytest.approx(float(g[f"grad_abs::{n}"]), rel=2e-3), n
+    # one SGD step: three groups, momentum 0.9, nesterov, wd 1e-4, lr 1e-3; frozen cls.0
+    groups = []
+    for pre in ("body.", "head.", "cls."):
+        ps = [v for k, v in Ps.items() if k.startswith(pre) and v.requires_grad and not k.startswith("cls.0.")]
+        groups.append({"params": ps, "weight_decay": 1e-4})
+    opt = torch.optim.SGD(groups, lr=1e-3, momentum=0.9, nesterov=True)
+    opt.step()
+    for n in names:
+        np.testing.assert_allclose(Ps[n].detach().flatten()[:16].numpy(), g[f"after_step::{n}"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(Ps["body.mod1.bn1.running_mean"].numpy(), g["running_mean_after"], rtol=1e-5, atol=1e-6)

@@ -1,0 +1,79 @@
+"""ResNet body of the segmentation network (ResNet-101 at output stride 16 on the hot path).
+
+Mirror of the reference's ``models/resnet.py:11-136``: ``mod1`` = 7x7/2 conv + ABN + 3x3/2 max
+pool, ``mod2..mod5`` = stacks of :class:`~ucd_amd.blocks.ResidualBlock`; the output stride is
+reached by trading the stride of the last one (OS16) or two (OS8) stages for dilation
+(``resnet.py:48-51,97-101``).  Module names (``mod1.conv1``, ``mod3.block2.convs.bn1`` ...)
+are the reference's, so its pretrained files and step checkpoints load unchanged.
+"""
+from __future__ import annotations
+
+import sys
+from collections import OrderedDict
+from functools import partial
+
+import torch.nn as nn
+
+from .blocks import ResidualBlock, try_index
+
+_STAGE_DILATION = {16: (1, 1, 1, 2), 8: (1, 1, 2, 4)}
+
+
+class GlobalAvgPool2d(nn.Module):
+    """[B, C, H, W] -> [B, C] (reference ``modules/misc.py:4-12``); classifier variant only."""
+
+    def forward(self, inputs):
+        return inputs.flatten(2).mean(dim=2)
+
+
+class ResNet(nn.Module):
+    def __init__(self, structure, bottleneck, norm_act=nn.BatchNorm2d, classes=0,
+                 output_stride=16, keep_outputs=False):
+        super().__init__()
+        if len(structure) != 4:
+            raise ValueError("Expected a structure with four values")
+        if output_stride not in _STAGE_DILATION:
+            raise ValueError("Output stride must be 8 or 16")
+        self.structure, self.bottleneck, self.keep_outputs = structure, bottleneck, keep_outputs
+        self.dilation = dilation = list(_STAGE_DILATION[output_stride])
+
+        stem = [("conv1", nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)), ("bn1", norm_act(64))]
+        if try_index(dilation, 0) == 1:
+            stem.append(("pool1", nn.MaxPool2d(3, stride=2, padding=1)))
+        self.mod1 = nn.Sequential(OrderedDict(stem))
+
+        width = (64, 64, 256) if bottleneck else (64, 64)
+        cin = 64
+        for stage, depth in enumerate(structure):
+            d = try_index(dilation, stage)
+            blocks = OrderedDict()
+            for b in range(depth):
+                # a stage downsamples in its first block unless it is dilated (or is the first)
+                stride = 2 if (d == 1 and b == 0 and stage > 0) else 1
+                blocks[f"block{b + 1}"] = ResidualBlock(cin, width, norm_act=norm_act, stride=stride, dilation=d)
+                cin = width[-1]
+            self.add_module(f"mod{stage + 2}", nn.Sequential(blocks))
+            width = tuple(2 * c for c in width)
+        self.out_channels = cin
+
+        if classes != 0:
+            self.classifier = nn.Sequential(OrderedDict(
+                [("avg_pool", GlobalAvgPool2d()), ("fc", nn.Linear(cin, classes))]))
+
+    def forward(self, x):
+        outs = [self.mod1(x)]
+        for name in ("mod2", "mod3", "mod4", "mod5"):
+            outs.append(getattr(self, name)(outs[-1]))
+        if hasattr(self, "classifier"):
+            outs.append(self.classifier(outs[-1]))
+        return outs if self.keep_outputs else outs[-1]
+
+
+_NETS = {
+    "18": ([2, 2, 2, 2], False), "34": ([3, 4, 6, 3], False), "50": ([3, 4, 6, 3], True),
+    "101": ([3, 4, 23, 3], True), "152": ([3, 8, 36, 3], True),
+}
+__all__ = ["ResNet"]
+for _n, (_s, _b) in _NETS.items():
+    setattr(sys.modules[__name__], f"net_resnet{_n}", partial(ResNet, structure=_s, bottleneck=_b))
+    __all__.append(f"net_resnet{_n}")

@@ -1,0 +1,194 @@
+"""Bottleneck residual block and DeepLab-V3 ASPP head of the UCD student / teacher.
+
+Host-side mirror of the reference's ``modules/residual.py:7-98`` (``ResidualBlock``) and
+``modules/deeplab.py:8-89`` (``DeeplabV3``): same constructor arguments, same sub-module
+names (so ``state_dict`` keys are interchangeable with reference checkpoints), same
+arithmetic.  What differs is where the HBM-bound glue runs.  When the ``norm_act`` modules
+are this package's HIP ABN (``ucd_amd.abn``), the block epilogue
+``bn3 -> + residual -> leaky_relu`` (``residual.py:84-97``) and the head's
+``cat -> map_bn`` / ``out += pool -> red_bn`` (``deeplab.py:56-69``) are single fused
+kernels:
+
+* ``bn3`` normalises, adds the shortcut and applies the block activation in one pass;
+* ``map_bn`` runs per 256-channel branch and writes straight into its channel slice of the
+  1024-wide ``red_conv`` input, so the concatenation is never materialised;
+* the image-level pooling branch enters ``red_bn`` as a per-(image, channel) bias, so the
+  ``repeat`` + ``+=`` over the full map never happens.
+
+With any other ``norm_act`` (e.g. a stock BatchNorm shim in the CPU tests) the same modules
+fall back to the literal op sequence of the reference.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def try_index(scalar_or_list, i):
+    """``x[i]`` when indexable, else ``x`` (reference ``models/util.py:1-5``)."""
+    try:
+        return scalar_or_list[i]
+    except TypeError:
+        return scalar_or_list
+
+
+def _is_fused_abn(m) -> bool:
+    return getattr(m, "ucd_fused_abn", False)
+
+
+def _apply_act(x, activation, param):
+    if activation == "leaky_relu":
+        return F.leaky_relu(x, negative_slope=param, inplace=True)
+    if activation == "elu":
+        return F.elu(x, alpha=param, inplace=True)
+    if activation == "identity":
+        return x
+    raise RuntimeError(f"unknown activation {activation!r}")
+
+
+class ResidualBlock(nn.Module):
+    """``channels`` of length 3 -> bottleneck 1x1 / 3x3(stride, dilation) / 1x1, length 2 -> basic
+    3x3 / 3x3.  The last norm of the block is created like the others and then switched to
+    ``activation = "identity"`` (reference ``residual.py:52,65``); the projection shortcut exists
+    when the stride or the channel count changes (``residual.py:48,79-82``).
+    """
+
+    def __init__(self, in_channels, channels, stride=1, dilation=1, groups=1,
+                 norm_act=nn.BatchNorm2d, dropout=None):
+        super().__init__()
+        if len(channels) not in (2, 3):
+            raise ValueError("channels must contain either two or three values")
+        if len(channels) == 2 and groups != 1:
+            raise ValueError("groups > 1 are only valid if len(channels) == 3")
+
+        def conv(cin, cout, k, s=1, g=1):
+            pad = dilation if k == 3 else 0
+            return nn.Conv2d(cin, cout, k, stride=s, padding=pad, dilation=dilation if k == 3 else 1,
+                             groups=g, bias=False)
+
+        if len(channels) == 3:
+            spec = [(1, 1, 1), (3, stride, groups), (1, 1, 1)]
+        else:
+            spec = [(3, stride, 1), (3, 1, 1)]
+        layers, cin = [], in_channels
+        for i, ((k, s, g), cout) in enumerate(zip(spec, channels), 1):
+            layers.append((f"conv{i}", conv(cin, cout, k, s, g)))
+            layers.append((f"bn{i}", norm_act(cout)))
+            if dropout is not None and i == len(spec) - 1:
+                layers.append(("dropout", dropout()))
+            cin = cout
+        layers[-1][1].activation = "identity"
+        self.convs = nn.Sequential(OrderedDict(layers))
+        self._last_bn = f"bn{len(spec)}"
+
+        if stride != 1 or in_channels != channels[-1]:
+            self.proj_conv = nn.Conv2d(in_channels, channels[-1], 1, stride=stride, padding=0, bias=False)
+            self.proj_bn = norm_act(channels[-1])
+            self.proj_bn.activation = "identity"
+
+    def forward(self, x):
+        if hasattr(self, "proj_conv"):
+            residual = self.proj_bn(self.proj_conv(x))
+        else:
+            residual = x
+        act, slope = self.convs.bn1.activation, self.convs.bn1.activation_param
+        last = getattr(self.convs, self._last_bn)
+        if _is_fused_abn(last) and last.activation == "identity" and act in ("leaky_relu", "identity"):
+            # fused epilogue: act(bn(conv_out) + residual) in one HBM pass
+            h = x
+            for name, mod in self.convs.named_children():
+                if mod is last:
+                    h = mod(h, residual=residual, activation=act, activation_param=slope)
+                else:
+                    h = mod(h)
+            return h
+        return _apply_act(self.convs(x) + residual, act, slope)
+
+
+class DeeplabV3(nn.Module):
+    """ASPP head: four parallel 2048->256 convs (1x1 and 3x3 with dilation 6/12/18 at output
+    stride 16, 12/24/32 at 8), ABN over the 1024 concatenated channels, 1x1 reduction, plus the
+    image-level pooling branch added before the last ABN (reference ``deeplab.py:54-70``).
+    """
+
+    def __init__(self, in_channels, out_channels, hidden_channels=256, out_stride=16,
+                 norm_act=nn.BatchNorm2d, pooling_size=None):
+        super().__init__()
+        self.pooling_size = pooling_size
+        if out_stride == 16:
+            dilations = (6, 12, 18)
+        elif out_stride == 8:
+            dilations = (12, 24, 32)
+        else:
+            raise ValueError("out_stride must be 8 or 16")
+        self.hidden_channels = hidden_channels
+
+        branches = [nn.Conv2d(in_channels, hidden_channels, 1, bias=False)]
+        branches += [nn.Conv2d(in_channels, hidden_channels, 3, bias=False, dilation=d, padding=d)
+                     for d in dilations]
+        self.map_convs = nn.ModuleList(branches)
+        self.map_bn = norm_act(hidden_channels * len(branches))
+
+        self.global_pooling_conv = nn.Conv2d(in_channels, hidden_channels, 1, bias=False)
+        self.global_pooling_bn = norm_act(hidden_channels)
+
+        self.red_conv = nn.Conv2d(hidden_channels * len(branches), out_channels, 1, bias=False)
+        self.pool_red_conv = nn.Conv2d(hidden_channels, out_channels, 1, bias=False)
+        self.red_bn = norm_act(out_channels)
+
+        self.reset_parameters(self.map_bn.activation, self.map_bn.activation_param)
+
+    def reset_parameters(self, activation, slope):
+        """Xavier-normal conv weights with the activation's gain, unit/zero affine norms
+        (reference ``deeplab.py:41-52``)."""
+        gain = nn.init.calculate_gain(activation, slope)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.xavier_normal_(m.weight.data, gain)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d) or _is_fused_abn(m):
+                if getattr(m, "weight", None) is not None:
+                    nn.init.constant_(m.weight, 1)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    # -- image-level pooling -----------------------------------------------------------------
+    def _global_pooling(self, x):
+        if self.training or self.pooling_size is None:
+            # training: plain global average -> [B, C, 1, 1]
+            if _is_fused_abn(self.red_bn):
+                from . import abn as _abn
+                return _abn.global_avg_pool(x)
+            return x.flatten(2).mean(dim=-1)[:, :, None, None]
+        # evaluation: sliding average of (at most) pooling_size, stride 1, then replicate-pad
+        # back to the input size (reference deeplab.py:77-88)
+        ph = min(try_index(self.pooling_size, 0), x.shape[2])
+        pw = min(try_index(self.pooling_size, 1), x.shape[3])
+        pad = ((pw - 1) // 2, (pw - 1) // 2 + (1 - pw % 2),
+               (ph - 1) // 2, (ph - 1) // 2 + (1 - ph % 2))
+        pool = F.avg_pool2d(x, (ph, pw), stride=1)
+        return F.pad(pool, pad=pad, mode="replicate")
+
+    def forward(self, x):
+        fused = _is_fused_abn(self.map_bn) and _is_fused_abn(self.red_bn)
+        if fused:
+            # each branch is normalised on its own channel slice and lands in the shared
+            # 1024-channel buffer that red_conv reads: no cat
+            out = self.map_bn.forward_branches([m(x) for m in self.map_convs])
+        else:
+            out = self.map_bn(torch.cat([m(x) for m in self.map_convs], dim=1))
+        out = self.red_conv(out)
+
+        pool = self._global_pooling(x)
+        pool = self.pool_red_conv(self.global_pooling_bn(self.global_pooling_conv(pool)))
+        if fused and pool.shape[-2:] == (1, 1):
+            # per-(image, channel) bias folded into red_bn's statistics and apply passes
+            return self.red_bn(out, plane_bias=pool)
+        if pool.shape[-2:] == (1, 1):
+            pool = pool.expand(-1, -1, x.size(2), x.size(3))
+        out = out + pool
+        return self.red_bn(out)
