@@ -1,0 +1,211 @@
+/*
+ * ucd_hip.h - C ABI of libucd_hip.so: the MI355X (gfx950) kernels of the UCD train-step hot path.
+ *
+ * The reference (ygjwd12345/UCD) has no FFI layer of its own: its native work enters through the
+ * third-party wheels inplace-abn / apex and through ~40 stock PyTorch kernels per loss.  Each entry
+ * point below names the reference call site (file:line under the reference tree) whose device work
+ * it replaces; INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch); nothing is allocated, freed or
+ *     retained past the call; workspaces are caller-provided and sized by the *_workspace_bytes calls;
+ *   - every call is asynchronous on the given hipStream_t (passed as void*), re-entrant, and makes
+ *     no host synchronisation (data-dependent sizes such as the anchor count stay on the device);
+ *   - return 0 on success, a negative UCD_E* code for argument errors, or the positive hipError_t of
+ *     a failed launch; ucd_last_error() returns the thread-local message; no C++ exception crosses;
+ *   - activations ("act" tensors) are channels-last: a [B,C,H,W] map is the row-major matrix
+ *     [M = B*H*W rows][C channels] with a leading dimension `ld` in ELEMENTS (ld >= C, so a channel
+ *     slice of a wider buffer can be addressed); dtype is UCD_F32 or UCD_BF16; base pointers and
+ *     ld*sizeof(elem) must be 16-byte aligned and C a multiple of 16/sizeof(elem);
+ *   - per-channel parameters and statistics are float32.
+ */
+#ifndef UCD_HIP_H
+#define UCD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCD_VERSION 100 /* 0.1.0 */
+
+typedef void* ucd_stream_t; /* hipStream_t */
+
+enum ucd_dtype { UCD_F32 = 0, UCD_BF16 = 1 };
+enum ucd_act { UCD_ACT_IDENTITY = 0, UCD_ACT_LEAKY_RELU = 1 };
+enum ucd_error {
+  UCD_OK = 0,
+  UCD_EINVAL = -1,      /* bad argument (null pointer, negative size, unknown enum) */
+  UCD_EALIGN = -2,      /* pointer / leading dimension / channel count not 16-byte friendly */
+  UCD_EWORKSPACE = -3,  /* workspace too small */
+  UCD_EUNSUPPORTED = -4 /* shape outside what the kernels are built for */
+};
+
+int ucd_version(void);
+const char* ucd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * ABN: fused BatchNorm + LeakyReLU(slope) / identity.  Replaces the inplace-abn==1.0.7 CUDA extension
+ * behind every norm_act(...) instance: models/resnet.py:60, modules/residual.py:51,56,64,68,71,81,
+ * modules/deeplab.py:30,33,37 (selected at segmentation_module.py:15-20), plus the glue the reference
+ * runs as separate kernels around it: residual add + activation (modules/residual.py:90-97), channel
+ * concatenation (modules/deeplab.py:56) and the pooled-branch broadcast add (modules/deeplab.py:65-68).
+ *
+ *   z = (x [+ plane_bias[b, c]]) * scale[c] + shift[c] [+ residual]      y = act(z)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* bytes of scratch needed by ucd_abn_stats / ucd_abn_bwd_reduce for an [M, C] map */
+size_t ucd_abn_workspace_bytes(int M, int C);
+
+/* Per-channel sums over the M rows: sums[0:C] = sum x', sums[C:2C] = sum x'^2 with
+ * x' = x + plane_bias[row / HW, c] (plane_bias may be NULL).  Deterministic two-stage reduction. */
+int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C,
+                  const float* plane_bias, int HW,
+                  float* sums /* [2*C] */, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* Batch statistics -> affine form.  count = rows behind `sums` (after a cross-rank all-reduce of
+ * sums: the global count).  mean = s/n, var = ss/n - mean^2 (biased), invstd = rsqrt(var + eps);
+ * running_mean/var are updated in place with `momentum` (unbiased variance) unless NULL;
+ * scale = weight * invstd, shift = bias - mean * scale.  weight/bias NULL mean 1 / 0. */
+int ucd_abn_finalize(const float* sums, float count, int C,
+                     const float* weight, const float* bias,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     float* mean, float* invstd, float* scale, float* shift, ucd_stream_t stream);
+
+/* Evaluation-mode affine form from the running statistics (teacher; --fix_bn). */
+int ucd_abn_eval_params(const float* weight, const float* bias, const float* running_mean,
+                        const float* running_var, float eps, int C,
+                        float* scale, float* shift, ucd_stream_t stream);
+
+/* y = act((x + plane_bias) * scale + shift + residual); y may alias x (in place) or be a channel
+ * slice of a wider buffer (ld_y > C).  residual / plane_bias may be NULL. */
+int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r,
+                  int dtype, int M, int C, const float* plane_bias, int HW,
+                  const float* scale, const float* shift, int act, float slope, ucd_stream_t stream);
+
+/* Backward, stage 1: dz = dy * act'(z) and the two per-channel sums
+ *   sums[0:C] = sum dz            (= d bias)
+ *   sums[C:2C] = sum dz * xhat    (= d weight),   xhat = (x' - mean) * invstd.
+ * The sign of z is taken from y when y != NULL (needed when a residual was fused), else z is
+ * recomputed from x. */
+int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
+                       int dtype, int M, int C, const float* plane_bias, int HW,
+                       const float* mean, const float* invstd, const float* scale, const float* shift,
+                       int act, float slope,
+                       float* sums /* [2*C] */, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* Backward, stage 2: dx = (dz - sums[0]/count - xhat * sums[1]/count) * weight * invstd
+ * (training statistics) or dx = dz * scale when frozen != 0 (running statistics).  dz_out, when not
+ * NULL, receives dz (the gradient of the fused residual input).  dx may alias dy. */
+int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
+                      void* dx, int ld_dx, void* dz_out, int ld_dz,
+                      int dtype, int M, int C, const float* plane_bias, int HW,
+                      const float* mean, const float* invstd, const float* scale, const float* shift,
+                      const float* weight, const float* sums, float count, int frozen,
+                      int act, float slope, ucd_stream_t stream);
+
+/* Per-(image, channel) reduction over the HW rows of each image: out[b, c] = alpha * sum_hw x.
+ * Global average pooling of the ASPP image-level branch (modules/deeplab.py:72-76) with alpha = 1/HW,
+ * and the gradient of a plane_bias (sum of dz over the plane) with alpha = 1. */
+int ucd_plane_sum(const void* x, int ld_x, int dtype, int B, int HW, int C, float alpha,
+                  float* out /* [B, C] */, ucd_stream_t stream);
+
+/* Spatial attention map (segmentation_module.py:86-94): a[b,p] = sum_c x^2, normalised per image by
+ * its Frobenius norm; y = a * x.  workspace: B*HW + B floats. */
+size_t ucd_attmap_workspace_bytes(int B, int HW);
+int ucd_attmap(const void* x, int ld_x, void* y, int ld_y, int dtype, int B, int HW, int C,
+               void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Uncertainty-weighted pixel-contrastive distillation.  Replaces pre_contractive_pixel
+ * (utils/utils.py:256-393; twin utils/loss.py:258-395) and PixelConLossV2.forward
+ * (utils/loss.py:412-466) - and, with shift_pos = 0, no teacher and no joint-probability weight,
+ * PixelConLoss.forward of the dead file utils/loss_new.py:359-400.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Device-resident description of one batch's anchor / contrast sets, written by ucd_pixcon_prep and
+ * read by the loss kernels (the host never needs it; tests copy it back). */
+typedef struct ucd_pixcon_meta {
+  int32_t A;        /* anchors: pixels with mixed label > 0                      (utils.py:358) */
+  int32_t Co;       /* teacher-only contrast rows: kept pixels that are not new (utils.py:359) */
+  int32_t min_new;  /* smallest down-sampled ground-truth label > 0              (utils.py:353) */
+  int32_t n_new;    /* pixels with a ground-truth (new-class) label              (utils.py:352) */
+  int32_t Apad;     /* A rounded up to the contrast tile (row offset of the teacher segment) */
+  int32_t Cpad;     /* Apad + Co rounded up to the tile: rows of the contrast matrix */
+  int32_t n_valid;  /* anchors with at least one positive (rows of the final mean, loss.py:465) */
+  int32_t sorted;   /* rows grouped by label (sort_by_label) */
+  /* with sorted != 0: rows [label_start_a[L], label_start_a[L+1]) of the anchor segment and rows
+     Apad + [label_start_o[L], label_start_o[L+1]) of the teacher segment carry label L */
+  int32_t label_start_a[257];
+  int32_t label_start_o[257];
+  int32_t label_count_a[256]; /* anchors per label */
+  int32_t label_count_c[256]; /* contrast rows per label (anchors + teacher rows): num_i + 1 */
+  int32_t reserved[2];
+} ucd_pixcon_meta;
+
+size_t ucd_pixcon_prep_workspace_bytes(int BHW, int K);
+
+/* Stage 1 (utils/utils.py:264-268,352-359,367-371): per low-resolution pixel p of the [B,h,w] grid
+ *   label_ds = trunc(bilinear(labels)) kept when in [0, max_label] else 0   (bit-exact float32
+ *              arithmetic of torch's one-channel bilinear kernel, align_corners = False);
+ *   mix      = label_ds, or the teacher arg-max where label_ds == 0;
+ *   keep     = mix > 0;  keep_o = keep && label_ds == 0;
+ * then order-preserving stream compaction.  sort_by_label != 0 additionally groups anchors and
+ * teacher rows by label (stable), which is what the fused loss wants; 0 keeps the reference's pixel
+ * order.  Outputs (all device):
+ *   anchor_pix[BHW], old_pix[BHW]  : pixel index of anchor row r / teacher row r
+ *   row_label[2*BHW + 2*tile]      : label of contrast row r (anchors first, teacher rows from
+ *                                    meta->Apad), 255 for padding rows
+ *   prob[BHW, K]                   : softmax of the teacher logits per pixel (float32)
+ *   meta                           : counts, see above
+ * teacher_logits is the [B*h*w, K] channels-last low-resolution teacher output ("sem",
+ * segmentation_module.py:136) in float32 or bf16 with leading dimension ld_t. */
+int ucd_pixcon_prep(const int64_t* labels, int B, int H, int W, int h, int w, int max_label,
+                    const void* teacher_logits, int ld_t, int dtype_t, int K, int sort_by_label,
+                    int32_t* anchor_pix, int32_t* old_pix, uint8_t* row_label, float* prob,
+                    ucd_pixcon_meta* meta, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* Stage 2 (utils/utils.py:361-364,372-375): gather the kept rows of the student (anchors) and teacher
+ * (teacher-only rows) pre-logit maps, L2-normalise each row (F.normalize, eps 1e-12) and write the
+ * contrast matrix chat[Cpad, ldc] (float32): rows [0, A) anchors, [Apad, Apad+Co) teacher rows,
+ * zeros elsewhere (also columns N..ldc); inv_norm[r] = 1 / max(||row||, eps) for the anchors (needed
+ * by the backward).  When pcat != NULL the teacher probabilities of the same pixels are gathered in
+ * the same row order into pcat[Cpad, ldp] (columns K..ldp zero).
+ * f_n / f_o are [B*h*w, N] channels-last maps (float32 or bf16). */
+int ucd_pixcon_gather(const void* f_n, int ld_n, const void* f_o, int ld_o, int dtype, int BHW, int N,
+                      const int32_t* anchor_pix, const int32_t* old_pix, const float* prob, int K,
+                      const ucd_pixcon_meta* meta, float* chat, int ldc, float* pcat, int ldp,
+                      float* inv_norm, ucd_stream_t stream);
+
+size_t ucd_pixcon_loss_workspace_bytes(int BHW, int N, int K);
+
+/* Loss and its gradient w.r.t. the normalised anchors in one launch sequence (utils/loss.py:435-466):
+ *   S_ij = a_i . c_j / T;  neg_i = sum_j [la_i != lc_j] exp(S_ij)                     (un-shifted)
+ *   m_i = max_j S_ij (shift_pos != 0) or 0;  S' = S - m_i;  pos_ij = [la_i == lc_j] - [j == i]
+ *   P_ij = 1 when use_prob == 0 or (la_i >= min_new and lc_j >= min_new), else p_i . p_j
+ *   loss = mean_{i: num_i != 0} ( - sum_j pos_ij P_ij (S'_ij - log(exp S'_ij + neg_i)) / num_i )
+ *   grad_a[i, :] = d loss / d a_i  (closed form); grad_a may be NULL.
+ * chat [Cpad, ldc] / pcat [Cpad, ldp] / row_label are the outputs of ucd_pixcon_prep + ucd_pixcon_gather
+ * (ldc must be 256: feature rows zero-padded to 256 columns; ldp >= K rounded up to even).
+ * loss_out[0] = loss, loss_out[1] = number of valid rows.  row_stats (optional, [3, BHW]) receives
+ * neg_i, num_i and the per-row loss for inspection.  float32 MFMA arithmetic throughout. */
+int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label,
+                    const float* pcat, int ldp, int K, const ucd_pixcon_meta* meta, int BHW,
+                    float temperature, int shift_pos, int use_prob,
+                    float* loss_out, float* grad_a /* [BHW, ldg] */, int ldg, float* row_stats,
+                    void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* Chain rule through F.normalize and scatter to the student map:
+ *   d f_n[pix(r), :] = grad_scale[0] * inv_norm[r] * (g_r - (g_r . a_r) a_r),  zero for unkept pixels.
+ * grad_scale is a device scalar (the upstream gradient of the loss).  d_f_n has dtype `dtype`. */
+int ucd_pixcon_scatter_grad(const float* grad_a, const float* chat, int ldc, const float* inv_norm,
+                            const int32_t* anchor_pix, const ucd_pixcon_meta* meta,
+                            const float* grad_scale, void* d_f_n, int ld_d, int dtype, int BHW, int N,
+                            ucd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCD_HIP_H */

@@ -1,0 +1,153 @@
+"""GPU parity tests proper: the HIP contrastive path, called through the C ABI, against the pinned CPU
+oracle on the same seeded inputs and against the golden vectors captured from the reference.
+Bars: labels / counts / index sets bit-exact; float32 loss and gradients within 1e-3 relative
+(north_star), in practice ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_matches_compact, load_golden
+from oracle import contrastive as OC
+from ucd_amd import synth
+
+pytestmark = pytest.mark.gpu
+PIXCON = ["voc_15_5", "city_13_6", "voc_15_5s_step2", "voc_19_1_odd"]
+
+
+def _case(g):
+    cfg = [int(v) for v in g["cfg"]]
+    seed, B, N, h, w, K, H, W = cfg[:8]
+    return synth.contrastive_case(seed, B, N, h, w, K, H, W, cfg[8:])
+
+
+def _to_dev(*ts):
+    dev = torch.device("cuda:0")
+    return [t.to(dev) for t in ts]
+
+
+@pytest.mark.parametrize("name", PIXCON)
+def test_reference_shaped_api_matches_golden(name):
+    """pre_contractive_pixel -> (a, c, la, lc, P) in the reference's order; PixelConLossV2 on it."""
+    from ucd_amd.contrastive import PixelConLossV2, pre_contractive_pixel
+    g = load_golden(f"pixcon_{name}.npz")
+    f_n, f_o, l_po, labels = _case(g)
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    fn_d = fn_d.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    tup = pre_contractive_pixel(fn_d, lab_d, l_po=lpo_d, f_o=fo_d)
+    a, c, la, lc, P = tup
+    assert a.shape[0] == int(g["A"]) and c.shape[0] == int(g["C"])
+    np.testing.assert_array_equal(la.cpu().numpy(), g["la"])           # bit-exact integer work
+    np.testing.assert_array_equal(lc.cpu().numpy(), g["lc"])
+    assert_matches_compact(g, "a", a.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert_matches_compact(g, "c", c.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert_matches_compact(g, "P", P.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    loss = PixelConLossV2(temperature=0.07)(tup)
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-3)
+    assert abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])) < 1e-4
+    loss.backward()
+    assert_matches_compact(g, "grad_f_n", fn_d.grad.cpu().numpy(), rtol=1e-3, atol=1e-7)
+    # P = None variant
+    tup2 = pre_contractive_pixel(fn_d.detach(), lab_d, l_po=lpo_d, f_o=fo_d)
+    l2 = PixelConLossV2(temperature=0.07)(tup2[0], tup2[1], tup2[2], tup2[3], None, batch=tup2.batch)
+    assert l2.item() == pytest.approx(float(g["loss_noP"]), rel=1e-4)
+
+
+@pytest.mark.parametrize("name", PIXCON)
+def test_fused_loss_matches_oracle_and_golden(name):
+    """The fused trainer path (rows grouped by label, positives-only second sweep)."""
+    from ucd_amd.contrastive import ucd_contrastive_loss
+    g = load_golden(f"pixcon_{name}.npz")
+    f_n, f_o, l_po, labels = _case(g)
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    fn_d = fn_d.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    loss = ucd_contrastive_loss(fn_d, lab_d, lpo_d, fo_d, 0.07, 20)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])) < 1e-4
+    assert_matches_compact(g, "grad_f_n", fn_d.grad.cpu().numpy(), rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,N,h,K,H,new_ids,max_label", [
+    (3, 256, 33, 16, 513, list(range(16, 21)), 20),      # VOC 15-5 per-rank shape of the 8-GPU config
+    (2, 256, 16, 14, 256, list(range(14, 20)), 20),      # Cityscapes-like
+    (2, 64, 12, 101, 192, list(range(101, 151)), 150),   # ADE: labels beyond int8's 20-clamp (generalised bound)
+    (2, 32, 9, 16, 129, [16], 20),
+])
+def test_prep_and_loss_vs_oracle(B, N, h, K, H, new_ids, max_label):
+    from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare, ucd_contrastive_loss
+    f_n, f_o, l_po, labels = synth.contrastive_case(1000 + N + h, B, N, h, h, K, H, H, new_ids)
+    ref_in = f_n.clone().requires_grad_(True)
+    prep = OC.pre_contrastive_pixel(ref_in, labels, l_po, f_o, max_label=max_label)
+    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    ref.backward()
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    fn_d = fn_d.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    # integer side, unsorted order == oracle order
+    pb = pixcon_prepare(fn_d.detach(), lab_d, lpo_d, fo_d, max_label=max_label, sort_by_label=False)
+    m = pb.meta_host()
+    assert (m.A, m.Co, m.min_new) == (int(prep["keep"].sum()), int(prep["keep_o"].sum()), prep["min_new"])
+    keep_idx = torch.nonzero(prep["keep"])[:, 0].int()
+    old_idx = torch.nonzero(prep["keep_o"])[:, 0].int()
+    assert torch.equal(pb.anchor_pix[:m.A].cpu(), keep_idx)
+    assert torch.equal(pb.old_pix[:m.Co].cpu(), old_idx)
+    assert torch.equal(pb.row_label[:m.A].cpu().long(), prep["la"])
+    assert torch.equal(pb.row_label[m.Apad:m.Apad + m.Co].cpu().long(), prep["lc"][m.A:])
+    assert m.n_valid == int(((prep["la"].view(-1, 1) == prep["lc"].view(1, -1)).sum(1) - 1 > 0).sum())
+    torch.testing.assert_close(pb.pcat[:m.A, :K].cpu(), prep["pa"], rtol=1e-5, atol=1e-7)
+    # sorted order: same sets, grouped by label, stable
+    pbs = pixcon_prepare(fn_d.detach(), lab_d, lpo_d, fo_d, max_label=max_label, sort_by_label=True)
+    ms = pbs.meta_host()
+    order = torch.argsort(prep["la"], stable=True)
+    assert torch.equal(pbs.anchor_pix[:ms.A].cpu(), keep_idx[order])
+    assert torch.equal(pbs.row_label[:ms.A].cpu().long(), prep["la"][order])
+    # row statistics and loss, both orders
+    for batch in (pb, pbs):
+        loss_out, grad_a, stats = pixcon_loss_raw(batch, 0.07, True, True, need_grad=True, row_stats=True)
+        assert abs(loss_out[0].item() - ref.item()) / abs(ref.item()) < 1e-4
+        assert int(loss_out[1].item()) == m.n_valid
+    _, da, neg, G, num = OC.pixcon_loss_backward(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    loss_out, grad_a, stats = pixcon_loss_raw(pb, 0.07, True, True, need_grad=True, row_stats=True)
+    torch.testing.assert_close(stats[0, :m.A].cpu().double(), neg, rtol=1e-4, atol=0)
+    torch.testing.assert_close(stats[1, :m.A].cpu().double(), num, rtol=0, atol=0)
+    torch.testing.assert_close(grad_a[:m.A, :N].cpu().double(), da, rtol=1e-3, atol=1e-9)
+    # end to end through autograd
+    loss = ucd_contrastive_loss(fn_d, lab_d, lpo_d, fo_d, 0.07, max_label)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-4
+    scale = ref_in.grad.abs().max().item()
+    assert (fn_d.grad.cpu() - ref_in.grad).abs().max().item() / scale < 1e-3
+
+
+def test_label_downsample_bit_exact_full_size():
+    """513x513 -> 33x33 at batch 24 (BASELINE config 2): every down-sampled label equals torch's."""
+    from ucd_amd.contrastive import pixcon_prepare
+    B, H, h, K = 24, 513, 33, 16
+    labels = synth.seg_labels(77, B, H, H, range(16, 21))
+    ds = OC.downsample_labels(labels, h, h, 20)
+    dev = torch.device("cuda:0")
+    f = torch.zeros(B, 32, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    lpo = torch.full((B, K, h, h), -5.0, device=dev)
+    lpo[:, 0] = 5.0                                   # teacher says background everywhere
+    pb = pixcon_prepare(f, labels.to(dev), lpo, f, max_label=20, sort_by_label=False)
+    m = pb.meta_host()
+    flat = ds.reshape(-1)
+    assert m.A == int((flat > 0).sum()) and m.Co == 0 and m.min_new == int(flat[flat > 0].min())
+    assert torch.equal(pb.anchor_pix[:m.A].cpu().long(), torch.nonzero(flat > 0)[:, 0])
+    assert torch.equal(pb.row_label[:m.A].cpu().long(), flat[flat > 0])
+
+
+def test_bf16_inputs_and_no_new_pixels():
+    from ucd_amd.contrastive import ucd_contrastive_loss
+    f_n, f_o, l_po, labels = synth.contrastive_case(5, 2, 256, 9, 9, 16, 129, 129, range(16, 21))
+    fb, fob = f_n.bfloat16(), f_o.bfloat16()
+    ref_in = fb.float().requires_grad_(True)
+    prep = OC.pre_contrastive_pixel(ref_in, labels, l_po, fob.float())
+    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    ref.backward()
+    dev = torch.device("cuda:0")
+    x = fb.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    loss = ucd_contrastive_loss(x, labels.to(dev), l_po.to(dev), fob.to(dev), 0.07, 20)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-4      # same bf16-rounded inputs, fp32 math
+    assert x.grad.dtype == torch.bfloat16
+    scale = ref_in.grad.abs().max().item()
+    assert (x.grad.float().cpu() - ref_in.grad).abs().max().item() / scale < 1e-2

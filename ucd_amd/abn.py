@@ -1,0 +1,283 @@
+"""ABN / InPlaceABN / InPlaceABNSync on the HIP kernels of ``libucd_hip.so``.
+
+Drop-in for the three classes the reference imports from the third-party ``inplace_abn`` wheel
+(``segmentation_module.py:5-6,15-20``): same constructor, same attributes (``weight``, ``bias``,
+``running_mean``, ``running_var``, mutable ``activation`` / ``activation_param``) and the same
+``state_dict`` keys, so the reference's pretrained files and step checkpoints load unchanged.
+
+MI355X design notes
+  * activations are channels-last ([B*H*W, C] rows; bf16 or fp32), statistics and parameters fp32;
+  * the "in-place" of inplace_abn is a memory trick for 16 GB cards: with 288 GB of HBM the training
+    forward keeps the pre-norm tensor and recomputes xhat from it in the backward (exact in bf16,
+    no division by gamma), at the same HBM traffic (2 reads per pass).  Under ``torch.no_grad()``
+    (the frozen teacher) InPlaceABN / InPlaceABNSync do overwrite their input, as their contract says;
+  * the block epilogue ``+ residual -> leaky_relu`` and the ASPP ``cat`` / ``+= pool`` ride in the
+    same passes (``forward(..., residual=)``, ``forward_branches``, ``forward(..., plane_bias=)``);
+  * InPlaceABNSync all-reduces one packed ``[sum, sum_sq, count]`` (forward) / ``[sum_dz, sum_dz_xhat]``
+    (backward) vector per layer over RCCL; without an initialised process group it is InPlaceABN.
+Semantics follow ``F.batch_norm`` + ``leaky_relu`` (biased batch variance, unbiased running variance,
+eps 1e-5, momentum 0.1); inplace_abn's ``abs(gamma) + eps`` re-parameterisation is not reproduced
+(its source is not in the reference tree; the two coincide for the positive gammas of the pretrained
+files - SURVEY.md section 8-a5).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import hip
+
+
+def _act_code(name):
+    try:
+        return hip.ACT_CODES[name]
+    except KeyError:
+        raise RuntimeError(f"activation {name!r} is not supported by the HIP ABN (leaky_relu, identity)") from None
+
+
+def _group_size(group):
+    if group is False or not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(group if group is not None else None)
+
+
+class _ABNFunction(torch.autograd.Function):
+    """y = act(BN(x [+ plane_bias]) [+ residual]) with batch (training) or running (eval) statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, plane_bias, running_mean, running_var, training, momentum, eps,
+                act, slope, group, out, inplace):
+        x_in = x
+        x, M, Cc, HW, ld_x = hip.rows_view(x)
+        dev = x.device
+        ld_r = 0
+        if residual is not None:
+            residual, _, _, _, ld_r = hip.rows_view(residual)
+        if plane_bias is not None:
+            plane_bias = plane_bias.reshape(x.shape[0], Cc).float().contiguous()
+        # [sums(2C) | pad | mean | invstd | scale | shift]
+        buf = torch.empty(6 * Cc + 1, dtype=torch.float32, device=dev)
+        sums, mean, invstd = buf[:2 * Cc], buf[2 * Cc + 1:3 * Cc + 1], buf[3 * Cc + 1:4 * Cc + 1]
+        scale, shift = buf[4 * Cc + 1:5 * Cc + 1], buf[5 * Cc + 1:]
+        world = 1
+        if training:
+            hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums)
+            world = _group_size(group)
+            if world > 1:   # equal shards on every rank (DistributedSampler with drop_last, run.py:147-149)
+                dist.all_reduce(sums, group=group if group is not None else None)
+            hip.abn_finalize(sums, float(M * world), Cc, weight, bias, running_mean, running_var, momentum, eps, mean,
+                             invstd, scale, shift)
+        else:
+            hip.abn_eval_params(weight, bias, running_mean, running_var, eps, Cc, scale, shift)
+            if weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+                mean.copy_(running_mean)                      # d weight under frozen statistics needs xhat
+                torch.rsqrt(running_var + eps, out=invstd)
+        count = float(M * world)
+        if out is not None:
+            y = out
+            y, _, _, _, ld_y = hip.rows_view(y)
+            if y.data_ptr() != out.data_ptr():
+                raise RuntimeError("ABN: `out` must be a channels-last tensor or channel slice")
+        elif inplace:
+            y, ld_y = x, ld_x
+        else:
+            y = hip.empty_like_rows(x)
+            ld_y = Cc
+        hip.abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, scale, shift, act, slope)
+        needs_y = residual is not None and act != hip.ACT_IDENTITY
+        ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, buf)
+        ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, residual is not None,
+                   plane_bias is not None, x.shape[0])
+        if y is x_in:
+            ctx.mark_dirty(x_in)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, plane_bias, weight, buf = ctx.saved_tensors
+        M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, has_res, has_pb, B = ctx.cfg
+        dy, _, _, _, ld_dy = hip.rows_view(dy if dy.dtype == x.dtype else dy.to(x.dtype))
+        mean, invstd = buf[2 * Cc + 1:3 * Cc + 1], buf[3 * Cc + 1:4 * Cc + 1]
+        scale, shift = buf[4 * Cc + 1:5 * Cc + 1], buf[5 * Cc + 1:]
+        sums = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+        need_param_grad = weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        if training or need_param_grad:
+            hip.abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y if y is not None else 0, M, Cc, plane_bias, HW, mean,
+                               invstd, scale, shift, act, slope, sums)
+        dbias = dweight = None
+        if need_param_grad:
+            dbias, dweight = sums[:Cc].clone(), sums[Cc:].clone()
+        if training and world > 1:
+            dist.all_reduce(sums, group=group if group is not None else None)
+        dx = hip.empty_like_rows(x)
+        dz = hip.empty_like_rows(x) if has_res else None
+        hip.abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y if y is not None else 0, dx, Cc, dz, Cc if has_res else 0, M, Cc,
+                          plane_bias, HW, mean, invstd, scale, shift, weight, sums, count, 0 if training else 1, act,
+                          slope)
+        dpb = None
+        if has_pb:
+            # plane_bias enters like x: its gradient is dx summed over each image plane
+            dpb = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+            hip.plane_sum(dx, Cc, B, HW, Cc, 1.0, dpb)
+            dpb = dpb.view(B, Cc, 1, 1)
+        return (dx, dweight, dbias, dz, dpb) + (None,) * 10
+
+
+class _ABNBranchesFunction(torch.autograd.Function):
+    """ABN over the channel concatenation of several maps, written branch by branch into one
+    [B, sum C_i, H, W] buffer (the concatenation of modules/deeplab.py:56 is never materialised)."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, running_mean, running_var, training, momentum, eps, act, slope, group, *xs):
+        n = len(xs)
+        views = [hip.rows_view(x) for x in xs]
+        x0, M, _, HW, _ = views[0]
+        chans = [v[2] for v in views]
+        Ct = sum(chans)
+        dev = x0.device
+        out = hip.empty_like_rows(x0, channels=Ct)
+        buf = torch.empty(6 * Ct + 1, dtype=torch.float32, device=dev)
+        sums, mean, invstd = buf[:2 * Ct], buf[2 * Ct + 1:3 * Ct + 1], buf[3 * Ct + 1:4 * Ct + 1]
+        scale, shift = buf[4 * Ct + 1:5 * Ct + 1], buf[5 * Ct + 1:]
+        world = _group_size(group) if training else 1
+        count = float(M * world)
+        offs, o = [], 0
+        for c in chans:
+            offs.append(o)
+            o += c
+        if training:
+            # per-branch [sum | sum_sq] blocks, laid out so that one all-reduce covers all branches
+            for (x, _, c, _, ld), o in zip(views, offs):
+                hip.abn_stats(x, ld, M, c, None, HW, sums[2 * o:2 * (o + c)])
+            if world > 1:
+                dist.all_reduce(sums, group=group if group is not None else None)
+        for (x, _, c, _, ld), o in zip(views, offs):
+            sl = slice(o, o + c)
+            w, b = (weight[sl], bias[sl]) if weight is not None else (None, None)
+            if training:
+                hip.abn_finalize(sums[2 * o:2 * (o + c)], count, c, w, b, running_mean[sl], running_var[sl], momentum,
+                                 eps, mean[sl], invstd[sl], scale[sl], shift[sl])
+            else:
+                hip.abn_eval_params(w, b, running_mean[sl], running_var[sl], eps, c, scale[sl], shift[sl])
+            hip.abn_apply(x, ld, out[:, sl], Ct, None, 0, M, c, None, HW, scale[sl], shift[sl], act, slope)
+        ctx.save_for_backward(weight, buf, *[v[0] for v in views])
+        ctx.cfg = (M, HW, chans, offs, [v[4] for v in views], training, act, slope, group, count, world)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, buf, *xs = ctx.saved_tensors
+        M, HW, chans, offs, lds, training, act, slope, group, count, world = ctx.cfg
+        Ct = sum(chans)
+        dy, _, _, _, ld_dy = hip.rows_view(dy if dy.dtype == xs[0].dtype else dy.to(xs[0].dtype))
+        mean, invstd = buf[2 * Ct + 1:3 * Ct + 1], buf[3 * Ct + 1:4 * Ct + 1]
+        scale, shift = buf[4 * Ct + 1:5 * Ct + 1], buf[5 * Ct + 1:]
+        sums = torch.empty(2 * Ct, dtype=torch.float32, device=dy.device)
+        if training:
+            for x, c, o, ld in zip(xs, chans, offs, lds):
+                sl = slice(o, o + c)
+                hip.abn_bwd_reduce(x, ld, dy[:, sl], ld_dy, None, 0, M, c, None, HW, mean[sl], invstd[sl], scale[sl],
+                                   shift[sl], act, slope, sums[2 * o:2 * (o + c)])
+        dweight = dbias = None
+        if training and weight is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            dbias = torch.cat([sums[2 * o:2 * o + c] for c, o in zip(chans, offs)])
+            dweight = torch.cat([sums[2 * o + c:2 * (o + c)] for c, o in zip(chans, offs)])
+        if training and world > 1:
+            dist.all_reduce(sums, group=group if group is not None else None)
+        dxs = []
+        for x, c, o, ld in zip(xs, chans, offs, lds):
+            sl = slice(o, o + c)
+            dx = hip.empty_like_rows(x)
+            hip.abn_bwd_apply(x, ld, dy[:, sl], ld_dy, None, 0, dx, c, None, 0, M, c, None, HW, mean[sl], invstd[sl],
+                              scale[sl], shift[sl], weight[sl] if weight is not None else None,
+                              sums[2 * o:2 * (o + c)], count, 0 if training else 1, act, slope)
+            dxs.append(dx)
+        return (dweight, dbias) + (None,) * 8 + tuple(dxs)
+
+
+class _PlaneMean(torch.autograd.Function):
+    """Global average pooling [B, C, H, W] -> [B, C, 1, 1] (modules/deeplab.py:72-76)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x, M, Cc, HW, ld = hip.rows_view(x)
+        B = x.shape[0]
+        out = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
+        hip.plane_sum(x, ld, B, HW, Cc, 1.0 / HW, out)
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        return out.to(x.dtype).view(B, Cc, 1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Cc, H, W = ctx.shape
+        return (g.to(ctx.dtype) / (H * W)).expand(B, Cc, H, W)
+
+
+def global_avg_pool(x):
+    return _PlaneMean.apply(x)
+
+
+class ABN(nn.Module):
+    """BatchNorm + activation on the HIP kernels; base class of the in-place variants."""
+
+    ucd_fused_abn = True
+    _inplace_contract = False
+    _sync = False
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu",
+                 activation_param=0.01, group=None):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.affine = num_features, eps, momentum, affine
+        self.activation, self.activation_param = activation, activation_param
+        self.group = group
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def reset_parameters(self):
+        nn.init.constant_(self.running_mean, 0)
+        nn.init.constant_(self.running_var, 1)
+        if self.affine:
+            nn.init.constant_(self.weight, 1)
+            nn.init.constant_(self.bias, 0)
+
+    def _group(self):
+        return self.group if self._sync else False
+
+    def forward(self, x, residual=None, activation=None, activation_param=None, plane_bias=None, out=None):
+        if not x.is_cuda:
+            raise RuntimeError("ucd_amd.abn runs on the GPU only (there is no CPU fallback)")
+        act = _act_code(self.activation if activation is None else activation)
+        slope = self.activation_param if activation_param is None else activation_param
+        inplace = self._inplace_contract and not torch.is_grad_enabled() and out is None
+        return _ABNFunction.apply(x, self.weight, self.bias, residual, plane_bias, self.running_mean,
+                                  self.running_var, self.training, self.momentum, self.eps, act, slope,
+                                  self._group(), out, inplace)
+
+    def forward_branches(self, xs):
+        """``self(torch.cat(xs, 1))`` without the concatenation."""
+        return _ABNBranchesFunction.apply(self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                          self.momentum, self.eps, _act_code(self.activation), self.activation_param,
+                                          self._group(), *xs)
+
+    def extra_repr(self):
+        s = "{num_features}, eps={eps}, momentum={momentum}, affine={affine}, activation={activation}"
+        if self.activation in ("leaky_relu", "elu"):
+            s += "[{activation_param}]"
+        return s.format(**self.__dict__)
+
+
+class InPlaceABN(ABN):
+    """Same arithmetic; under ``no_grad`` the input tensor is overwritten (inplace_abn's contract)."""
+    _inplace_contract = True
+
+
+class InPlaceABNSync(InPlaceABN):
+    """InPlaceABN with statistics reduced over the process group (RCCL over xGMI)."""
+    _sync = True

@@ -1,0 +1,230 @@
+"""Uncertainty-weighted pixel-contrastive distillation on the HIP kernels.
+
+Host-side mirror of the reference's wired contrastive path:
+  * ``pre_contractive_pixel(f_n, l_n, l_po, f_o)``          utils/utils.py:256-393 (twin utils/loss.py:258-395)
+  * ``PixelConLossV2(temperature).forward(a, c, la, lc, P)``  utils/loss.py:403-466
+and of the step the reference's trainer composes from them (train.py:115-116, as intended - SURVEY.md
+section 0): :func:`ucd_contrastive_loss` fuses prep + loss + gradient and never builds the [A, C]
+matrices; it is what :class:`ucd_amd.train.Trainer` calls.  The two reference-shaped entry points are
+kept for drop-in use and for the parity tests: ``pre_contractive_pixel`` returns the reference's
+5-tuple (``P`` materialised on request only), and ``PixelConLossV2`` accepts that tuple.
+
+All sizes that depend on the data (anchor count A, contrast count C) stay on the device; the host only
+allocates worst-case buffers (A <= BHW, C <= 2 BHW) - there is no ``.cpu()`` round trip
+(the reference syncs at utils/utils.py:356).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+
+class PixconBatch:
+    """Device-resident anchor / contrast sets of one batch (outputs of the prep + gather kernels)."""
+
+    __slots__ = ("BHW", "N", "K", "anchor_pix", "old_pix", "row_label", "prob", "meta", "chat", "pcat",
+                 "inv_norm", "ldp", "sorted", "f_dtype")
+
+    def meta_host(self):
+        """Copy the meta record to the host (tests / logging only: this synchronises)."""
+        raw = self.meta.cpu().numpy().tobytes()
+        return hip.PixconMeta.from_buffer_copy(raw)
+
+
+def _rows2d(t, what):
+    """[B, C, h, w] map -> ([B*h*w, C] row view sharing memory, ld)."""
+    t2, M, Cc, HW, ld = hip.rows_view(t)
+    return t2, M, Cc, ld
+
+
+def pixcon_prepare(f_n, labels, l_po, f_o, max_label=20, sort_by_label=True):
+    """Run ucd_pixcon_prep + ucd_pixcon_gather.  ``f_n``/``f_o``: [B, N, h, w] student / teacher
+    pre-logits (any strides; channels-last is zero-copy), ``labels``: [B, H, W] int64,
+    ``l_po``: [B, K, h, w] teacher low-resolution logits."""
+    lib = hip.load()
+    if not f_n.is_cuda:
+        raise RuntimeError("ucd_amd.contrastive runs on the GPU only (there is no CPU fallback)")
+    B, N, h, w = f_n.shape
+    K = l_po.shape[1]
+    H, W = labels.shape[-2:]
+    if N > hip.PIXCON_LD:
+        raise RuntimeError(f"feature dimension {N} > {hip.PIXCON_LD} is not supported")
+    dev = f_n.device
+    BHW = B * h * w
+    if f_o.dtype != f_n.dtype:
+        f_o = f_o.to(f_n.dtype)
+    fn2, _, _, ld_n = _rows2d(f_n, "f_n")
+    fo2, _, _, ld_o = _rows2d(f_o.detach(), "f_o")
+    # the teacher logits row matrix [BHW, K]; K is small, so a packed copy is cheap
+    t = l_po.detach().permute(0, 2, 3, 1).reshape(BHW, K)
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    t = t.contiguous()
+    labels = labels.contiguous()
+    if labels.dtype != torch.int64:
+        labels = labels.long()
+
+    pb = PixconBatch()
+    pb.BHW, pb.N, pb.K, pb.sorted, pb.f_dtype = BHW, N, K, bool(sort_by_label), f_n.dtype
+    rows = 2 * BHW + 2 * hip.PIX_TILE
+    pb.anchor_pix = torch.empty(BHW, dtype=torch.int32, device=dev)
+    pb.old_pix = torch.empty(BHW, dtype=torch.int32, device=dev)
+    pb.row_label = torch.empty(rows, dtype=torch.uint8, device=dev)
+    pb.prob = torch.empty(BHW, K, dtype=torch.float32, device=dev)
+    pb.meta = torch.empty(hip.META_BYTES, dtype=torch.uint8, device=dev)
+    nbytes = lib.ucd_pixcon_prep_workspace_bytes(BHW, K)
+    ws = hip.workspace(nbytes, dev, "pixprep")
+    hip._check(lib.ucd_pixcon_prep(hip.ptr(labels), B, H, W, h, w, int(max_label), hip.ptr(t), K, hip.dtype_code(t), K,
+                                   int(bool(sort_by_label)), hip.ptr(pb.anchor_pix), hip.ptr(pb.old_pix),
+                                   hip.ptr(pb.row_label), hip.ptr(pb.prob), hip.ptr(pb.meta), hip.ptr(ws), nbytes,
+                                   hip.stream()), "ucd_pixcon_prep")
+    pb.ldp = (K + 1) & ~1
+    pb.chat = torch.empty(rows, hip.PIXCON_LD, dtype=torch.float32, device=dev)
+    pb.pcat = torch.empty(rows, pb.ldp, dtype=torch.float32, device=dev)
+    pb.inv_norm = torch.empty(BHW, dtype=torch.float32, device=dev)
+    hip._check(lib.ucd_pixcon_gather(hip.ptr(fn2), ld_n, hip.ptr(fo2), ld_o, hip.dtype_code(fn2), BHW, N,
+                                     hip.ptr(pb.anchor_pix), hip.ptr(pb.old_pix), hip.ptr(pb.prob), K, hip.ptr(pb.meta),
+                                     hip.ptr(pb.chat), hip.PIXCON_LD, hip.ptr(pb.pcat), pb.ldp, hip.ptr(pb.inv_norm),
+                                     hip.stream()), "ucd_pixcon_gather")
+    return pb
+
+
+def pixcon_loss_raw(pb, temperature=0.07, shift_pos=True, use_prob=True, need_grad=True, row_stats=False):
+    """ucd_pixcon_loss on a prepared batch: returns (loss_out[2], grad_a or None, row_stats or None)."""
+    lib = hip.load()
+    dev = pb.chat.device
+    loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+    grad_a = torch.empty(pb.BHW, hip.PIXCON_LD, dtype=torch.float32, device=dev) if need_grad else None
+    stats = torch.zeros(3, pb.BHW, dtype=torch.float32, device=dev) if row_stats else None
+    nbytes = lib.ucd_pixcon_loss_workspace_bytes(pb.BHW, pb.N, pb.K)
+    ws = hip.workspace(nbytes, dev, "pixloss")
+    hip._check(lib.ucd_pixcon_loss(hip.ptr(pb.chat), hip.PIXCON_LD, pb.N, hip.ptr(pb.row_label), hip.ptr(pb.pcat), pb.ldp,
+                                   pb.K, hip.ptr(pb.meta), pb.BHW, float(temperature), int(bool(shift_pos)),
+                                   int(bool(use_prob)), hip.ptr(loss_out), hip.ptr(grad_a), hip.PIXCON_LD, hip.ptr(stats),
+                                   hip.ptr(ws), nbytes, hip.stream()), "ucd_pixcon_loss")
+    return loss_out, grad_a, stats
+
+
+class _FusedContrastive(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, f_n, labels, l_po, f_o, temperature, max_label):
+        pb = pixcon_prepare(f_n, labels, l_po, f_o, max_label=max_label, sort_by_label=True)
+        loss_out, grad_a, _ = pixcon_loss_raw(pb, temperature, True, True, need_grad=ctx.needs_input_grad[0])
+        ctx.pb, ctx.grad_a, ctx.shape, ctx.dtype = pb, grad_a, f_n.shape, f_n.dtype
+        return loss_out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = hip.load()
+        pb, grad_a = ctx.pb, ctx.grad_a
+        B, N, h, w = ctx.shape
+        d = torch.empty((B, N, h, w), dtype=ctx.dtype, device=g.device, memory_format=torch.channels_last)
+        gs = g.reshape(1).float().contiguous()
+        hip._check(lib.ucd_pixcon_scatter_grad(hip.ptr(grad_a), hip.ptr(pb.chat), hip.PIXCON_LD, hip.ptr(pb.inv_norm),
+                                               hip.ptr(pb.anchor_pix), hip.ptr(pb.meta), hip.ptr(gs), hip.ptr(d), N,
+                                               hip.dtype_code(d), pb.BHW, N, hip.stream()), "ucd_pixcon_scatter_grad")
+        ctx.pb = ctx.grad_a = None
+        return d, None, None, None, None, None
+
+
+def ucd_contrastive_loss(f_n, labels, l_po, f_o, temperature=0.07, max_label=20):
+    """``PixelConLossV2(T)(*pre_contractive_pixel(f_n, labels, l_po, f_o))`` as one fused, differentiable
+    device-side operation (train.py:115-116 as intended)."""
+    return _FusedContrastive.apply(f_n, labels, l_po, f_o, float(temperature), int(max_label))
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-shaped entry points
+# ---------------------------------------------------------------------------------------------
+class _NormalizedAnchors(torch.autograd.Function):
+    """a = normalize(f_n rows kept as anchors); backward scatters through the normalisation."""
+
+    @staticmethod
+    def forward(ctx, f_n, pb, A):
+        ctx.pb, ctx.shape, ctx.dtype, ctx.A = pb, f_n.shape, f_n.dtype, A
+        return pb.chat[:A, :pb.N].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = hip.load()
+        pb = ctx.pb
+        B, N, h, w = ctx.shape
+        ga = torch.zeros(pb.BHW, hip.PIXCON_LD, dtype=torch.float32, device=g.device)
+        ga[:ctx.A, :N] = g
+        one = torch.ones(1, dtype=torch.float32, device=g.device)
+        d = torch.empty((B, N, h, w), dtype=ctx.dtype, device=g.device, memory_format=torch.channels_last)
+        hip._check(lib.ucd_pixcon_scatter_grad(hip.ptr(ga), hip.ptr(pb.chat), hip.PIXCON_LD, hip.ptr(pb.inv_norm),
+                                               hip.ptr(pb.anchor_pix), hip.ptr(pb.meta), hip.ptr(one), hip.ptr(d), N,
+                                               hip.dtype_code(d), pb.BHW, N, hip.stream()), "ucd_pixcon_scatter_grad")
+        return d, None, None
+
+
+class PixconTuple(tuple):
+    """The reference's 5-tuple ``(a, c, la, lc, P)`` plus the prepared batch it came from (``.batch``), so
+    that :class:`PixelConLossV2` can run the fused kernel instead of re-deriving everything from ``P``."""
+    batch = None
+
+
+def pre_contractive_pixel(f_n, l_n, l_po=None, f_o=None, max_label=20, materialize_P=True):
+    """Reference signature and return order (utils/utils.py:256,393): anchors ``a`` [A, N] (grad flows to
+    ``f_n``), contrast ``c`` [C, N], labels ``la`` [A] / ``lc`` [C] (int8 like the reference) and the
+    joint-probability weight ``P`` [A, C].  Rows are in the reference's pixel order.  This entry point
+    returns host-sized tensors, so it reads the counts back (one sync) - the trainer uses
+    :func:`ucd_contrastive_loss`, which does not."""
+    if l_po is None or f_o is None:
+        raise NotImplementedError("only the wired teacher/student form (utils/utils.py:316-393) is on the hot path")
+    pb = pixcon_prepare(f_n, l_n, l_po, f_o, max_label=max_label, sort_by_label=False)
+    m = pb.meta_host()
+    A, Co, Apad = m.A, m.Co, m.Apad
+    if m.n_new == 0:
+        raise RuntimeError("no new-class pixel in the batch (the reference fails at utils/utils.py:353)")
+    a = _NormalizedAnchors.apply(f_n, pb, A)
+    c = torch.cat((pb.chat[:A, :pb.N], pb.chat[Apad:Apad + Co, :pb.N]), dim=0)
+    la = pb.row_label[:A].to(torch.int8)
+    lc = torch.cat((pb.row_label[:A], pb.row_label[Apad:Apad + Co])).to(torch.int8)
+    P = None
+    if materialize_P:
+        pa = pb.pcat[:A, :pb.K]
+        pc = torch.cat((pa, pb.pcat[Apad:Apad + Co, :pb.K]), dim=0)
+        P = pa @ pc.T
+        gt_a, gt_c = la >= m.min_new, lc >= m.min_new
+        P = torch.where(gt_a[:, None] & gt_c[None, :], torch.ones_like(P), P)
+    out = PixconTuple((a, c, la, lc, P))
+    out.batch = pb
+    return out
+
+
+class _LossOnBatch(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, pb, temperature, use_prob, shift_pos):
+        loss_out, grad_a, _ = pixcon_loss_raw(pb, temperature, shift_pos, use_prob, need_grad=True)
+        ctx.grad_a, ctx.A, ctx.N = grad_a, a.shape[0], a.shape[1]
+        return loss_out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.grad_a[:ctx.A, :ctx.N] * g, None, None, None, None
+
+
+class PixelConLossV2(nn.Module):
+    """``forward(anchor_features, contrast_feature, anchor_labels, contrast_labels, P=None)`` like the
+    reference (utils/loss.py:412).  The tensors must come from :func:`pre_contractive_pixel` of this
+    package (they carry the prepared device batch); the loss runs the fused MFMA kernel on it."""
+
+    def __init__(self, sample_method="none", temperature=0.07):
+        super().__init__()
+        self.temperature, self.sample_method = temperature, sample_method
+
+    def forward(self, anchor_features, contrast_feature=None, anchor_labels=None, contrast_labels=None, P=None,
+                batch=None):
+        if isinstance(anchor_features, PixconTuple):
+            tup = anchor_features
+            anchor_features, batch, P = tup[0], tup.batch, tup[4]
+        if batch is None:
+            raise RuntimeError("PixelConLossV2 needs the PixconTuple returned by ucd_amd.contrastive."
+                               "pre_contractive_pixel (pass the tuple itself, or batch=tuple.batch)")
+        return _LossOnBatch.apply(anchor_features, batch, float(self.temperature), P is not None, True)

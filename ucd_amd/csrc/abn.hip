@@ -1,0 +1,641 @@
+// ABN (BatchNorm + LeakyReLU/identity) kernels for channels-last activations on gfx950.
+//
+// Replaces the inplace-abn CUDA extension behind the reference's norm_act(...) layers
+// (segmentation_module.py:15-20; 107 instances) and the elementwise glue around it
+// (residual add + activation, modules/residual.py:90-97; pooled-branch broadcast add,
+// modules/deeplab.py:65-68).  All kernels are HBM streams:
+//
+//   stats       1 read              sum x, sum x^2 per channel           (two-stage, deterministic)
+//   apply       1-2 reads, 1 write  y = act((x+pb)*scale + shift + r)
+//   bwd_reduce  2-3 reads           sum dz, sum dz*xhat per channel
+//   bwd_apply   2-3 reads, 1-2 wr.  dx (and dz for the fused residual)
+//
+// Layout: an activation is the row-major matrix [M = B*H*W][C]; every lane moves 16 bytes (4 f32 or
+// 8 bf16 channels) so a wave reads 1 KiB of consecutive channels/pixels per instruction.  A 256-thread
+// block is TX channel-groups wide (TX <= 64) and TY = 256/TX rows tall; blockIdx.x walks channel
+// groups, blockIdx.y owns a contiguous band of rows.  Per-channel parameters sit in registers.
+#include "common.h"
+
+namespace ucd {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxBands = 512;  // row bands (= partial sums per channel) of the two-stage reductions
+
+struct Geom {
+  int TX, TY, gx, gy, rows_per_band;
+};
+
+template <int VEC>
+Geom make_geom(int M, int C, int target_blocks, int min_iters) {
+  Geom g;
+  int CG = C / VEC;
+  g.TX = CG < 64 ? CG : 64;
+  g.TY = kBlock / g.TX;
+  g.gx = ceil_div(CG, g.TX);
+  int by_rows = M / (g.TY * min_iters);
+  int gy = target_blocks / g.gx;
+  if (gy > by_rows) gy = by_rows;
+  if (gy > kMaxBands) gy = kMaxBands;
+  if (gy < 1) gy = 1;
+  g.rows_per_band = ceil_div(M, gy);
+  g.gy = ceil_div(M, g.rows_per_band);
+  return g;
+}
+
+// Reduce NV floats per thread over the TY rows of a block; result valid in threads with ty == 0.
+template <int NV>
+__device__ __forceinline__ void block_reduce_rows(float (&v)[NV], int tx, int ty, int TX, int TY, float* lds) {
+  // lds: [kBlock][NV]
+#pragma unroll
+  for (int i = 0; i < NV; ++i) lds[(ty * TX + tx) * NV + i] = v[i];
+  __syncthreads();
+  int span = 1;
+  while (span < TY) span <<= 1;
+  for (int s = span >> 1; s > 0; s >>= 1) {
+    if (ty < s && ty + s < TY) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) lds[(ty * TX + tx) * NV + i] += lds[((ty + s) * TX + tx) * NV + i];
+    }
+    __syncthreads();
+  }
+  if (ty == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = lds[tx * NV + i];
+  }
+}
+
+// ---- forward statistics -------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__ x, int ld_x, int M, int C,
+                                                          const float* __restrict__ plane_bias, int HW,
+                                                          int TX, int TY, int rows_per_band,
+                                                          float* __restrict__ partial) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  const bool live = ty < TY && cg * VEC < C;
+  float acc[2 * VEC];
+#pragma unroll
+  for (int i = 0; i < 2 * VEC; ++i) acc[i] = 0.f;
+  const int r_begin = blockIdx.y * rows_per_band;
+  const int r_end = min(M, r_begin + rows_per_band);
+  if (live) {
+    const T* xp = x + (size_t)cg * VEC;
+    for (int r = r_begin + ty; r < r_end; r += TY) {
+      Vec<T> v;
+      v.load(xp + (size_t)r * ld_x);
+      if (plane_bias) {
+        const float* pb = plane_bias + (size_t)(r / HW) * C + cg * VEC;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          float f = v.get(i) + pb[i];
+          acc[i] += f;
+          acc[VEC + i] += f * f;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          float f = v.get(i);
+          acc[i] += f;
+          acc[VEC + i] += f * f;
+        }
+      }
+    }
+  }
+  // idle tail threads (TX does not divide 256) carry zeros through the reduction: ty*TX+tx == threadIdx.x
+  block_reduce_rows<2 * VEC>(acc, tx, ty, TX, TY, lds);
+  if (ty == 0 && cg * VEC < C) {
+    float* p = partial + (size_t)blockIdx.y * 2 * C + cg * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      p[i] = acc[i];
+      p[C + i] = acc[VEC + i];
+    }
+  }
+}
+
+// Stage 2 of both reductions: sums[k] = sum over bands of partial[band][k], k in [0, 2C).
+// 32 outputs x 8 band-lanes per block.
+__global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int n,
+                                                              float* __restrict__ sums) {
+  __shared__ float lds[8][32];
+  const int k = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int lane = threadIdx.x >> 5;
+  float s = 0.f;
+  if (k < n)
+    for (int b = lane; b < bands; b += 8) s += partial[(size_t)b * n + k];
+  lds[lane][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (lane == 0 && k < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += lds[i][threadIdx.x & 31];
+    sums[k] = t;
+  }
+}
+
+__global__ void abn_finalize_kernel(const float* __restrict__ sums, float count, int C,
+                                    const float* __restrict__ weight, const float* __restrict__ bias,
+                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                    float momentum, float eps, float* __restrict__ mean_o,
+                                    float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                    float* __restrict__ shift_o) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float inv_n = 1.f / count;
+  float mean = sums[c] * inv_n;
+  float var = fmaxf(sums[C + c] * inv_n - mean * mean, 0.f);
+  float invstd = rsqrtf(var + eps);
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+  if (running_var) {
+    float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+  float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+  float sc = w * invstd;
+  if (mean_o) mean_o[c] = mean;
+  if (invstd_o) invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = b - mean * sc;
+}
+
+__global__ void abn_eval_params_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
+                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                       float* __restrict__ scale, float* __restrict__ shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+  float sc = w * rsqrtf(rv[c] + eps);
+  scale[c] = sc;
+  shift[c] = b - rm[c] * sc;
+}
+
+// ---- forward apply ------------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(kBlock) void abn_apply_kernel(const T* x, int ld_x, T* y, int ld_y,
+                                                          const T* __restrict__ res, int ld_r, int M, int C,
+                                                          const float* __restrict__ plane_bias, int HW,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float slope, int TX, int TY, int rows_per_band) {
+  constexpr int VEC = Vec<T>::N;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  if (ty >= TY || cg * VEC >= C) return;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    sc[i] = scale[cg * VEC + i];
+    sh[i] = shift[cg * VEC + i];
+  }
+  const int r_begin = blockIdx.y * rows_per_band;
+  const int r_end = min(M, r_begin + rows_per_band);
+  const size_t coff = (size_t)cg * VEC;
+  for (int r = r_begin + ty; r < r_end; r += TY) {
+    Vec<T> v, rv, o;
+    v.load(x + (size_t)r * ld_x + coff);
+    if (res) rv.load(res + (size_t)r * ld_r + coff);
+    const float* pb = plane_bias ? plane_bias + (size_t)(r / HW) * C + coff : nullptr;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float f = v.get(i);
+      if (pb) f += pb[i];
+      float z = f * sc[i] + sh[i];
+      if (res) z += rv.get(i);
+      o.set(i, act_fwd<ACT>(z, slope));
+    }
+    o.store(y + (size_t)r * ld_y + coff);
+  }
+}
+
+// ---- backward reduce ----------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
+    const T* __restrict__ x, int ld_x, const T* __restrict__ dy, int ld_dy, const T* __restrict__ yout, int ld_y,
+    int M, int C, const float* __restrict__ plane_bias, int HW, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, float slope,
+    int TX, int TY, int rows_per_band, float* __restrict__ partial) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  const bool live = ty < TY && cg * VEC < C;
+  float acc[2 * VEC];
+#pragma unroll
+  for (int i = 0; i < 2 * VEC; ++i) acc[i] = 0.f;
+  if (live) {
+    float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      mu[i] = mean[cg * VEC + i];
+      is[i] = invstd[cg * VEC + i];
+      sc[i] = scale[cg * VEC + i];
+      sh[i] = shift[cg * VEC + i];
+    }
+    const int r_begin = blockIdx.y * rows_per_band;
+    const int r_end = min(M, r_begin + rows_per_band);
+    const size_t coff = (size_t)cg * VEC;
+    for (int r = r_begin + ty; r < r_end; r += TY) {
+      Vec<T> v, g, yo;
+      v.load(x + (size_t)r * ld_x + coff);
+      g.load(dy + (size_t)r * ld_dy + coff);
+      if (yout) yo.load(yout + (size_t)r * ld_y + coff);
+      const float* pb = plane_bias ? plane_bias + (size_t)(r / HW) * C + coff : nullptr;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        float f = v.get(i);
+        if (pb) f += pb[i];
+        float sgn = yout ? yo.get(i) : f * sc[i] + sh[i];
+        float dz = g.get(i) * act_grad<ACT>(sgn, slope);
+        float xh = (f - mu[i]) * is[i];
+        acc[i] += dz;
+        acc[VEC + i] += dz * xh;
+      }
+    }
+  }
+  block_reduce_rows<2 * VEC>(acc, tx, ty, TX, TY, lds);
+  if (ty == 0 && cg * VEC < C) {
+    float* p = partial + (size_t)blockIdx.y * 2 * C + cg * VEC;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      p[i] = acc[i];
+      p[C + i] = acc[VEC + i];
+    }
+  }
+}
+
+// ---- backward apply -----------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
+    const T* x, int ld_x, const T* dy, int ld_dy, const T* yout, int ld_y,
+    T* dx, int ld_dx, T* dz_out, int ld_dz, int M, int C,
+    const float* __restrict__ plane_bias, int HW, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ weight,
+    const float* __restrict__ sums, float inv_count, int frozen, float slope, int TX, int TY, int rows_per_band) {
+  constexpr int VEC = Vec<T>::N;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  if (ty >= TY || cg * VEC >= C) return;
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC], k0[VEC], k1[VEC], gw[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) {
+    const int c = cg * VEC + i;
+    sc[i] = scale[c];
+    sh[i] = shift[c];
+    if (frozen) {
+      mu[i] = 0.f; is[i] = 0.f; k0[i] = 0.f; k1[i] = 0.f;
+      gw[i] = sc[i];
+    } else {
+      mu[i] = mean[c];
+      is[i] = invstd[c];
+      k0[i] = sums[c] * inv_count;       // mean(dz)
+      k1[i] = sums[C + c] * inv_count;   // mean(dz * xhat)
+      gw[i] = (weight ? weight[c] : 1.f) * is[i];
+    }
+  }
+  const int r_begin = blockIdx.y * rows_per_band;
+  const int r_end = min(M, r_begin + rows_per_band);
+  const size_t coff = (size_t)cg * VEC;
+  for (int r = r_begin + ty; r < r_end; r += TY) {
+    Vec<T> v, g, yo, o, oz;
+    v.load(x + (size_t)r * ld_x + coff);
+    g.load(dy + (size_t)r * ld_dy + coff);
+    if (yout) yo.load(yout + (size_t)r * ld_y + coff);
+    const float* pb = plane_bias ? plane_bias + (size_t)(r / HW) * C + coff : nullptr;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float f = v.get(i);
+      if (pb) f += pb[i];
+      float sgn = yout ? yo.get(i) : f * sc[i] + sh[i];
+      float dz = g.get(i) * act_grad<ACT>(sgn, slope);
+      float xh = (f - mu[i]) * is[i];
+      o.set(i, (dz - k0[i] - xh * k1[i]) * gw[i]);
+      oz.set(i, dz);
+    }
+    o.store(dx + (size_t)r * ld_dx + coff);
+    if (dz_out) oz.store(dz_out + (size_t)r * ld_dz + coff);
+  }
+}
+
+// ---- per-(image, channel) plane sums ------------------------------------------------------------
+// grid: (channel tiles, B); the block's TY rows stride over the HW pixels of image b.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void plane_sum_kernel(const T* __restrict__ x, int ld_x, int HW, int C, float alpha,
+                                                          int TX, int TY, float* __restrict__ out) {
+  constexpr int VEC = Vec<T>::N;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  const int b = blockIdx.y;
+  const bool live = ty < TY && cg * VEC < C;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  if (live) {
+    const T* xp = x + (size_t)b * HW * ld_x + (size_t)cg * VEC;
+    for (int r = ty; r < HW; r += TY) {
+      Vec<T> v;
+      v.load(xp + (size_t)r * ld_x);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] += v.get(i);
+    }
+  }
+  block_reduce_rows<VEC>(acc, tx, ty, TX, TY, lds);
+  if (ty == 0 && cg * VEC < C) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) out[(size_t)b * C + cg * VEC + i] = acc[i] * alpha;
+  }
+}
+
+// ---- attention map (segmentation_module.py:86-94) -----------------------------------------------
+// pass 1: a[p] = sum_c x[p,c]^2 (one wave per pixel row), pass 2: per-image sum of a^2, pass 3: y = x*a/||a||
+template <typename T>
+__global__ __launch_bounds__(kBlock) void attmap_rowsq_kernel(const T* __restrict__ x, int ld_x, int M, int C,
+                                                             float* __restrict__ a) {
+  constexpr int VEC = Vec<T>::N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (kBlock / 64) + wave;
+  if (r >= M) return;
+  float s = 0.f;
+  for (int c = lane * VEC; c < C; c += 64 * VEC) {
+    Vec<T> v;
+    v.load(x + (size_t)r * ld_x + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s += v.get(i) * v.get(i);
+  }
+  s = wave_sum(s);
+  if (lane == 0) a[r] = s;
+}
+__global__ __launch_bounds__(kBlock) void attmap_norm_kernel(const float* __restrict__ a, int HW, float* __restrict__ inv) {
+  __shared__ float lds[kBlock / 64];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int p = threadIdx.x; p < HW; p += kBlock) {
+    float v = a[(size_t)b * HW + p];
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int i = 0; i < kBlock / 64; ++i) t += lds[i];
+    inv[b] = 1.f / sqrtf(t);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void attmap_scale_kernel(const T* __restrict__ x, int ld_x, T* __restrict__ y, int ld_y,
+                                                             int M, int HW, int C, const float* __restrict__ a,
+                                                             const float* __restrict__ inv) {
+  constexpr int VEC = Vec<T>::N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (kBlock / 64) + wave;
+  if (r >= M) return;
+  const float f = a[r] * inv[r / HW];
+  for (int c = lane * VEC; c < C; c += 64 * VEC) {
+    Vec<T> v, o;
+    v.load(x + (size_t)r * ld_x + c);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) o.set(i, v.get(i) * f);
+    o.store(y + (size_t)r * ld_y + c);
+  }
+}
+
+// ---- argument checks ----------------------------------------------------------------------------
+int check_act_tensor(const char* fn, const char* name, const void* p, int ld, int dtype, int C, bool optional) {
+  if (!p) {
+    UCD_REQUIRE(optional, UCD_EINVAL, "%s: %s is NULL", fn, name);
+    return 0;
+  }
+  const int es = dtype == UCD_BF16 ? 2 : 4;
+  UCD_REQUIRE(aligned16(p) && ((size_t)ld * es) % 16 == 0, UCD_EALIGN,
+              "%s: %s must be 16-byte aligned with a 16-byte multiple row pitch (ld=%d)", fn, name, ld);
+  UCD_REQUIRE(ld >= C, UCD_EINVAL, "%s: ld of %s (%d) < C (%d)", fn, name, ld, C);
+  return 0;
+}
+int check_common(const char* fn, int dtype, int M, int C, int act) {
+  UCD_REQUIRE(dtype == UCD_F32 || dtype == UCD_BF16, UCD_EINVAL, "%s: unknown dtype %d", fn, dtype);
+  UCD_REQUIRE(M > 0 && C > 0, UCD_EINVAL, "%s: empty tensor (M=%d, C=%d)", fn, M, C);
+  const int vec = dtype == UCD_BF16 ? 8 : 4;
+  UCD_REQUIRE(C % vec == 0, UCD_EALIGN, "%s: C=%d is not a multiple of %d", fn, C, vec);
+  UCD_REQUIRE(act == UCD_ACT_IDENTITY || act == UCD_ACT_LEAKY_RELU, UCD_EINVAL, "%s: unknown activation %d", fn, act);
+  return 0;
+}
+
+#define UCD_TRY(expr)          \
+  do {                         \
+    int _rc = (expr);          \
+    if (_rc) return _rc;       \
+  } while (0)
+
+}  // namespace
+}  // namespace ucd
+
+using namespace ucd;
+
+extern "C" {
+
+size_t ucd_abn_workspace_bytes(int M, int C) {
+  (void)M;
+  return (size_t)kMaxBands * 2 * (size_t)C * sizeof(float);
+}
+
+int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW, float* sums,
+                  void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_stats";
+  UCD_TRY(check_common(fn, dtype, M, C, UCD_ACT_IDENTITY));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
+  UCD_REQUIRE(sums && workspace, UCD_EINVAL, "%s: sums/workspace is NULL", fn);
+  UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  Geom g;
+  if (dtype == UCD_BF16) {
+    g = make_geom<8>(M, C, 2048, 8);
+    UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
+    abn_stats_kernel<__hip_bfloat16><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>(
+        (const __hip_bfloat16*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial);
+  } else {
+    g = make_geom<4>(M, C, 2048, 8);
+    UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
+    abn_stats_kernel<float><<<dim3(g.gx, g.gy), kBlock, kBlock * 8 * 4, s>>>(
+        (const float*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial);
+  }
+  UCD_TRY(check_launch(fn));
+  reduce_bands_kernel<<<ceil_div(2 * C, 32), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
+  return check_launch(fn);
+}
+
+int ucd_abn_finalize(const float* sums, float count, int C, const float* weight, const float* bias,
+                     float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                     float* scale, float* shift, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_finalize";
+  UCD_REQUIRE(sums && scale && shift && C > 0 && count > 0.f, UCD_EINVAL, "%s: bad arguments", fn);
+  abn_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, count, C, weight, bias, running_mean,
+                                                                        running_var, momentum, eps, mean, invstd,
+                                                                        scale, shift);
+  return check_launch(fn);
+}
+
+int ucd_abn_eval_params(const float* weight, const float* bias, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_eval_params";
+  UCD_REQUIRE(running_mean && running_var && scale && shift && C > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  abn_eval_params_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(weight, bias, running_mean, running_var,
+                                                                           eps, C, scale, shift);
+  return check_launch(fn);
+}
+
+int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r, int dtype, int M, int C,
+                  const float* plane_bias, int HW, const float* scale, const float* shift, int act, float slope,
+                  ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_apply";
+  UCD_TRY(check_common(fn, dtype, M, C, act));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "y", y, ld_y, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "residual", residual, ld_r, dtype, C, true));
+  UCD_REQUIRE(scale && shift, UCD_EINVAL, "%s: scale/shift is NULL", fn);
+  UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_APPLY(T, VECN, ACT)                                                                             \
+  {                                                                                                            \
+    Geom g = make_geom<VECN>(M, C, 2048, 4);                                                                   \
+    abn_apply_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, 0, s>>>((const T*)x, ld_x, (T*)y, ld_y,               \
+                                                                 (const T*)residual, ld_r, M, C, plane_bias,   \
+                                                                 HW, scale, shift, slope, g.TX, g.TY,          \
+                                                                 g.rows_per_band);                             \
+  }
+  if (dtype == UCD_BF16) {
+    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    else LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_IDENTITY)
+  } else {
+    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_APPLY(float, 4, UCD_ACT_LEAKY_RELU)
+    else LAUNCH_APPLY(float, 4, UCD_ACT_IDENTITY)
+  }
+#undef LAUNCH_APPLY
+  return check_launch(fn);
+}
+
+int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,
+                       int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
+                       const float* scale, const float* shift, int act, float slope, float* sums, void* workspace,
+                       size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_bwd_reduce";
+  UCD_TRY(check_common(fn, dtype, M, C, act));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "dy", dy, ld_dy, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "y", y, ld_y, dtype, C, true));
+  UCD_REQUIRE(mean && invstd && scale && shift && sums && workspace, UCD_EINVAL, "%s: NULL argument", fn);
+  UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
+  hipStream_t s = (hipStream_t)stream;
+  float* partial = (float*)workspace;
+  Geom g;
+#define LAUNCH_RED(T, VECN, ACT)                                                                                   \
+  {                                                                                                                \
+    g = make_geom<VECN>(M, C, 2048, 8);                                                                            \
+    UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);       \
+    abn_bwd_reduce_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, kBlock * 2 * VECN * 4, s>>>(                         \
+        (const T*)x, ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, M, C, plane_bias, HW, mean, invstd, scale,     \
+        shift, slope, g.TX, g.TY, g.rows_per_band, partial);                                                       \
+  }
+  if (dtype == UCD_BF16) {
+    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    else LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_IDENTITY)
+  } else {
+    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_RED(float, 4, UCD_ACT_LEAKY_RELU)
+    else LAUNCH_RED(float, 4, UCD_ACT_IDENTITY)
+  }
+#undef LAUNCH_RED
+  UCD_TRY(check_launch(fn));
+  reduce_bands_kernel<<<ceil_div(2 * C, 32), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
+  return check_launch(fn);
+}
+
+int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, void* dx, int ld_dx,
+                      void* dz_out, int ld_dz, int dtype, int M, int C, const float* plane_bias, int HW,
+                      const float* mean, const float* invstd, const float* scale, const float* shift,
+                      const float* weight, const float* sums, float count, int frozen, int act, float slope,
+                      ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_bwd_apply";
+  UCD_TRY(check_common(fn, dtype, M, C, act));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "dy", dy, ld_dy, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "y", y, ld_y, dtype, C, true));
+  UCD_TRY(check_act_tensor(fn, "dx", dx, ld_dx, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "dz_out", dz_out, ld_dz, dtype, C, true));
+  UCD_REQUIRE(scale && shift, UCD_EINVAL, "%s: scale/shift is NULL", fn);
+  UCD_REQUIRE(frozen || (mean && invstd && sums && count > 0.f), UCD_EINVAL, "%s: training statistics missing", fn);
+  UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
+  hipStream_t s = (hipStream_t)stream;
+  const float inv_count = frozen ? 0.f : 1.f / count;
+#define LAUNCH_BWD(T, VECN, ACT)                                                                                   \
+  {                                                                                                                \
+    Geom g = make_geom<VECN>(M, C, 2048, 4);                                                                       \
+    abn_bwd_apply_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, 0, s>>>(                                              \
+        (const T*)x, ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, (T*)dx, ld_dx, (T*)dz_out, ld_dz, M, C,        \
+        plane_bias, HW, mean, invstd, scale, shift, weight, sums, inv_count, frozen, slope, g.TX, g.TY,           \
+        g.rows_per_band);                                                                                          \
+  }
+  if (dtype == UCD_BF16) {
+    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    else LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_IDENTITY)
+  } else {
+    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_BWD(float, 4, UCD_ACT_LEAKY_RELU)
+    else LAUNCH_BWD(float, 4, UCD_ACT_IDENTITY)
+  }
+#undef LAUNCH_BWD
+  return check_launch(fn);
+}
+
+int ucd_plane_sum(const void* x, int ld_x, int dtype, int B, int HW, int C, float alpha, float* out,
+                  ucd_stream_t stream) {
+  static const char* fn = "ucd_plane_sum";
+  UCD_TRY(check_common(fn, dtype, B * HW, C, UCD_ACT_IDENTITY));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
+  UCD_REQUIRE(out && B > 0 && HW > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == UCD_BF16) {
+    Geom g = make_geom<8>(HW, C, 1, 1);
+    plane_sum_kernel<__hip_bfloat16><<<dim3(g.gx, B), kBlock, kBlock * 8 * 4, s>>>((const __hip_bfloat16*)x, ld_x, HW,
+                                                                                  C, alpha, g.TX, g.TY, out);
+  } else {
+    Geom g = make_geom<4>(HW, C, 1, 1);
+    plane_sum_kernel<float><<<dim3(g.gx, B), kBlock, kBlock * 4 * 4, s>>>((const float*)x, ld_x, HW, C, alpha, g.TX,
+                                                                         g.TY, out);
+  }
+  return check_launch(fn);
+}
+
+size_t ucd_attmap_workspace_bytes(int B, int HW) { return ((size_t)B * HW + B) * sizeof(float); }
+
+int ucd_attmap(const void* x, int ld_x, void* y, int ld_y, int dtype, int B, int HW, int C, void* workspace,
+               size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_attmap";
+  UCD_TRY(check_common(fn, dtype, B * HW, C, UCD_ACT_IDENTITY));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "y", y, ld_y, dtype, C, false));
+  UCD_REQUIRE(workspace && workspace_bytes >= ucd_attmap_workspace_bytes(B, HW), UCD_EWORKSPACE,
+              "%s: workspace too small", fn);
+  hipStream_t s = (hipStream_t)stream;
+  const int M = B * HW;
+  float* a = (float*)workspace;
+  float* inv = a + M;
+  const int rows_per_block = kBlock / 64;
+  if (dtype == UCD_BF16)
+    attmap_rowsq_kernel<__hip_bfloat16><<<ceil_div(M, rows_per_block), kBlock, 0, s>>>((const __hip_bfloat16*)x, ld_x, M, C, a);
+  else
+    attmap_rowsq_kernel<float><<<ceil_div(M, rows_per_block), kBlock, 0, s>>>((const float*)x, ld_x, M, C, a);
+  UCD_TRY(check_launch(fn));
+  attmap_norm_kernel<<<B, kBlock, 0, s>>>(a, HW, inv);
+  UCD_TRY(check_launch(fn));
+  if (dtype == UCD_BF16)
+    attmap_scale_kernel<__hip_bfloat16><<<ceil_div(M, rows_per_block), kBlock, 0, s>>>(
+        (const __hip_bfloat16*)x, ld_x, (__hip_bfloat16*)y, ld_y, M, HW, C, a, inv);
+  else
+    attmap_scale_kernel<float><<<ceil_div(M, rows_per_block), kBlock, 0, s>>>((const float*)x, ld_x, (float*)y, ld_y,
+                                                                             M, HW, C, a, inv);
+  return check_launch(fn);
+}
+
+}  // extern "C"

@@ -1,0 +1,83 @@
+// Shared device/host helpers of libucd_hip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/ucd_hip.h"
+
+namespace ucd {
+
+constexpr int kWave = 64;
+
+// ---- error plumbing ----------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);  // hipGetLastError -> 0 or positive hipError_t (message recorded)
+
+#define UCD_REQUIRE(cond, code, ...)      \
+  do {                                    \
+    if (!(cond)) {                        \
+      ucd::set_error(__VA_ARGS__);        \
+      return (code);                      \
+    }                                     \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- 16-byte vectors of activations ------------------------------------------------------------
+// One lane always moves 16 bytes: 4 floats or 8 bf16.
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  float4 raw;
+  __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+  __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const { return (&raw.x)[i]; }
+  __device__ __forceinline__ void set(int i, float v) { (&raw.x)[i] = v; }
+};
+template <> struct Vec<__hip_bfloat16> {
+  static constexpr int N = 8;
+  uint4 raw;
+  __device__ __forceinline__ void load(const __hip_bfloat16* p) { raw = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void store(__hip_bfloat16* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  __device__ __forceinline__ float get(int i) const {
+    uint32_t w = (&raw.x)[i >> 1];
+    return __uint_as_float((i & 1) ? (w & 0xFFFF0000u) : (w << 16));
+  }
+  __device__ __forceinline__ void set(int i, float v) {
+    // round-to-nearest-even via the hardware conversion (keeps NaN a NaN)
+    __hip_bfloat16 b = __float2bfloat16(v);
+    uint32_t bits = *reinterpret_cast<const uint16_t*>(&b);
+    uint32_t& w = (&raw.x)[i >> 1];
+    w = (i & 1) ? ((w & 0x0000FFFFu) | (bits << 16)) : ((w & 0xFFFF0000u) | bits);
+  }
+};
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z, float slope) {
+  if (ACT == UCD_ACT_LEAKY_RELU) return z > 0.f ? z : z * slope;
+  return z;
+}
+// derivative selected by the sign of z (== sign of y for leaky_relu with slope > 0)
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z_or_y, float slope) {
+  if (ACT == UCD_ACT_LEAKY_RELU) return z_or_y > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+}  // namespace ucd

@@ -1,0 +1,220 @@
+"""ctypes binding of ``libucd_hip.so`` (the C ABI declared in ``include/ucd_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and streams; every compute call below hands raw
+device pointers and the current ``hipStream_t`` to the library.  There is no CPU fallback - if the
+shared library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libucd_hip.so")
+
+F32, BF16 = 0, 1
+ACT_IDENTITY, ACT_LEAKY_RELU = 0, 1
+ACT_CODES = {"identity": ACT_IDENTITY, "leaky_relu": ACT_LEAKY_RELU}
+PIX_TILE = 128          # kPixTile of csrc/pixcon.h
+PIXCON_LD = 256         # feature rows of the contrast matrix are padded to 256 columns
+
+
+class PixconMeta(C.Structure):
+    """Mirror of ``ucd_pixcon_meta`` (include/ucd_hip.h)."""
+    _fields_ = [("A", C.c_int32), ("Co", C.c_int32), ("min_new", C.c_int32), ("n_new", C.c_int32),
+                ("Apad", C.c_int32), ("Cpad", C.c_int32), ("n_valid", C.c_int32), ("sorted", C.c_int32),
+                ("label_start_a", C.c_int32 * 257), ("label_start_o", C.c_int32 * 257),
+                ("label_count_a", C.c_int32 * 256), ("label_count_c", C.c_int32 * 256),
+                ("reserved", C.c_int32 * 2)]
+
+
+META_BYTES = C.sizeof(PixconMeta)
+
+_p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+# name -> (restype, argtypes); must list every symbol of include/ucd_hip.h (checked by the CPU tests)
+SIGNATURES = {
+    "ucd_version": (_i, []),
+    "ucd_last_error": (C.c_char_p, []),
+    "ucd_abn_workspace_bytes": (_z, [_i, _i]),
+    "ucd_abn_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _z, _p]),
+    "ucd_abn_finalize": (_i, [_p, _f, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
+    "ucd_abn_eval_params": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
+    "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p]),
+    "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_abn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p,
+                               _f, _i, _i, _f, _p]),
+    "ucd_plane_sum": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "ucd_attmap_workspace_bytes": (_z, [_i, _i]),
+    "ucd_attmap": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "ucd_pixcon_prep_workspace_bytes": (_z, [_i, _i]),
+    "ucd_pixcon_prep": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
+    "ucd_pixcon_gather": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p]),
+    "ucd_pixcon_loss_workspace_bytes": (_z, [_i, _i, _i]),
+    "ucd_pixcon_loss": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _i, _f, _i, _i, _p, _p, _i, _p, _p, _z, _p]),
+    "ucd_pixcon_scatter_grad": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP kernels first (python -c 'import __graft_entry__ as g; "
+                f"g.build()' or make -C ucd_amd/csrc).  ucd_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _check(rc, name):
+    if rc != 0:
+        msg = load().ucd_last_error().decode(errors="replace")
+        raise RuntimeError(f"{name} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"ucd_amd kernels take float32 or bfloat16 activations, got {t.dtype}")
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device, tag="abn"):
+    """Grow-only scratch buffer per (device, tag); calls on one stream are ordered, so it is shared."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------------------------------------
+# activations as row matrices
+# ---------------------------------------------------------------------------------------------
+def rows_view(x):
+    """[B, C, H, W] tensor -> (tensor, M, C, HW, ld): the channels-last row matrix behind it.  The
+    tensor is returned unchanged when its strides already describe rows of C contiguous channels with
+    a constant pitch (a channels_last tensor or a channel slice of one); otherwise it is copied."""
+    B, Cc, H, W = x.shape
+    ok = _rows_ld(x)
+    if ok is None:
+        x = x.contiguous(memory_format=torch.channels_last)
+        ok = _rows_ld(x)
+        if ok is None:      # 1x1 maps etc. whose channels_last strides are ambiguous
+            x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            ok = Cc
+    return x, B * H * W, Cc, H * W, ok
+
+
+def _rows_ld(x):
+    B, Cc, H, W = x.shape
+    sb, sc, sh, sw = x.stride()
+    if Cc > 1 and sc != 1:
+        return None
+    if W > 1:
+        ld = sw
+    elif H > 1:
+        ld = sh
+    elif B > 1:
+        ld = sb
+    else:
+        ld = Cc
+    if ld < Cc:
+        return None
+    if W > 1 and H > 1 and sh != W * ld:
+        return None
+    if B > 1 and (H > 1 or W > 1) and sb != H * W * ld:
+        return None
+    if B > 1 and H == 1 and W == 1 and sb != ld:
+        return None
+    es = x.element_size()
+    if (x.data_ptr() % 16) or (ld * es) % 16:
+        return None
+    return ld
+
+
+def empty_like_rows(x, channels=None, dtype=None):
+    """New channels_last [B, C', H, W] tensor."""
+    B, Cc, H, W = x.shape
+    return torch.empty((B, channels or Cc, H, W), dtype=dtype or x.dtype, device=x.device,
+                       memory_format=torch.channels_last)
+
+
+# ---------------------------------------------------------------------------------------------
+# thin wrappers (no autograd)
+# ---------------------------------------------------------------------------------------------
+def abn_stats(x, ld, M, Cc, plane_bias, HW, sums):
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    _check(lib.ucd_abn_stats(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(ws), nbytes,
+                             stream()), "ucd_abn_stats")
+
+
+def abn_finalize(sums, count, Cc, weight, bias, running_mean, running_var, momentum, eps, mean, invstd, scale, shift):
+    _check(load().ucd_abn_finalize(ptr(sums), float(count), Cc, ptr(weight), ptr(bias), ptr(running_mean),
+                                   ptr(running_var), float(momentum), float(eps), ptr(mean), ptr(invstd), ptr(scale),
+                                   ptr(shift), stream()), "ucd_abn_finalize")
+
+
+def abn_eval_params(weight, bias, running_mean, running_var, eps, Cc, scale, shift):
+    _check(load().ucd_abn_eval_params(ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), float(eps), Cc,
+                                      ptr(scale), ptr(shift), stream()), "ucd_abn_eval_params")
+
+
+def abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, scale, shift, act, slope):
+    _check(load().ucd_abn_apply(ptr(x), ld_x, ptr(y), ld_y, ptr(residual), ld_r, dtype_code(x), M, Cc,
+                                ptr(plane_bias), HW, ptr(scale), ptr(shift), act, float(slope), stream()),
+           "ucd_abn_apply")
+
+
+def abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope, sums):
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    _check(lib.ucd_abn_bwd_reduce(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, dtype_code(x), M, Cc, ptr(plane_bias),
+                                  HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), act, float(slope), ptr(sums),
+                                  ptr(ws), nbytes, stream()), "ucd_abn_bwd_reduce")
+
+
+def abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane_bias, HW, mean, invstd, scale,
+                  shift, weight, sums, count, frozen, act, slope):
+    _check(load().ucd_abn_bwd_apply(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, ptr(dx), ld_dx, ptr(dz), ld_dz,
+                                    dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale),
+                                    ptr(shift), ptr(weight), ptr(sums), float(count), int(frozen), act, float(slope),
+                                    stream()), "ucd_abn_bwd_apply")
+
+
+def plane_sum(x, ld, B, HW, Cc, alpha, out):
+    _check(load().ucd_plane_sum(ptr(x), ld, dtype_code(x), B, HW, Cc, float(alpha), ptr(out), stream()),
+           "ucd_plane_sum")
+
+
+def attmap(x, ld_x, y, ld_y, B, HW, Cc):
+    lib = load()
+    nbytes = lib.ucd_attmap_workspace_bytes(B, HW)
+    ws = workspace(nbytes, x.device, "attmap")
+    _check(lib.ucd_attmap(ptr(x), ld_x, ptr(y), ld_y, dtype_code(x), B, HW, Cc, ptr(ws), nbytes, stream()),
+           "ucd_attmap")
