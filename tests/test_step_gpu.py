@@ -1,0 +1,125 @@
+"""GPU: the product's full UCD step (HIP ABN + fused contrastive + torch convs) in fp32 against
+(1) the golden captured from the reference's own classes and (2) the CPU oracle on identical inputs.
+Bar: losses and logits within 1e-3 relative (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from ucd_amd import argparser, synth, tasks
+
+pytestmark = pytest.mark.gpu
+
+
+def _opts(extra=()):
+    o = argparser.get_argparser().parse_args(["--method", "UCD", "--task", "15-5", "--step", "1", "--lr", "0.001",
+                                              "--no_pretrained", "--norm_act", "iabn_sync", *extra])
+    return argparser.modify_command_options(o)
+
+
+def _build(opts, dev):
+    from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+    classes = tasks.get_per_task_classes("voc", "15-5", 1)
+    torch.backends.cudnn.allow_tf32 = False
+    model, model_old = build_models(opts, dev, classes)
+    state = synth.fill_state_dict({k: v.cpu() for k, v in model_old.state_dict().items()}, 42)
+    load_step_checkpoint(opts, model, model_old, state, dev)
+    return model, model_old, classes
+
+
+def test_full_step_matches_reference_golden_fp32():
+    from ucd_amd.run import make_optimizer
+    from ucd_amd.train import Trainer
+    g = load_golden("ucd_step.npz")
+    dev = torch.device("cuda:0")
+    opts = _opts()
+    model, model_old, classes = _build(opts, dev)
+    trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+    optim = make_optimizer(opts, model)
+    img = synth.images(501, 2, 129)
+    labels = synth.seg_labels(501, 2, 129, 129, range(16, 21))
+    model.train()
+    r = trainer.train_step(img, labels, optim, None)
+    torch.cuda.synchronize()
+    assert r["ce"].item() == pytest.approx(float(g["ce"]), rel=1e-3)
+    assert r["con"].item() == pytest.approx(float(g["con"]), rel=1e-3)
+    assert r["loss"].item() == pytest.approx(float(g["loss"]), rel=1e-3)
+    assert r["lkd"].item() == pytest.approx(float(g["lkd"]), rel=1e-3)
+    params = dict(model.named_parameters())
+    names = [k.split("::")[1] for k in g if k.startswith("grad_abs::")]
+    for n in names:
+        assert params[n].grad.double().abs().sum().item() == pytest.approx(float(g[f"grad_abs::{n}"]), rel=5e-3), n
+        np.testing.assert_allclose(params[n].detach().flatten()[:16].cpu().numpy(), g[f"after_step::{n}"],
+                                   rtol=1e-3, atol=2e-6)
+    np.testing.assert_allclose(model.body.mod1.bn1.running_mean.cpu().numpy(), g["running_mean_after"],
+                               rtol=1e-4, atol=1e-6)
+
+
+def test_logits_and_features_match_reference_golden():
+    g = load_golden("model_full.npz")
+    dev = torch.device("cuda:0")
+    opts = _opts()
+    model, model_old, classes = _build(opts, dev)
+    img = synth.images(500, 2, 65).to(dev)
+    with torch.no_grad():
+        lt, ft = model_old(img.clone())
+        np.testing.assert_allclose(ft["sem"].cpu().numpy(), g["teacher_sem"], rtol=1e-3, atol=1e-3)
+        assert lt.double().abs().sum().item() == pytest.approx(float(g["teacher_logits_abs"]), rel=1e-3)
+        assert ft["pre_logits"].double().abs().sum().item() == pytest.approx(float(g["teacher_pl_abs"]), rel=1e-3)
+        assert ft["body"].double().abs().sum().item() == pytest.approx(float(g["teacher_body_abs"]), rel=1e-3)
+        model.eval()
+        ls, fs = model(img.clone())
+        np.testing.assert_allclose(fs["sem"].cpu().numpy(), g["student_eval_sem"], rtol=1e-3, atol=1e-3)
+    model.train()
+    ls, fs = model(img.clone())
+    np.testing.assert_allclose(fs["sem"].detach().cpu().numpy(), g["student_train_sem"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(ls.detach().flatten()[torch.from_numpy(g["sample_idx"]).to(dev)].cpu().numpy(),
+                               g["student_train_logits_sample"], rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(model.cls[1].bias.detach().cpu().numpy(), g["new_head_bias"], rtol=1e-6)
+
+
+def test_bf16_step_runs_and_is_close():
+    """Performance mode (--opt_level O1: bf16 activations): same step, looser stated tolerance (5e-2)."""
+    from ucd_amd.run import make_optimizer
+    from ucd_amd.train import Trainer
+    g = load_golden("ucd_step.npz")
+    dev = torch.device("cuda:0")
+    opts = _opts(["--opt_level", "O1"])
+    model, model_old, classes = _build(opts, dev)
+    trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+    optim = make_optimizer(opts, model)
+    img = synth.images(501, 2, 129)
+    labels = synth.seg_labels(501, 2, 129, 129, range(16, 21))
+    model.train()
+    r = trainer.train_step(img, labels, optim, None)
+    assert r["ce"].item() == pytest.approx(float(g["ce"]), rel=5e-2)
+    assert r["lkd"].item() == pytest.approx(float(g["lkd"]), rel=5e-2)
+    assert r["con"].item() == pytest.approx(float(g["con"]), rel=5e-2)
+    r2 = trainer.train_step(img, labels, optim, None)
+    assert torch.isfinite(r2["loss"]).item()
+
+
+def test_checkpoint_roundtrip_reference_layout(tmp_path):
+    """save_ckpt writes the reference's dictionary (run.py:32-43) with module.-prefixed keys."""
+    from ucd_amd.ddp import DistributedDataParallel
+    from ucd_amd.run import make_optimizer, save_ckpt
+    from ucd_amd.scheduler import PolyLR
+    from ucd_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    opts = _opts()
+    model, model_old, classes = _build(opts, dev)
+    optim = make_optimizer(opts, model)
+    sched = PolyLR(optim, max_iters=100)
+    ddp = DistributedDataParallel(model)
+    trainer = Trainer(ddp, model_old, device=dev, opts=opts, classes=classes)
+    path = str(tmp_path / "15-5-voc_test_1.pth")
+    save_ckpt(path, ddp, trainer, optim, sched, 3, 0.5)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"epoch", "model_state", "optimizer_state", "scheduler_state", "best_score", "trainer_state"}
+    keys = list(ck["model_state"])
+    assert all(k.startswith("module.") for k in keys)
+    for k in ("module.body.mod1.conv1.weight", "module.body.mod3.block2.convs.bn2.running_var",
+              "module.head.map_convs.3.weight", "module.head.red_bn.weight", "module.cls.1.bias"):
+        assert k in ck["model_state"], k
+    assert ck["trainer_state"] == {"regularizer": None}
+    ddp.load_state_dict(ck["model_state"], strict=True)

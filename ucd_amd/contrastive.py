@@ -78,18 +78,20 @@ def pixcon_prepare(f_n, labels, l_po, f_o, max_label=20, sort_by_label=True):
     pb.meta = torch.empty(hip.META_BYTES, dtype=torch.uint8, device=dev)
     nbytes = lib.ucd_pixcon_prep_workspace_bytes(BHW, K)
     ws = hip.workspace(nbytes, dev, "pixprep")
-    hip._check(lib.ucd_pixcon_prep(hip.ptr(labels), B, H, W, h, w, int(max_label), hip.ptr(t), K, hip.dtype_code(t), K,
-                                   int(bool(sort_by_label)), hip.ptr(pb.anchor_pix), hip.ptr(pb.old_pix),
-                                   hip.ptr(pb.row_label), hip.ptr(pb.prob), hip.ptr(pb.meta), hip.ptr(ws), nbytes,
-                                   hip.stream()), "ucd_pixcon_prep")
+    with hip._timed("ucd_pixcon_prep", BHW * (4 * 8 + K * t.element_size())):
+        hip._check(lib.ucd_pixcon_prep(hip.ptr(labels), B, H, W, h, w, int(max_label), hip.ptr(t), K, hip.dtype_code(t),
+                                       K, int(bool(sort_by_label)), hip.ptr(pb.anchor_pix), hip.ptr(pb.old_pix),
+                                       hip.ptr(pb.row_label), hip.ptr(pb.prob), hip.ptr(pb.meta), hip.ptr(ws), nbytes,
+                                       hip.stream()), "ucd_pixcon_prep")
     pb.ldp = (K + 1) & ~1
     pb.chat = torch.empty(rows, hip.PIXCON_LD, dtype=torch.float32, device=dev)
     pb.pcat = torch.empty(rows, pb.ldp, dtype=torch.float32, device=dev)
     pb.inv_norm = torch.empty(BHW, dtype=torch.float32, device=dev)
-    hip._check(lib.ucd_pixcon_gather(hip.ptr(fn2), ld_n, hip.ptr(fo2), ld_o, hip.dtype_code(fn2), BHW, N,
-                                     hip.ptr(pb.anchor_pix), hip.ptr(pb.old_pix), hip.ptr(pb.prob), K, hip.ptr(pb.meta),
-                                     hip.ptr(pb.chat), hip.PIXCON_LD, hip.ptr(pb.pcat), pb.ldp, hip.ptr(pb.inv_norm),
-                                     hip.stream()), "ucd_pixcon_gather")
+    with hip._timed("ucd_pixcon_gather", 2 * BHW * N * (fn2.element_size() + 4)):
+        hip._check(lib.ucd_pixcon_gather(hip.ptr(fn2), ld_n, hip.ptr(fo2), ld_o, hip.dtype_code(fn2), BHW, N,
+                                         hip.ptr(pb.anchor_pix), hip.ptr(pb.old_pix), hip.ptr(pb.prob), K,
+                                         hip.ptr(pb.meta), hip.ptr(pb.chat), hip.PIXCON_LD, hip.ptr(pb.pcat), pb.ldp,
+                                         hip.ptr(pb.inv_norm), hip.stream()), "ucd_pixcon_gather")
     return pb
 
 
@@ -102,10 +104,15 @@ def pixcon_loss_raw(pb, temperature=0.07, shift_pos=True, use_prob=True, need_gr
     stats = torch.zeros(3, pb.BHW, dtype=torch.float32, device=dev) if row_stats else None
     nbytes = lib.ucd_pixcon_loss_workspace_bytes(pb.BHW, pb.N, pb.K)
     ws = hip.workspace(nbytes, dev, "pixloss")
-    hip._check(lib.ucd_pixcon_loss(hip.ptr(pb.chat), hip.PIXCON_LD, pb.N, hip.ptr(pb.row_label), hip.ptr(pb.pcat), pb.ldp,
-                                   pb.K, hip.ptr(pb.meta), pb.BHW, float(temperature), int(bool(shift_pos)),
-                                   int(bool(use_prob)), hip.ptr(loss_out), hip.ptr(grad_a), hip.PIXCON_LD, hip.ptr(stats),
-                                   hip.ptr(ws), nbytes, hip.stream()), "ucd_pixcon_loss")
+    work = 0
+    if hip._timing is not None:     # instrumented bench pass only: algorithmic flops A*C*(4N+2K) need the counts
+        m = pb.meta_host()
+        work = float(m.A) * float(m.A + m.Co) * (4 * pb.N + 2 * pb.K)
+    with hip._timed("ucd_pixcon_loss", work):
+        hip._check(lib.ucd_pixcon_loss(hip.ptr(pb.chat), hip.PIXCON_LD, pb.N, hip.ptr(pb.row_label), hip.ptr(pb.pcat),
+                                       pb.ldp, pb.K, hip.ptr(pb.meta), pb.BHW, float(temperature), int(bool(shift_pos)),
+                                       int(bool(use_prob)), hip.ptr(loss_out), hip.ptr(grad_a), hip.PIXCON_LD,
+                                       hip.ptr(stats), hip.ptr(ws), nbytes, hip.stream()), "ucd_pixcon_loss")
     return loss_out, grad_a, stats
 
 

@@ -81,6 +81,41 @@ def _check(rc, name):
         raise RuntimeError(f"{name} failed (code {rc}): {msg}")
 
 
+# Optional per-call timing (bench.py's instrumented pass): HIP events recorded on the stream each
+# library call is launched on, with the call's algorithmic work (bytes or flops).
+_timing = None
+
+
+def enable_call_timing():
+    global _timing
+    _timing = {}
+    return _timing
+
+
+def disable_call_timing():
+    global _timing
+    _timing = None
+
+
+class _timed:
+    """with _timed(name, work): <library call>"""
+
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _timing is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream())
+
+    def __exit__(self, *exc):
+        if _timing is not None:
+            self.end.record(torch.cuda.current_stream())
+            _timing.setdefault(self.name, []).append((self.start, self.end, self.work))
+        return False
+
+
 def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -169,8 +204,9 @@ def abn_stats(x, ld, M, Cc, plane_bias, HW, sums):
     lib = load()
     nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
     ws = workspace(nbytes, x.device)
-    _check(lib.ucd_abn_stats(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(ws), nbytes,
-                             stream()), "ucd_abn_stats")
+    with _timed("ucd_abn_stats", M * Cc * x.element_size()):
+        _check(lib.ucd_abn_stats(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(ws), nbytes,
+                                 stream()), "ucd_abn_stats")
 
 
 def abn_finalize(sums, count, Cc, weight, bias, running_mean, running_var, momentum, eps, mean, invstd, scale, shift):
@@ -185,31 +221,35 @@ def abn_eval_params(weight, bias, running_mean, running_var, eps, Cc, scale, shi
 
 
 def abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, scale, shift, act, slope):
-    _check(load().ucd_abn_apply(ptr(x), ld_x, ptr(y), ld_y, ptr(residual), ld_r, dtype_code(x), M, Cc,
-                                ptr(plane_bias), HW, ptr(scale), ptr(shift), act, float(slope), stream()),
-           "ucd_abn_apply")
+    with _timed("ucd_abn_apply", M * Cc * x.element_size() * (2 + (residual is not None))):
+        _check(load().ucd_abn_apply(ptr(x), ld_x, ptr(y), ld_y, ptr(residual), ld_r, dtype_code(x), M, Cc,
+                                    ptr(plane_bias), HW, ptr(scale), ptr(shift), act, float(slope), stream()),
+               "ucd_abn_apply")
 
 
 def abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope, sums):
     lib = load()
     nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
     ws = workspace(nbytes, x.device)
-    _check(lib.ucd_abn_bwd_reduce(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, dtype_code(x), M, Cc, ptr(plane_bias),
-                                  HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), act, float(slope), ptr(sums),
-                                  ptr(ws), nbytes, stream()), "ucd_abn_bwd_reduce")
+    with _timed("ucd_abn_bwd_reduce", M * Cc * x.element_size() * (2 + (y is not None))):
+        _check(lib.ucd_abn_bwd_reduce(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, dtype_code(x), M, Cc,
+                                      ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), act,
+                                      float(slope), ptr(sums), ptr(ws), nbytes, stream()), "ucd_abn_bwd_reduce")
 
 
 def abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane_bias, HW, mean, invstd, scale,
                   shift, weight, sums, count, frozen, act, slope):
-    _check(load().ucd_abn_bwd_apply(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, ptr(dx), ld_dx, ptr(dz), ld_dz,
-                                    dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale),
-                                    ptr(shift), ptr(weight), ptr(sums), float(count), int(frozen), act, float(slope),
-                                    stream()), "ucd_abn_bwd_apply")
+    with _timed("ucd_abn_bwd_apply", M * Cc * x.element_size() * (3 + (y is not None) + (dz is not None))):
+        _check(load().ucd_abn_bwd_apply(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, ptr(dx), ld_dx, ptr(dz), ld_dz,
+                                        dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(mean), ptr(invstd),
+                                        ptr(scale), ptr(shift), ptr(weight), ptr(sums), float(count), int(frozen),
+                                        act, float(slope), stream()), "ucd_abn_bwd_apply")
 
 
 def plane_sum(x, ld, B, HW, Cc, alpha, out):
-    _check(load().ucd_plane_sum(ptr(x), ld, dtype_code(x), B, HW, Cc, float(alpha), ptr(out), stream()),
-           "ucd_plane_sum")
+    with _timed("ucd_plane_sum", B * HW * Cc * x.element_size()):
+        _check(load().ucd_plane_sum(ptr(x), ld, dtype_code(x), B, HW, Cc, float(alpha), ptr(out), stream()),
+               "ucd_plane_sum")
 
 
 def attmap(x, ld_x, y, ld_y, B, HW, Cc):

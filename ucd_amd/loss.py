@@ -1,0 +1,88 @@
+"""Losses of the ``--method UCD`` step, reference interface (utils/loss.py).
+
+``UnbiasedCrossEntropy`` (utils/loss.py:89-109) and ``UnbiasedKnowledgeDistillationLoss``
+(utils/loss.py:139-184) act on the full-resolution logits; this round they are a lean PyTorch
+composition on the GPU (SURVEY.md section 8 ranks their fusion with the bilinear up-sampling as the first
+"next" row, f1).  The contrastive loss lives in :mod:`ucd_amd.contrastive`.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .contrastive import PixelConLossV2, pre_contractive_pixel, ucd_contrastive_loss  # noqa: F401
+
+
+class UnbiasedCrossEntropy(nn.Module):
+    """Cross entropy in which the background competes as the pooled old classes:
+    ``log p(bkg) = LSE(x[:, :old_cl]) - LSE(x)``; labels below ``old_cl`` count as background."""
+
+    def __init__(self, old_cl=None, reduction="mean", ignore_index=255):
+        super().__init__()
+        self.reduction, self.ignore_index, self.old_cl = reduction, ignore_index, old_cl
+
+    def forward(self, inputs, targets):
+        old_cl = self.old_cl
+        inputs = inputs.float()
+        den = torch.logsumexp(inputs, dim=1)
+        log_bkg = torch.logsumexp(inputs[:, :old_cl], dim=1) - den
+        # gather instead of materialising the [B, Ctot, H, W] log-probability tensor (loss.py:99-102)
+        labels = torch.where(targets < old_cl, torch.zeros_like(targets), targets)   # loss.py:104-105
+        ignore = labels == self.ignore_index
+        idx = torch.where(ignore, torch.zeros_like(labels), labels)
+        picked = inputs.gather(1, idx.unsqueeze(1)).squeeze(1) - den
+        logp = torch.where(idx == 0, log_bkg, picked)
+        loss = torch.where(ignore, torch.zeros_like(logp), -logp)
+        if self.reduction == "none":
+            return loss
+        if self.reduction == "sum":
+            return loss.sum()
+        return loss.sum() / (~ignore).sum()      # nll_loss 'mean': over the non-ignored pixels
+
+
+class KnowledgeDistillationLoss(nn.Module):
+    """Plain soft-target distillation on the old classes (utils/loss.py:112-136)."""
+
+    def __init__(self, reduction="mean", alpha=1.):
+        super().__init__()
+        self.reduction, self.alpha = reduction, alpha
+
+    def forward(self, inputs, targets, mask=None):
+        inputs = inputs.narrow(1, 0, targets.shape[1]).float()
+        loss = (torch.log_softmax(inputs, dim=1) * torch.softmax(targets.float() * self.alpha, dim=1)).mean(dim=1)
+        if mask is not None:
+            loss = loss * mask.float()
+        if self.reduction == "mean":
+            return -loss.mean()
+        if self.reduction == "sum":
+            return -loss.sum()
+        return -loss
+
+
+class UnbiasedKnowledgeDistillationLoss(nn.Module):
+    """The student's background is compared with the teacher's as ``p(bkg or any new class)``
+    (utils/loss.py:162-174).  The reference also evaluates an unused ``gamma`` from a global average pool
+    (:155-156); it never reaches the output and is dropped."""
+
+    def __init__(self, reduction="mean", alpha=1.):
+        super().__init__()
+        self.reduction, self.alpha = reduction, alpha
+
+    def forward(self, inputs, targets, mask=None):
+        K = targets.shape[1]
+        inputs, targets = inputs.float(), targets.float() * self.alpha
+        den = torch.logsumexp(inputs, dim=1)
+        out_old = inputs[:, 1:K] - den.unsqueeze(1)
+        # LSE over {background} U {new classes}: index_select-free
+        bkg_new = torch.cat((inputs[:, :1], inputs[:, K:]), dim=1)
+        out_bkg = torch.logsumexp(bkg_new, dim=1) - den
+        q = torch.softmax(targets, dim=1)
+        loss = (q[:, 0] * out_bkg + (q[:, 1:] * out_old).sum(dim=1)) / K
+        if mask is not None:
+            loss = loss * mask.float()
+        if self.reduction == "mean":
+            return -loss.mean()
+        if self.reduction == "sum":
+            return -loss.sum()
+        return -loss

@@ -1,0 +1,163 @@
+"""Driver: ``python -m torch.distributed.run --nproc_per_node=N run.py --method UCD ...`` (reference
+run.py:116-400; launcher README.md:35).  Keeps the reference's control flow, optimiser / scheduler
+semantics (run.py:175-189) and checkpoint layout (run.py:32-43: ``checkpoints/step/{task}-{dataset}_
+{name}_{step}.pth`` with keys epoch, model_state [``module.``-prefixed], optimizer_state, scheduler_state,
+best_score, trainer_state).  Data: the PIL dataset pipeline of the reference (dataset/*) is outside this
+round's scope; ``--data_root synthetic`` (or a missing data directory) trains on
+the closed-form synthetic batches the benchmark uses.
+"""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import argparser, synth, tasks
+from .ddp import DistributedDataParallel
+from .logger import Logger
+from .metrics import StreamSegMetrics
+from .scheduler import PolyLR
+from .segmentation_module import make_model
+from .train import Trainer
+
+
+def save_ckpt(path, model, trainer, optimizer, scheduler, epoch, best_score):
+    """Same dictionary as the reference (run.py:32-43)."""
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    torch.save({"epoch": epoch, "model_state": model.state_dict(), "optimizer_state": optimizer.state_dict(),
+                "scheduler_state": scheduler.state_dict(), "best_score": best_score,
+                "trainer_state": trainer.state_dict()}, path)
+
+
+def make_optimizer(opts, model):
+    """Three parameter groups (body unless --freeze, head, cls), trainable tensors only, SGD with
+    momentum 0.9 and Nesterov (run.py:175-186)."""
+    net = model.module if hasattr(model, "module") else model
+    groups = []
+    if not opts.freeze:
+        groups.append({"params": [p for p in net.body.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
+    groups.append({"params": [p for p in net.head.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
+    groups.append({"params": [p for p in net.cls.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
+    kw = {"fused": True} if next(net.parameters()).is_cuda else {}
+    return torch.optim.SGD(groups, lr=opts.lr, momentum=0.9, nesterov=True, **kw)
+
+
+class SyntheticSegmentation(torch.utils.data.Dataset):
+    """Closed-form stand-in for {Voc,Ade,City}SegmentationIncremental at a given step: normalised images,
+    labels in {0, new ids, 255} (old classes already mapped to background, dataset/voc.py:182-208)."""
+
+    def __init__(self, n, crop, new_ids, seed=0):
+        self.n, self.crop, self.new_ids, self.seed = n, crop, list(new_ids), seed
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        img = synth.images(self.seed * 100003 + i, 1, self.crop)[0]
+        lab = synth.seg_labels(self.seed * 100003 + i, 1, self.crop, self.crop, self.new_ids)[0]
+        return img, lab
+
+
+def build_models(opts, device, classes):
+    """Student (all heads) and, for step > 0, the teacher (previous heads) on ``device``."""
+    model = make_model(opts, classes=classes).to(device)
+    model_old = make_model(opts, classes=classes[:-1]).to(device) if opts.step > 0 else None
+    if opts.fix_bn:
+        model.fix_bn()
+    return model, model_old
+
+
+def load_step_checkpoint(opts, model, model_old, state, device):
+    """run.py:207-233: previous-step weights into student and teacher (strict=False because of the new
+    head), balanced init of the new head, teacher frozen in eval mode."""
+    target = model.module if hasattr(model, "module") else model
+    strip = lambda sd: {k[len("module."):] if k.startswith("module.") else k: v for k, v in sd.items()}
+    target.load_state_dict(strip(state), strict=False)
+    if opts.init_balanced:
+        target.init_new_classifier(device)
+    old = model_old.module if hasattr(model_old, "module") else model_old
+    old.load_state_dict(strip(state), strict=False)
+    for p in model_old.parameters():
+        p.requires_grad = False
+    model_old.eval()
+
+
+def main(opts):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", opts.MASTER_PORT)
+    use_cuda = torch.cuda.is_available()
+    local_rank = int(os.environ.get("LOCAL_RANK", opts.local_rank))
+    if "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        dist.init_process_group(backend="nccl" if use_cuda else "gloo")
+    else:
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="nccl" if use_cuda else "gloo", rank=0, world_size=1)
+    device = torch.device("cuda", local_rank) if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    rank, world_size = dist.get_rank(), dist.get_world_size()
+    task_name = f"{opts.task}-{opts.dataset}"
+    logger = Logger(f"{opts.logdir}/{task_name}/{opts.name}/", rank=rank, debug=opts.debug, step=opts.step)
+    logger.info(f"Device: {device}; total batch size {opts.batch_size * world_size}")
+    torch.manual_seed(opts.random_seed); np.random.seed(opts.random_seed); random.seed(opts.random_seed)
+
+    classes = tasks.get_per_task_classes(opts.dataset, opts.task, opts.step)
+    labels, labels_old, _ = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
+    if opts.data_root != "synthetic" and os.path.isdir(os.path.join(opts.data_root, opts.dataset)):
+        raise NotImplementedError("the PIL dataset pipeline is outside this round's scope (SURVEY.md 8-f2); "
+                                  "use --data_root synthetic")
+    n_train = 24 * 8
+    train_dst = SyntheticSegmentation(n_train, opts.crop_size, [l for l in labels if l != 0] or [1], seed=opts.step)
+    sampler = torch.utils.data.distributed.DistributedSampler(train_dst, num_replicas=world_size, rank=rank)
+    train_loader = torch.utils.data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler,
+                                               num_workers=opts.num_workers, drop_last=True)
+    model, model_old = build_models(opts, device, classes)
+    optimizer = make_optimizer(opts, model)
+    scheduler = PolyLR(optimizer, max_iters=opts.epochs * len(train_loader), power=opts.lr_power)
+    model = DistributedDataParallel(model, delay_allreduce=True)
+    if opts.step > 0:
+        path = opts.step_ckpt or f"checkpoints/step/{task_name}_{opts.name}_{opts.step - 1}.pth"
+        if os.path.exists(path):
+            ckpt = torch.load(path, map_location="cpu")
+            load_step_checkpoint(opts, model, model_old, ckpt["model_state"], device)
+            logger.info(f"[!] Previous model loaded from {path}")
+        elif not opts.debug:
+            raise FileNotFoundError(path)
+        for p in model_old.parameters():
+            p.requires_grad = False
+        model_old.eval()
+    trainer = Trainer(model, model_old, device=device, opts=opts, classes=classes)
+
+    cur_epoch, best_score = 0, 0.0
+    if opts.ckpt is not None and os.path.isfile(opts.ckpt):
+        ckpt = torch.load(opts.ckpt, map_location="cpu")
+        model.load_state_dict(ckpt["model_state"], strict=True)
+        optimizer.load_state_dict(ckpt["optimizer_state"])
+        scheduler.load_state_dict(ckpt["scheduler_state"])
+        cur_epoch, best_score = ckpt["epoch"] + 1, ckpt["best_score"]
+    ckpt_path = f"checkpoints/step/{task_name}_{opts.name}_{opts.step}.pth"
+    while cur_epoch < opts.epochs and not opts.test:
+        epoch_loss = trainer.train(cur_epoch=cur_epoch, optim=optimizer, train_loader=train_loader,
+                                   scheduler=scheduler, print_int=opts.print_interval, logger=logger)
+        logger.info(f"End of Epoch {cur_epoch}/{opts.epochs}, Average Loss={float(epoch_loss[0]) + float(epoch_loss[1])}")
+        if rank == 0 and (cur_epoch + 1) % opts.ckpt_interval == 0:
+            save_ckpt(ckpt_path, model, trainer, optimizer, scheduler, cur_epoch, best_score)
+        dist.barrier()
+        cur_epoch += 1
+    if rank == 0 and not opts.test:
+        save_ckpt(ckpt_path, model, trainer, optimizer, scheduler, cur_epoch, best_score)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def cli():
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args())
+    os.makedirs("checkpoints/step", exist_ok=True)
+    main(opts)
+
+
+if __name__ == "__main__":
+    cli()

@@ -100,9 +100,11 @@ def fill_state_dict(state: dict, seed: int = 42) -> dict:
     """Deterministic stand-in for a trained checkpoint (there is no network for the real
     ``pretrained/resnet101_iabn_sync.pth.tar``): He-scaled conv weights, norm scales near 1 (positive,
     as in the pretrained ABN files), small biases / running means, running variances near 1.  Values
-    depend only on (seed, key order, shape); keys are visited in sorted order."""
+    depend only on (seed, key name, shape) - not on which other keys are present."""
+    import zlib
     out = {}
-    for i, k in enumerate(sorted(state)):
+    for k in sorted(state):
+        i = zlib.crc32(k.encode()) & 0x3FFFFFFF
         v = state[k]
         if not torch.is_floating_point(v):
             out[k] = v.clone()

@@ -1,0 +1,193 @@
+"""``Trainer``: one UCD training iteration on an MI355X, reference interface (train.py:15-384).
+
+``Trainer(model, model_old, device, opts, trainer_state, classes)`` and
+``.train(cur_epoch, optim, train_loader, scheduler, print_int, logger) -> (epoch_loss, reg_loss)`` keep
+the reference's call shapes.  The iteration is the reference's ``train.py:95-151`` with the UCD branch
+repaired as intended (``pre_contractive_pixel`` returns five values and
+``PixelConLossV2`` takes five):
+
+    teacher forward (eval, no grad)          train.py:100-102
+    student forward (train)                  :108
+    loss = mean(CE(out, labels)) + PixCon(student/teacher pre-logits) / 100          :115-116
+    lkd  = loss_kd * KD(out, out_old)        :131-133
+    backward; gradient all-reduce; SGD; PolyLR step                                   :135-151
+
+What changed for the hardware: activations are channels-last bf16 (``--opt_level`` O1..O3) or fp32 (O0);
+the contrastive term is one fused HIP operation with no host round trip; the per-iteration ``.item()``
+reads (train.py:153-157, >= 5 device syncs) are replaced by device-side accumulators read once per
+``print_int`` iterations; gradient averaging overlaps the backward (ucd_amd.ddp).
+Out of scope on this path (raise ``NotImplementedError``): BCE/iCaRL losses and the EWC/RW/PI
+regularisers of the other baselines.
+"""
+from __future__ import annotations
+
+from functools import reduce
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .contrastive import ucd_contrastive_loss
+from .loss import KnowledgeDistillationLoss, UnbiasedCrossEntropy, UnbiasedKnowledgeDistillationLoss
+
+
+def _raw(features, name):
+    return features.raw(name) if hasattr(features, "raw") else features[name]
+
+
+class Trainer:
+    def __init__(self, model, model_old, device, opts, trainer_state=None, classes=None):
+        self.model_old, self.model, self.device = model_old, model, device
+        if classes is not None:
+            tot_classes = reduce(lambda a, b: a + b, classes)
+            self.old_classes = tot_classes - classes[-1]
+            self.tot_classes = tot_classes
+        else:
+            self.old_classes, self.tot_classes = 0, getattr(opts, "num_classes", None) or 21
+        if opts.bce or opts.icarl:
+            raise NotImplementedError("BCE / iCaRL (--bce, --icarl, --method LWF-MC) are other baselines, "
+                                      "outside the UCD hot path")
+        if getattr(opts, "regularizer", None) is not None:
+            raise NotImplementedError("EWC / RW / PI regularisers are outside the UCD hot path")
+        self.temperature = opts.temperature
+        # the reference clamps down-sampled labels at the VOC bound 20 (utils/utils.py:267-268); datasets
+        # with more classes need the real bound
+        self.max_label = max(20, self.tot_classes - 1)
+        if opts.unce and self.old_classes != 0:
+            self.criterion = UnbiasedCrossEntropy(old_cl=self.old_classes, ignore_index=255, reduction="none")
+        else:
+            self.criterion = nn.CrossEntropyLoss(ignore_index=255, reduction="none")
+        self.lde = opts.loss_de
+        self.lde_flag = self.lde > 0. and model_old is not None
+        self.lde_loss = nn.MSELoss()
+        self.lkd = opts.loss_kd
+        self.lkd_flag = self.lkd > 0. and model_old is not None
+        self.lkd_loss = (UnbiasedKnowledgeDistillationLoss if opts.unkd else KnowledgeDistillationLoss)(alpha=opts.alpha)
+        self.regularizer, self.regularizer_flag = None, False
+        self.ret_intermediate = self.lde
+        self.amp = getattr(opts, "opt_level", "O0") != "O0"
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------
+    def _autocast(self):
+        return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp and self.device.type == "cuda")
+
+    def train_step(self, images, labels, optim, scheduler=None):
+        """One iteration; returns device scalars (no host synchronisation)."""
+        model, model_old = self.model, self.model_old
+        images = images.to(self.device, dtype=torch.float32, non_blocking=True)
+        labels = labels.to(self.device, dtype=torch.long, non_blocking=True)
+        if self.device.type == "cuda":
+            images = images.contiguous(memory_format=torch.channels_last)
+        zero = torch.zeros((), device=self.device)
+        lkd = lde = zero
+        if model_old is not None:
+            with torch.no_grad(), self._autocast():
+                outputs_old, features_old = model_old(images, x_b_old=None, x_pl_old=None,
+                                                      ret_intermediate=self.ret_intermediate)
+        if hasattr(model, "zero_grad") and hasattr(model, "finish_grad_sync"):
+            model.zero_grad()
+        else:
+            optim.zero_grad(set_to_none=True)
+        with self._autocast():
+            if model_old is None:
+                outputs, features = model(images, ret_intermediate=self.ret_intermediate)
+            else:
+                outputs, features = model(images, x_b_old=_raw(features_old, "body"),
+                                          x_pl_old=_raw(features_old, "pre_logits"),
+                                          ret_intermediate=self.ret_intermediate)
+        ce = self.criterion(outputs.float() if outputs.dtype != torch.float32 else outputs, labels).mean()
+        con = zero
+        if model_old is not None:
+            con = ucd_contrastive_loss(_raw(features, "pre_logits"), labels, features_old["sem"],
+                                       _raw(features_old, "pre_logits"), self.temperature, self.max_label)
+        loss = ce + con / 100                                                     # train.py:116
+        if self.lde_flag:
+            lde = self.lde * (self.lde_loss(features["body"].float(), features_old["body"].float())
+                              + self.lde_loss(features["pre_logits"].float(), features_old["pre_logits"].float()))
+        if self.lkd_flag:
+            lkd = self.lkd * self.lkd_loss(outputs, outputs_old)                  # train.py:131-133
+        loss_tot = loss + lkd + lde
+        loss_tot.backward()
+        if hasattr(model, "finish_grad_sync"):
+            model.finish_grad_sync()
+        optim.step()
+        if scheduler is not None:
+            scheduler.step()
+        self.last = {"loss": loss.detach(), "lkd": lkd.detach(), "lde": lde.detach(), "ce": ce.detach(),
+                     "con": con.detach()}
+        return self.last
+
+    def train(self, cur_epoch, optim, train_loader, scheduler=None, print_int=10, logger=None):
+        """Train one epoch and return (epoch_loss, reg_loss) like the reference (train.py:76-183)."""
+        if logger is not None:
+            logger.info("Epoch %d, lr = %f" % (cur_epoch, optim.param_groups[0]["lr"]))
+        dev = self.device
+        epoch_loss = torch.zeros((), device=dev)
+        reg_loss = torch.zeros((), device=dev)
+        interval = torch.zeros((), device=dev)
+        if hasattr(train_loader, "sampler") and hasattr(train_loader.sampler, "set_epoch"):
+            train_loader.sampler.set_epoch(cur_epoch)
+        self.model.train()
+        n = 0
+        for cur_step, (images, labels) in enumerate(train_loader):
+            r = self.train_step(images, labels, optim, scheduler)
+            epoch_loss += r["loss"]
+            reg_loss += r["lkd"] + r["lde"]
+            interval += r["loss"] + r["lkd"] + r["lde"]
+            n += 1
+            if (cur_step + 1) % print_int == 0:
+                value = (interval / print_int).item()           # the only host sync of the interval
+                if logger is not None:
+                    logger.info(f"Epoch {cur_epoch}, Batch {cur_step + 1}/{len(train_loader)}, Loss={value}")
+                    logger.add_scalar("Loss", value, cur_epoch * len(train_loader) + cur_step + 1)
+                interval.zero_()
+        if dist.is_available() and dist.is_initialized():
+            dist.reduce(epoch_loss, dst=0)
+            dist.reduce(reg_loss, dst=0)
+            world = dist.get_world_size()
+            rank = dist.get_rank()
+        else:
+            world, rank = 1, 0
+        if rank == 0 and n:
+            epoch_loss = epoch_loss / world / n
+            reg_loss = reg_loss / world / n
+        if logger is not None:
+            logger.info(f"Epoch {cur_epoch}, Class Loss={epoch_loss}, Reg Loss={reg_loss}")
+        return (epoch_loss, reg_loss)
+
+    def validate(self, loader, metrics, ret_samples_ids=None, logger=None):
+        """Evaluation loop (train.py:185-270): class loss + confusion matrix, accumulated on the device."""
+        metrics.reset()
+        model = self.model
+        dev = self.device
+        class_loss = torch.zeros((), device=dev)
+        reg_loss = torch.zeros((), device=dev)
+        model.eval()
+        n = 0
+        with torch.no_grad():
+            for images, labels in loader:
+                images = images.to(dev, dtype=torch.float32)
+                labels = labels.to(dev, dtype=torch.long)
+                with self._autocast():
+                    outputs, _ = model(images, ret_intermediate=False)
+                class_loss += self.criterion(outputs.float(), labels.clone()).mean()
+                metrics.update(labels, outputs.argmax(dim=1))
+                n += 1
+            metrics.synch(dev)
+            score = metrics.get_results()
+        if dist.is_available() and dist.is_initialized():
+            dist.reduce(class_loss, dst=0)
+            world = dist.get_world_size()
+        else:
+            world = 1
+        class_loss = class_loss / world / max(n, 1)
+        if logger is not None:
+            logger.info(f"Validation, Class Loss={class_loss}, Reg Loss={reg_loss} (without scaling)")
+        return (class_loss, reg_loss), score, []
+
+    def state_dict(self):
+        return {"regularizer": None}
+
+    def load_state_dict(self, state):
+        pass
