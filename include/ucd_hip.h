@@ -35,6 +35,7 @@ typedef void* ucd_stream_t; /* hipStream_t */
 
 enum ucd_dtype { UCD_F32 = 0, UCD_BF16 = 1 };
 enum ucd_act { UCD_ACT_IDENTITY = 0, UCD_ACT_LEAKY_RELU = 1 };
+enum ucd_pixcon_precision { UCD_PIXCON_F32 = 0, UCD_PIXCON_F16 = 1 };
 enum ucd_error {
   UCD_OK = 0,
   UCD_EINVAL = -1,      /* bad argument (null pointer, negative size, unknown enum) */
@@ -177,6 +178,8 @@ int ucd_pixcon_prep(const int64_t* labels, int B, int H, int W, int h, int w, in
 int ucd_pixcon_gather(const void* f_n, int ld_n, const void* f_o, int ld_o, int dtype, int BHW, int N,
                       const int32_t* anchor_pix, const int32_t* old_pix, const float* prob, int K,
                       const ucd_pixcon_meta* meta, float* chat, int ldc, float* pcat, int ldp,
+                      void* ch16 /* fp16 [Cpad, ldc] copy of chat, or NULL */,
+                      void* p16 /* fp16 [Cpad, 2, K rounded up to 16]: hi | lo split of pcat, or NULL */,
                       float* inv_norm, ucd_stream_t stream);
 
 size_t ucd_pixcon_loss_workspace_bytes(int BHW, int N, int K);
@@ -190,9 +193,14 @@ size_t ucd_pixcon_loss_workspace_bytes(int BHW, int N, int K);
  * chat [Cpad, ldc] / pcat [Cpad, ldp] / row_label are the outputs of ucd_pixcon_prep + ucd_pixcon_gather
  * (ldc must be 256: feature rows zero-padded to 256 columns; ldp >= K rounded up to even).
  * loss_out[0] = loss, loss_out[1] = number of valid rows.  row_stats (optional, [3, BHW]) receives
- * neg_i, num_i and the per-row loss for inspection.  float32 MFMA arithmetic throughout. */
+ * neg_i, num_i and the per-row loss for inspection.
+ * precision = UCD_PIXCON_F32: exact float32 MFMA (v_mfma_f32_32x32x2_f32) on chat / pcat - the parity
+ * mode; UCD_PIXCON_F16: fp16 operands ch16 / p16 (from ucd_pixcon_gather), fp32 accumulation
+ * (v_mfma_f32_32x32x16_f16, 16x the rate) with an online rescale of the negative sums - the
+ * performance mode; loss within ~1e-4, gradients within ~1e-3 of the float32 path. */
 int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label,
-                    const float* pcat, int ldp, int K, const ucd_pixcon_meta* meta, int BHW,
+                    const float* pcat, int ldp, int K, const void* ch16, const void* p16, int precision,
+                    const ucd_pixcon_meta* meta, int BHW,
                     float temperature, int shift_pos, int use_prob,
                     float* loss_out, float* grad_a /* [BHW, ldg] */, int ldg, float* row_stats,
                     void* workspace, size_t workspace_bytes, ucd_stream_t stream);

@@ -151,3 +151,63 @@ def test_bf16_inputs_and_no_new_pixels():
     assert x.grad.dtype == torch.bfloat16
     scale = ref_in.grad.abs().max().item()
     assert (x.grad.float().cpu() - ref_in.grad).abs().max().item() / scale < 1e-2
+
+
+@pytest.mark.parametrize("B,N,h,K,H,new_ids,max_label", [
+    (3, 256, 33, 16, 513, list(range(16, 21)), 20),
+    (2, 64, 12, 101, 192, list(range(101, 151)), 150),
+    (2, 32, 9, 16, 129, [16], 20),
+])
+def test_fp16_performance_mode_vs_oracle(B, N, h, K, H, new_ids, max_label):
+    """fp16-operand sweep (v_mfma_f32_32x32x16_f16, online negative-max rescale): loss within 1e-3 relative
+    of the fp32 oracle (north_star bar); gradient within 2e-3 of its largest entry (stated tolerance of the
+    performance mode: operand rounding 2^-11 on unit vectors)."""
+    from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare, ucd_contrastive_loss
+    f_n, f_o, l_po, labels = synth.contrastive_case(2000 + N + h, B, N, h, h, K, H, H, new_ids)
+    ref_in = f_n.clone().requires_grad_(True)
+    prep = OC.pre_contrastive_pixel(ref_in, labels, l_po, f_o, max_label=max_label)
+    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    ref.backward()
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    fn_d = fn_d.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    _, da, neg, G, num = OC.pixcon_loss_backward(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    for sort in (False, True):
+        pb = pixcon_prepare(fn_d.detach(), lab_d, lpo_d, fo_d, max_label=max_label, sort_by_label=sort, fp16=True)
+        loss_out, grad_a, stats = pixcon_loss_raw(pb, 0.07, True, True, need_grad=True, row_stats=True, precision="f16")
+        assert abs(loss_out[0].item() - ref.item()) / abs(ref.item()) < 1e-3
+        if not sort:
+            m = pb.meta_host()
+            torch.testing.assert_close(stats[0, :m.A].cpu().double(), neg, rtol=2e-3, atol=0)
+            err = (grad_a[:m.A, :N].cpu().double() - da).abs().max().item() / da.abs().max().item()
+            assert err < 2e-3, err
+    loss = ucd_contrastive_loss(fn_d, lab_d, lpo_d, fo_d, 0.07, max_label, "f16")
+    loss.backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-3
+    scale = ref_in.grad.abs().max().item()
+    assert (fn_d.grad.cpu() - ref_in.grad).abs().max().item() / scale < 2e-3
+
+
+def test_fp16_rescale_branch_is_exercised():
+    """Force the online-maximum rescale: anchors whose first contrast tiles are far (cos ~ -1) and whose
+    later tiles are near (cos ~ +1) raise the running negative maximum by ~2/0.07*log2(e) = 41 log2 units,
+    far past the 2^8 threshold, at a chosen tile."""
+    from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare
+    B, N, h, K, H = 2, 64, 16, 16, 256
+    f_n, f_o, l_po, labels = synth.contrastive_case(4242, B, N, h, h, K, H, H, list(range(16, 21)))
+    # student features: a fixed direction per image half so early rows oppose late rows
+    d = torch.nn.functional.normalize(synth.t_normal(1, (N,), stream=9), dim=0)
+    f_n = 0.05 * f_n
+    f_n[0] += d[None, :, None, None].expand(1, N, h, h)[0]
+    f_n[1] -= d[None, :, None, None].expand(1, N, h, h)[0]
+    ref_in = f_n.clone().requires_grad_(True)
+    prep = OC.pre_contrastive_pixel(ref_in, labels, l_po, f_o)
+    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    _, da, neg, G, num = OC.pixcon_loss_backward(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    pb = pixcon_prepare(fn_d.contiguous(memory_format=torch.channels_last), lab_d, lpo_d, fo_d, sort_by_label=False, fp16=True)
+    loss_out, grad_a, stats = pixcon_loss_raw(pb, 0.07, True, True, need_grad=True, row_stats=True, precision="f16")
+    m = pb.meta_host()
+    assert abs(loss_out[0].item() - ref.item()) / abs(ref.item()) < 1e-3
+    torch.testing.assert_close(stats[0, :m.A].cpu().double(), neg, rtol=3e-3, atol=0)
+    err = (grad_a[:m.A, :N].cpu().double() - da).abs().max().item() / da.abs().max().item()
+    assert err < 3e-3, err

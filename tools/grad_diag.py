@@ -11,6 +11,8 @@ from oracle import step as OS, model as OM
 from oracle.params import template_state
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 129
+if len(sys.argv) > 2 and sys.argv[2] == "nomiopen":
+    torch.backends.cudnn.enabled = False      # native (exact fp32) convolution kernels instead of MIOpen
 dev = torch.device("cuda:0")
 opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
     ["--method", "UCD", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained"]))

@@ -27,7 +27,7 @@ class PixconBatch:
     """Device-resident anchor / contrast sets of one batch (outputs of the prep + gather kernels)."""
 
     __slots__ = ("BHW", "N", "K", "anchor_pix", "old_pix", "row_label", "prob", "meta", "chat", "pcat",
-                 "inv_norm", "ldp", "sorted", "f_dtype")
+                 "inv_norm", "ldp", "sorted", "f_dtype", "ch16", "p16")
 
     def meta_host(self):
         """Copy the meta record to the host (tests / logging only: this synchronises)."""
@@ -41,7 +41,7 @@ def _rows2d(t, what):
     return t2, M, Cc, ld
 
 
-def pixcon_prepare(f_n, labels, l_po, f_o, max_label=20, sort_by_label=True):
+def pixcon_prepare(f_n, labels, l_po, f_o, max_label=20, sort_by_label=True, fp16=False):
     """Run ucd_pixcon_prep + ucd_pixcon_gather.  ``f_n``/``f_o``: [B, N, h, w] student / teacher
     pre-logits (any strides; channels-last is zero-copy), ``labels``: [B, H, W] int64,
     ``l_po``: [B, K, h, w] teacher low-resolution logits."""
@@ -87,17 +87,28 @@ def pixcon_prepare(f_n, labels, l_po, f_o, max_label=20, sort_by_label=True):
     pb.chat = torch.empty(rows, hip.PIXCON_LD, dtype=torch.float32, device=dev)
     pb.pcat = torch.empty(rows, pb.ldp, dtype=torch.float32, device=dev)
     pb.inv_norm = torch.empty(BHW, dtype=torch.float32, device=dev)
+    pb.ch16 = pb.p16 = None
+    if fp16:
+        pb.ch16 = torch.empty(rows, hip.PIXCON_LD, dtype=torch.float16, device=dev)
+        pb.p16 = torch.empty(rows, 2 * ((K + 15) // 16 * 16), dtype=torch.float16, device=dev)
     with hip._timed("ucd_pixcon_gather", 2 * BHW * N * (fn2.element_size() + 4)):
         hip._check(lib.ucd_pixcon_gather(hip.ptr(fn2), ld_n, hip.ptr(fo2), ld_o, hip.dtype_code(fn2), BHW, N,
                                          hip.ptr(pb.anchor_pix), hip.ptr(pb.old_pix), hip.ptr(pb.prob), K,
                                          hip.ptr(pb.meta), hip.ptr(pb.chat), hip.PIXCON_LD, hip.ptr(pb.pcat), pb.ldp,
-                                         hip.ptr(pb.inv_norm), hip.stream()), "ucd_pixcon_gather")
+                                         hip.ptr(pb.ch16), hip.ptr(pb.p16), hip.ptr(pb.inv_norm), hip.stream()),
+                   "ucd_pixcon_gather")
     return pb
 
 
-def pixcon_loss_raw(pb, temperature=0.07, shift_pos=True, use_prob=True, need_grad=True, row_stats=False):
-    """ucd_pixcon_loss on a prepared batch: returns (loss_out[2], grad_a or None, row_stats or None)."""
+def pixcon_loss_raw(pb, temperature=0.07, shift_pos=True, use_prob=True, need_grad=True, row_stats=False,
+                    precision="f32"):
+    """ucd_pixcon_loss on a prepared batch: returns (loss_out[2], grad_a or None, row_stats or None).
+    precision "f32" = exact-fp32 MFMA parity mode, "f16" = fp16-operand performance mode (needs a batch
+    prepared with fp16=True)."""
     lib = hip.load()
+    prec = hip.PIXCON_PRECISION[precision]
+    if prec == hip.PIXCON_F16 and pb.ch16 is None:
+        raise RuntimeError("precision='f16' needs pixcon_prepare(..., fp16=True)")
     dev = pb.chat.device
     loss_out = torch.empty(2, dtype=torch.float32, device=dev)
     grad_a = torch.empty(pb.BHW, hip.PIXCON_LD, dtype=torch.float32, device=dev) if need_grad else None
@@ -108,19 +119,22 @@ def pixcon_loss_raw(pb, temperature=0.07, shift_pos=True, use_prob=True, need_gr
     if hip._timing is not None:     # instrumented bench pass only: algorithmic flops A*C*(4N+2K) need the counts
         m = pb.meta_host()
         work = float(m.A) * float(m.A + m.Co) * (4 * pb.N + 2 * pb.K)
-    with hip._timed("ucd_pixcon_loss", work):
+    with hip._timed("ucd_pixcon_loss[%s]" % precision, work):
         hip._check(lib.ucd_pixcon_loss(hip.ptr(pb.chat), hip.PIXCON_LD, pb.N, hip.ptr(pb.row_label), hip.ptr(pb.pcat),
-                                       pb.ldp, pb.K, hip.ptr(pb.meta), pb.BHW, float(temperature), int(bool(shift_pos)),
-                                       int(bool(use_prob)), hip.ptr(loss_out), hip.ptr(grad_a), hip.PIXCON_LD,
-                                       hip.ptr(stats), hip.ptr(ws), nbytes, hip.stream()), "ucd_pixcon_loss")
+                                       pb.ldp, pb.K, hip.ptr(pb.ch16), hip.ptr(pb.p16), prec, hip.ptr(pb.meta), pb.BHW,
+                                       float(temperature), int(bool(shift_pos)), int(bool(use_prob)),
+                                       hip.ptr(loss_out), hip.ptr(grad_a), hip.PIXCON_LD, hip.ptr(stats), hip.ptr(ws),
+                                       nbytes, hip.stream()), "ucd_pixcon_loss")
     return loss_out, grad_a, stats
 
 
 class _FusedContrastive(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, f_n, labels, l_po, f_o, temperature, max_label):
-        pb = pixcon_prepare(f_n, labels, l_po, f_o, max_label=max_label, sort_by_label=True)
-        loss_out, grad_a, _ = pixcon_loss_raw(pb, temperature, True, True, need_grad=ctx.needs_input_grad[0])
+    def forward(ctx, f_n, labels, l_po, f_o, temperature, max_label, precision):
+        pb = pixcon_prepare(f_n, labels, l_po, f_o, max_label=max_label, sort_by_label=True,
+                            fp16=hip.PIXCON_PRECISION[precision] == hip.PIXCON_F16)
+        loss_out, grad_a, _ = pixcon_loss_raw(pb, temperature, True, True, need_grad=ctx.needs_input_grad[0],
+                                              precision=precision)
         ctx.pb, ctx.grad_a, ctx.shape, ctx.dtype = pb, grad_a, f_n.shape, f_n.dtype
         return loss_out[0].clone()
 
@@ -135,13 +149,14 @@ class _FusedContrastive(torch.autograd.Function):
                                                hip.ptr(pb.anchor_pix), hip.ptr(pb.meta), hip.ptr(gs), hip.ptr(d), N,
                                                hip.dtype_code(d), pb.BHW, N, hip.stream()), "ucd_pixcon_scatter_grad")
         ctx.pb = ctx.grad_a = None
-        return d, None, None, None, None, None
+        return d, None, None, None, None, None, None
 
 
-def ucd_contrastive_loss(f_n, labels, l_po, f_o, temperature=0.07, max_label=20):
+def ucd_contrastive_loss(f_n, labels, l_po, f_o, temperature=0.07, max_label=20, precision="f32"):
     """``PixelConLossV2(T)(*pre_contractive_pixel(f_n, labels, l_po, f_o))`` as one fused, differentiable
-    device-side operation (train.py:115-116 as intended)."""
-    return _FusedContrastive.apply(f_n, labels, l_po, f_o, float(temperature), int(max_label))
+    device-side operation (train.py:115-116 as intended).  ``precision``: "f32" (exact-fp32 MFMA, parity
+    mode) or "f16" (fp16 operands / fp32 accumulation, performance mode)."""
+    return _FusedContrastive.apply(f_n, labels, l_po, f_o, float(temperature), int(max_label), precision)
 
 
 # ---------------------------------------------------------------------------------------------

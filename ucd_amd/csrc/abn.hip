@@ -20,7 +20,7 @@ namespace ucd {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxBands = 512;  // row bands (= partial sums per channel) of the two-stage reductions
+constexpr int kMaxBands = 256;  // row bands (= partial sums per channel) of the two-stage reductions
 
 struct Geom {
   int TX, TY, gx, gy, rows_per_band;
@@ -117,21 +117,30 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
 }
 
 // Stage 2 of both reductions: sums[k] = sum over bands of partial[band][k], k in [0, 2C).
-// 32 outputs x 8 band-lanes per block.
+// 16 outputs x 16 band-lanes per block, four independent loads in flight per thread (the loop is
+// latency-bound: a partial row is only 2C floats), fixed combination order (deterministic).
 __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int n,
                                                               float* __restrict__ sums) {
-  __shared__ float lds[8][32];
-  const int k = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int lane = threadIdx.x >> 5;
-  float s = 0.f;
-  if (k < n)
-    for (int b = lane; b < bands; b += 8) s += partial[(size_t)b * n + k];
-  lds[lane][threadIdx.x & 31] = s;
+  __shared__ float lds[16][17];
+  const int kl = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + kl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (k < n) {
+    int b = lane;
+    for (; b + 48 < bands; b += 64) {
+      s0 += partial[(size_t)b * n + k];
+      s1 += partial[(size_t)(b + 16) * n + k];
+      s2 += partial[(size_t)(b + 32) * n + k];
+      s3 += partial[(size_t)(b + 48) * n + k];
+    }
+    for (; b < bands; b += 16) s0 += partial[(size_t)b * n + k];
+  }
+  lds[lane][kl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (lane == 0 && k < n) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t += lds[i][threadIdx.x & 31];
+    for (int i = 0; i < 16; ++i) t += lds[i][kl];
     sums[k] = t;
   }
 }
@@ -463,7 +472,7 @@ int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float*
         (const float*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial);
   }
   UCD_TRY(check_launch(fn));
-  reduce_bands_kernel<<<ceil_div(2 * C, 32), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
+  reduce_bands_kernel<<<ceil_div(2 * C, 16), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
   return check_launch(fn);
 }
 
@@ -548,7 +557,7 @@ int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const
   }
 #undef LAUNCH_RED
   UCD_TRY(check_launch(fn));
-  reduce_bands_kernel<<<ceil_div(2 * C, 32), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
+  reduce_bands_kernel<<<ceil_div(2 * C, 16), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
   return check_launch(fn);
 }
 

@@ -432,6 +432,10 @@ Plan make_plan(int BHW, int K) {
 }
 
 }  // namespace
+
+void pixcon_launch_reduce(const float* row_loss, const ucd_pixcon_meta* meta, float* loss_out, hipStream_t s) {
+  pixcon_reduce_kernel<<<1, 1024, 0, s>>>(row_loss, meta, loss_out);
+}
 }  // namespace ucd
 
 using namespace ucd;
@@ -440,16 +444,28 @@ extern "C" {
 
 size_t ucd_pixcon_loss_workspace_bytes(int BHW, int N, int K) {
   (void)N;
-  return make_plan(BHW, K).total;
+  const size_t a = make_plan(BHW, K).total, b = pixcon16_workspace_bytes(BHW);
+  return a > b ? a : b;
 }
 
 int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label, const float* pcat, int ldp, int K,
-                    const ucd_pixcon_meta* meta, int BHW, float temperature, int shift_pos, int use_prob,
-                    float* loss_out, float* grad_a, int ldg, float* row_stats, void* workspace, size_t workspace_bytes,
-                    ucd_stream_t stream) {
+                    const void* ch16, const void* p16, int precision, const ucd_pixcon_meta* meta, int BHW,
+                    float temperature, int shift_pos, int use_prob, float* loss_out, float* grad_a, int ldg,
+                    float* row_stats, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   static const char* fn = "ucd_pixcon_loss";
-  UCD_REQUIRE(chat && row_label && meta && loss_out && workspace, UCD_EINVAL, "%s: NULL argument", fn);
+  UCD_REQUIRE(row_label && meta && loss_out && workspace, UCD_EINVAL, "%s: NULL argument", fn);
   UCD_REQUIRE(BHW > 0 && N > 0 && temperature > 0.f, UCD_EINVAL, "%s: bad sizes", fn);
+  UCD_REQUIRE(precision == UCD_PIXCON_F32 || precision == UCD_PIXCON_F16, UCD_EINVAL, "%s: unknown precision %d", fn, precision);
+  UCD_REQUIRE(!grad_a || (aligned16(grad_a) && ldg % 4 == 0 && ldg >= N && ldg <= kN), UCD_EALIGN,
+              "%s: grad_a must be 16-byte aligned, ldg a multiple of 4 in [N, %d]", fn, kN);
+  if (precision == UCD_PIXCON_F16) {
+    UCD_REQUIRE(ch16 && aligned16(ch16) && N <= kN, UCD_EINVAL, "%s: the fp16 path needs ch16 [Cpad, %d]", fn, kN);
+    UCD_REQUIRE(!use_prob || (p16 && aligned16(p16) && K > 0 && K <= 112), UCD_EUNSUPPORTED,
+                "%s: the fp16 path needs p16 and K <= 112", fn);
+    return pixcon16_launch((const _Float16*)ch16, row_label, (const _Float16*)p16, K, meta, BHW, temperature, shift_pos,
+                           use_prob, loss_out, grad_a, ldg, row_stats, workspace, workspace_bytes, (hipStream_t)stream);
+  }
+  UCD_REQUIRE(chat, UCD_EINVAL, "%s: chat is NULL", fn);
   UCD_REQUIRE(ldc == kN && N <= kN, UCD_EUNSUPPORTED, "%s: the contrast matrix must be padded to ldc == %d columns (N <= %d)", fn, kN, kN);
   UCD_REQUIRE(aligned16(chat) && (!grad_a || (aligned16(grad_a) && ldg % 4 == 0 && ldg >= N)), UCD_EALIGN,
               "%s: chat / grad_a must be 16-byte aligned, ldg a multiple of 4", fn);

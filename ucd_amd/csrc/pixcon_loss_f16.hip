@@ -1,0 +1,476 @@
+// PixelConLossV2 streaming kernels, fp16-operand path (the performance mode).
+//
+// Same two-sweep structure and the same math as pixcon_loss.hip (see the derivation there); what changes
+// is the arithmetic of the two GEMM pairs: v_mfma_f32_32x32x16_f16 (16x the fp32-MFMA rate) with fp32
+// accumulation.  Why fp16 and not bf16: the operands are L2-normalised rows (|x| <= 1), so fp16's
+// 11-bit mantissa costs ~3e-4 absolute on S = cos/T where bf16 costs ~2.5e-3 - inside exp() that is the
+// difference between meeting and missing the 1e-3 contract.
+//
+//   sweep 1, per 32x32 tile and wave:  16 MFMA  X = S^T tile (contrast rows x anchors)
+//                                     epilogue  s2 = X*log2(e)/T; E = exp2(s2 - m_run)[negative]
+//                                     16 MFMA  U^T += C_j^T . E
+//   E must fit fp16: an online, thresholded running maximum m_run of the NEGATIVE logits per anchor keeps
+//   E <= 2^8; when a tile raises the maximum by more than 2^8 the anchor's accumulators are rescaled
+//   (flash-attention style).  Every lane owns one anchor, so the maximum, the rescale factor and the sums
+//   are per-lane scalars - the only cross-lane traffic is one shfl_xor(32) per tile.
+//   The E tile never leaves registers: accumulator registers 8s..8s+7 converted to fp16 are the B operand
+//   of k-step s of the second GEMM; the matching A operand (C_j^T, k order permuted the same way) is
+//   fetched with ds_read_b64_tr_b16 from the row-major LDS tile (hardware transpose, 4 rows x 16 columns
+//   per 16-lane group).
+//   Teacher joint probabilities P = p_i . p_j use a hi/lo fp16 split (3 MFMAs per 16 classes, ~2^-21).
+#include "common.h"
+#include "pixcon.h"
+
+namespace ucd {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 h4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kTI = 32;
+constexpr int kBI = kWaves * kTI;
+constexpr int kTJ = 32;
+constexpr int kN = 256;
+constexpr int kPitchH = kN + 24;   // halfs; 560 B = 140 dwords = 12 (mod 64): ds_read_b128 rows conflict-free
+constexpr int kMaxSplit = 16;
+constexpr float kRescaleTh = 8.f;  // log2 units
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int tile_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+struct TileList {
+  int t1a, n1, t2a, n2;
+  __device__ __forceinline__ int count() const { return n1 + n2; }
+  __device__ __forceinline__ int at(int v) const { return v < n1 ? t1a + v : t2a + (v - n1); }
+};
+
+__device__ __forceinline__ void load_anchor_frags(f16x8 (&a16)[16], const _Float16* __restrict__ ch16, int row, bool ok, int half) {
+  if (ok) {
+    const f16x8* src = reinterpret_cast<const f16x8*>(ch16 + (size_t)row * kN + 8 * half);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) a16[ks] = src[2 * ks];   // halfs 16 ks + 8 half .. +7
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a16[ks][j] = (_Float16)0.f;
+  }
+}
+
+__device__ __forceinline__ void tile_fetch(uint4 (&stage)[4], const _Float16* __restrict__ ch16, int j0) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = threadIdx.x + kThreads * q;  // 0..1023 x 16 B
+    const int row = idx >> 5, c = idx & 31;
+    stage[q] = *reinterpret_cast<const uint4*>(ch16 + (size_t)(j0 + row) * kN + c * 8);
+  }
+}
+__device__ __forceinline__ void tile_commit(const uint4 (&stage)[4], _Float16* __restrict__ cs) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = threadIdx.x + kThreads * q;
+    const int row = idx >> 5, c = idx & 31;
+    *reinterpret_cast<uint4*>(cs + row * kPitchH + c * 8) = stage[q];
+  }
+}
+
+__device__ __forceinline__ f32x16 gemm_scores(const _Float16* __restrict__ cs, const f16x8 (&a16)[16], int lane) {
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const _Float16* rowp = cs + (lane & 31) * kPitchH + 8 * (lane >> 5);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const f16x8 c = *reinterpret_cast<const f16x8*>(rowp + 16 * ks);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c, a16[ks], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// Y[n][i] += sum_j C[j][n] w[j][i]; w (fp32 accumulator layout, values in fp16 range) is the B operand
+__device__ __forceinline__ void gemm_values(f32x16 (&acc)[8], const _Float16* __restrict__ cs, const f32x16& w, int lane) {
+  const int half = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  f16x8 bfrag[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) bfrag[s][jj] = (_Float16)w[8 * s + jj];
+  // this lane supplies the address of row (R0 + q), columns 4p..4p+3 of its 16-lane group's 4x16 block
+  const _Float16* base = cs + (4 * half + q) * kPitchH + 16 * g + 4 * p;
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const _Float16* a0 = base + (16 * s) * kPitchH + 32 * nt;
+      const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)a0);
+      const h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(a0 + 8 * kPitchH));
+      f16x8 a;
+      a[0] = (_Float16)lo[0]; a[1] = (_Float16)lo[1]; a[2] = (_Float16)lo[2]; a[3] = (_Float16)lo[3];
+      a[4] = (_Float16)hi[0]; a[5] = (_Float16)hi[1]; a[6] = (_Float16)hi[2]; a[7] = (_Float16)hi[3];
+      acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag[s], acc[nt], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ void store_values(const f32x16 (&acc)[8], float* __restrict__ dst, int half) {
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 v = {acc[nt][4 * g + 0], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+      *reinterpret_cast<float4*>(dst + 32 * nt + 8 * g + 4 * half) = v;
+    }
+}
+
+// ---- sweep 1 --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float16* __restrict__ ch16,
+                                                                  const uint8_t* __restrict__ row_label,
+                                                                  const ucd_pixcon_meta* __restrict__ meta, float k2,
+                                                                  int nsplit, int maxA, float* __restrict__ negp,
+                                                                  float* __restrict__ mrunp, float* __restrict__ maxp,
+                                                                  float* __restrict__ Up) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* cs0 = reinterpret_cast<_Float16*>(smem_raw);                       // [2][32][kPitchH]
+  int* labs0 = reinterpret_cast<int*>(smem_raw + 2 * kTJ * kPitchH * 2);       // [2][32]
+  const int A = meta->A, Cpad = meta->Cpad;
+  const int i_base = blockIdx.x * kBI;
+  if (i_base >= A) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+  const int i_row = i_base + wave * kTI + (lane & 31);
+  const bool row_ok = i_row < A;
+  const bool wave_ok = i_base + wave * kTI < A;
+  const int la = row_ok ? row_label[i_row] : -1;
+  const int ntiles = Cpad / kTJ;
+  const int per = (ntiles + nsplit - 1) / nsplit;
+  const int v_begin = blockIdx.y * per, v_end = min(ntiles, v_begin + per);
+
+  f16x8 a16[16];
+  load_anchor_frags(a16, ch16, i_row, row_ok, half);
+  f32x16 U[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) U[nt][r] = 0.f;
+  float neg = 0.f, m_run = -1e30f, mx_all = -INFINITY;
+
+  uint4 stage[4];
+  int cur = 0;
+  if (v_begin < v_end) {
+    tile_fetch(stage, ch16, v_begin * kTJ);
+    tile_commit(stage, cs0);
+    if (threadIdx.x < kTJ) labs0[threadIdx.x] = row_label[v_begin * kTJ + threadIdx.x];
+  }
+  __syncthreads();
+  for (int v = v_begin; v < v_end; ++v) {
+    const bool has_next = v + 1 < v_end;
+    if (has_next) tile_fetch(stage, ch16, (v + 1) * kTJ);
+    const _Float16* cs = cs0 + cur * kTJ * kPitchH;
+    const int* labs = labs0 + cur * kTJ;
+    if (wave_ok) {
+      f32x16 x = gemm_scores(cs, a16, lane);
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int lc = labs[tile_row(reg, half)];
+        const float s2 = x[reg] * k2;
+        const bool valid = lc != kPadLabel;
+        mx_all = valid ? fmaxf(mx_all, s2) : mx_all;
+        const float sn = (valid && lc != la) ? s2 : -INFINITY;
+        tmax = fmaxf(tmax, sn);
+        x[reg] = sn;
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = tmax > m_run + kRescaleTh ? tmax : m_run;
+      if (__any(m_new != m_run)) {   // wave-uniform branch; lanes that keep their maximum scale by 1
+        const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+        neg *= sc;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) U[nt][r] *= sc;
+        m_run = m_new;
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const float e = __builtin_amdgcn_exp2f(x[reg] - m_run);   // exp2(-inf) = 0 for masked entries
+        neg += e;
+        x[reg] = e;
+      }
+      gemm_values(U, cs, x, lane);
+    }
+    if (has_next) {
+      tile_commit(stage, cs0 + (cur ^ 1) * kTJ * kPitchH);
+      if (threadIdx.x < kTJ) labs0[(cur ^ 1) * kTJ + threadIdx.x] = row_label[(v + 1) * kTJ + threadIdx.x];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  neg += __shfl_xor(neg, 32, 64);
+  mx_all = fmaxf(mx_all, __shfl_xor(mx_all, 32, 64));
+  if (row_ok) {
+    if (half == 0) {
+      const size_t o = (size_t)blockIdx.y * maxA + i_row;
+      negp[o] = neg;       // in units of 2^m_run
+      mrunp[o] = m_run;    // log2 domain
+      maxp[o] = mx_all;    // log2 domain
+    }
+    store_values(U, Up + ((size_t)blockIdx.y * maxA + i_row) * kN, half);
+  }
+}
+
+// ---- sweep 2 --------------------------------------------------------------------------------------------
+// p16: [Cpad][2][KP16] halfs (hi then lo) ; KP16 = K rounded up to 16
+__global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
+    const _Float16* __restrict__ ch16, const uint8_t* __restrict__ row_label, const _Float16* __restrict__ p16, int KP16,
+    const ucd_pixcon_meta* __restrict__ meta, float k2, int shift_pos, int use_prob, int nsplit1, int nsplit2, int maxA,
+    const float* __restrict__ negp, const float* __restrict__ mrunp, const float* __restrict__ maxp,
+    float* __restrict__ lossp, float* __restrict__ qsump, float* __restrict__ Vp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int ppitch = 2 * KP16 + 8;                                              // halfs per row: hi | lo | pad
+  _Float16* cs0 = reinterpret_cast<_Float16*>(smem_raw);                        // [2][32][kPitchH]
+  int* labs0 = reinterpret_cast<int*>(smem_raw + 2 * kTJ * kPitchH * 2);        // [2][32]
+  _Float16* ps0 = reinterpret_cast<_Float16*>(smem_raw + 2 * kTJ * kPitchH * 2 + 2 * kTJ * 4);  // [2][32][ppitch]
+  const int A = meta->A, Apad = meta->Apad, Cpad = meta->Cpad, min_new = meta->min_new;
+  const int i_base = blockIdx.x * kBI;
+  if (i_base >= A) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
+  const int i_row = i_base + wave * kTI + (lane & 31);
+  const bool row_ok = i_row < A;
+  const bool wave_ok = i_base + wave * kTI < A;
+  const int la = row_ok ? row_label[i_row] : -1;
+  const bool gt_i = la >= min_new;
+
+  TileList tl;
+  if (meta->sorted) {
+    const int Lmin = row_label[i_base], Lmax = row_label[min(i_base + kBI, A) - 1];
+    const int r1a = meta->label_start_a[Lmin], r1b = meta->label_start_a[Lmax + 1];
+    const int r2a = Apad + meta->label_start_o[Lmin], r2b = Apad + meta->label_start_o[Lmax + 1];
+    tl.t1a = r1a / kTJ; tl.n1 = (r1b + kTJ - 1) / kTJ - tl.t1a;
+    tl.t2a = r2a / kTJ; tl.n2 = r2b > r2a ? (r2b + kTJ - 1) / kTJ - tl.t2a : 0;
+  } else {
+    tl.t1a = 0; tl.n1 = Cpad / kTJ; tl.t2a = 0; tl.n2 = 0;
+  }
+  const int nv = tl.count();
+  const int per = (nv + nsplit2 - 1) / nsplit2;
+  const int v_begin = blockIdx.y * per, v_end = min(nv, v_begin + per);
+
+  // row constants from sweep 1: combine the split partials at a common scale
+  float neg_true = 0.f, m2 = -INFINITY;
+  if (row_ok) {
+    float M = -1e30f;
+    for (int s = 0; s < nsplit1; ++s) M = fmaxf(M, mrunp[(size_t)s * maxA + i_row]);
+    float acc = 0.f;
+    for (int s = 0; s < nsplit1; ++s) {
+      acc += negp[(size_t)s * maxA + i_row] * exp2f(mrunp[(size_t)s * maxA + i_row] - M);
+      m2 = fmaxf(m2, maxp[(size_t)s * maxA + i_row]);
+    }
+    neg_true = acc > 0.f ? acc * exp2f(M) : 0.f;
+  }
+  if (!shift_pos) m2 = 0.f;
+
+  f16x8 a16[16];
+  load_anchor_frags(a16, ch16, i_row, row_ok, half);
+  f32x16 V[8];
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) V[nt][r] = 0.f;
+  float lossacc = 0.f, qsum = 0.f;
+  const int nk = KP16 / 16;
+
+  auto commit_side = [&](int buf, int j0) {
+    if (threadIdx.x < kTJ) labs0[buf * kTJ + threadIdx.x] = row_label[j0 + threadIdx.x];
+    if (use_prob) {
+      const int chunks = (2 * KP16) / 8;                    // 16-byte chunks per row
+      for (int idx = threadIdx.x; idx < kTJ * chunks; idx += kThreads) {
+        const int row = idx / chunks, c = idx - row * chunks;
+        *reinterpret_cast<uint4*>(ps0 + (buf * kTJ + row) * ppitch + c * 8) =
+            *reinterpret_cast<const uint4*>(p16 + (size_t)(j0 + row) * 2 * KP16 + c * 8);
+      }
+    }
+  };
+
+  uint4 stage[4];
+  int cur = 0;
+  if (v_begin < v_end) {
+    const int j0 = tl.at(v_begin) * kTJ;
+    tile_fetch(stage, ch16, j0);
+    tile_commit(stage, cs0);
+    commit_side(0, j0);
+  }
+  __syncthreads();
+  for (int v = v_begin; v < v_end; ++v) {
+    const bool has_next = v + 1 < v_end;
+    const int j0 = tl.at(v) * kTJ;
+    const int j0n = has_next ? tl.at(v + 1) * kTJ : 0;
+    if (has_next) tile_fetch(stage, ch16, j0n);
+    const _Float16* cs = cs0 + cur * kTJ * kPitchH;
+    const int* labs = labs0 + cur * kTJ;
+    if (wave_ok) {
+      f32x16 x = gemm_scores(cs, a16, lane);
+      f32x16 pm;
+      if (use_prob) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pm[r] = 0.f;
+        const _Float16* pc = ps0 + (cur * kTJ + (lane & 31)) * ppitch + 8 * half;
+        const _Float16* pa = p16 + (size_t)(row_ok ? i_row : 0) * 2 * KP16 + 8 * half;
+        for (int kk = 0; kk < nk; ++kk) {
+          const f16x8 ch = *reinterpret_cast<const f16x8*>(pc + 16 * kk);
+          const f16x8 cl = *reinterpret_cast<const f16x8*>(pc + KP16 + 16 * kk);
+          const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + 16 * kk);
+          const f16x8 al = *reinterpret_cast<const f16x8*>(pa + KP16 + 16 * kk);
+          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, ah, pm, 0, 0, 0);
+          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, al, pm, 0, 0, 0);
+          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, ah, pm, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int jl = tile_row(reg, half);
+        const int lc = labs[jl];
+        const bool pos = row_ok && lc == la && (j0 + jl) != i_row;
+        float q = 0.f;
+        if (pos) {
+          const float pw = (use_prob && !(gt_i && lc >= min_new)) ? pm[reg] : 1.f;
+          const float sp2 = x[reg] * k2 - m2;
+          const float d = __builtin_amdgcn_exp2f(sp2) + neg_true;
+          lossacc += pw * (sp2 * kLn2 - __logf(d));
+          q = pw * (neg_true / d);
+          qsum += q;
+        }
+        x[reg] = q;
+      }
+      gemm_values(V, cs, x, lane);
+    }
+    if (has_next) {
+      tile_commit(stage, cs0 + (cur ^ 1) * kTJ * kPitchH);
+      commit_side(cur ^ 1, j0n);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  lossacc += __shfl_xor(lossacc, 32, 64);
+  qsum += __shfl_xor(qsum, 32, 64);
+  if (row_ok) {
+    if (half == 0) {
+      lossp[(size_t)blockIdx.y * maxA + i_row] = lossacc;
+      qsump[(size_t)blockIdx.y * maxA + i_row] = qsum;
+    }
+    store_values(V, Vp + ((size_t)blockIdx.y * maxA + i_row) * kN, half);
+  }
+}
+
+// ---- combine ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void pixcon16_finalize_kernel(
+    const uint8_t* __restrict__ row_label, const ucd_pixcon_meta* __restrict__ meta, float inv_T, int nsplit1, int nsplit2,
+    int maxA, const float* __restrict__ negp, const float* __restrict__ mrunp, const float* __restrict__ lossp,
+    const float* __restrict__ qsump, const float* __restrict__ Up, const float* __restrict__ Vp,
+    float* __restrict__ grad_a, int ldg, float* __restrict__ row_stats, float* __restrict__ row_loss) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * (kThreads / 64) + wave;
+  const int A = meta->A;
+  if (i >= A) return;
+  const int num = meta->label_count_c[row_label[i]] - 1;
+  const float R = (float)meta->n_valid;
+  float M = -1e30f;
+  for (int s = 0; s < nsplit1; ++s) M = fmaxf(M, mrunp[(size_t)s * maxA + i]);
+  float negs = 0.f, la = 0.f, qs = 0.f;   // negs in units of 2^M
+  for (int s = 0; s < nsplit1; ++s) negs += negp[(size_t)s * maxA + i] * exp2f(mrunp[(size_t)s * maxA + i] - M);
+  for (int s = 0; s < nsplit2; ++s) {
+    la += lossp[(size_t)s * maxA + i];
+    qs += qsump[(size_t)s * maxA + i];
+  }
+  const float coef = num > 0 ? inv_T / ((float)num * R) : 0.f;
+  const float ratio = negs > 0.f ? qs / negs : 0.f;   // U is in the same 2^M units: the scale cancels
+  const float rl = num > 0 ? -la / (float)num : 0.f;
+  if (grad_a) {
+    for (int c = lane * 4; c < ldg; c += 256) {
+      float4 u = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (c < kN) {
+        for (int s = 0; s < nsplit1; ++s) {
+          const float w = exp2f(mrunp[(size_t)s * maxA + i] - M);
+          const float4 t = *reinterpret_cast<const float4*>(Up + ((size_t)s * maxA + i) * kN + c);
+          u.x += w * t.x; u.y += w * t.y; u.z += w * t.z; u.w += w * t.w;
+        }
+        for (int s = 0; s < nsplit2; ++s) {
+          const float4 t = *reinterpret_cast<const float4*>(Vp + ((size_t)s * maxA + i) * kN + c);
+          vv.x += t.x; vv.y += t.y; vv.z += t.z; vv.w += t.w;
+        }
+      }
+      float4 g = {coef * (ratio * u.x - vv.x), coef * (ratio * u.y - vv.y), coef * (ratio * u.z - vv.z),
+                  coef * (ratio * u.w - vv.w)};
+      *reinterpret_cast<float4*>(grad_a + (size_t)i * ldg + c) = g;
+    }
+  }
+  if (lane == 0) {
+    row_loss[i] = rl;
+    if (row_stats) {
+      row_stats[i] = negs > 0.f ? negs * exp2f(M) : 0.f;
+      row_stats[(size_t)maxA + i] = (float)num;
+      row_stats[(size_t)2 * maxA + i] = rl;
+    }
+  }
+}
+
+}  // namespace
+
+// Plan shared with the fp32 path (same workspace layout + one extra row vector)
+size_t pixcon16_workspace_bytes(int BHW) {
+  int nt_i = ceil_div(BHW, kBI);
+  int ns = ceil_div(1024, nt_i);
+  if (ns > kMaxSplit) ns = kMaxSplit;
+  if (ns < 1) ns = 1;
+  const size_t rowvec = align_up((size_t)BHW * 4, 256);
+  return rowvec * ns * 5 + rowvec + (size_t)2 * ns * BHW * kN * 4;
+}
+
+int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float16* p16, int K,
+                    const ucd_pixcon_meta* meta, int BHW, float temperature, int shift_pos, int use_prob,
+                    float* loss_out, float* grad_a, int ldg, float* row_stats, void* workspace, size_t workspace_bytes,
+                    hipStream_t s) {
+  static const char* fn = "ucd_pixcon_loss[f16]";
+  const int nt_i = ceil_div(BHW, kBI);
+  int ns = ceil_div(1024, nt_i);
+  if (ns > kMaxSplit) ns = kMaxSplit;
+  if (ns < 1) ns = 1;
+  UCD_REQUIRE(workspace_bytes >= pixcon16_workspace_bytes(BHW), UCD_EWORKSPACE, "%s: workspace too small", fn);
+  const size_t rowvec = align_up((size_t)BHW * 4, 256);
+  char* ws = (char*)workspace;
+  float* negp = (float*)ws; ws += rowvec * ns;
+  float* mrunp = (float*)ws; ws += rowvec * ns;
+  float* maxp = (float*)ws; ws += rowvec * ns;
+  float* lossp = (float*)ws; ws += rowvec * ns;
+  float* qsump = (float*)ws; ws += rowvec * ns;
+  float* rowloss = (float*)ws; ws += rowvec;
+  float* Up = (float*)ws; ws += (size_t)ns * BHW * kN * 4;
+  float* Vp = (float*)ws;
+  const int KP16 = use_prob ? (K + 15) / 16 * 16 : 0;
+  const float k2 = kLog2e / temperature;
+  const int maxA = BHW;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)pixcon16_neg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pixcon16_pos_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const size_t lds1 = (size_t)2 * kTJ * kPitchH * 2 + 2 * kTJ * 4;
+  pixcon16_neg_kernel<<<dim3(nt_i, ns), kThreads, lds1, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
+  int rc = check_launch(fn);
+  if (rc) return rc;
+  const size_t lds2 = lds1 + (size_t)2 * kTJ * (2 * KP16 + 8) * 2;
+  pixcon16_pos_kernel<<<dim3(nt_i, ns), kThreads, lds2, s>>>(ch16, row_label, p16, KP16, meta, k2, shift_pos, use_prob, ns,
+                                                            ns, maxA, negp, mrunp, maxp, lossp, qsump, Vp);
+  rc = check_launch(fn);
+  if (rc) return rc;
+  pixcon16_finalize_kernel<<<ceil_div(BHW, kThreads / 64), kThreads, 0, s>>>(row_label, meta, 1.f / temperature, ns, ns,
+                                                                             maxA, negp, mrunp, lossp, qsump, Up, Vp,
+                                                                             grad_a, ldg, row_stats, rowloss);
+  rc = check_launch(fn);
+  if (rc) return rc;
+  pixcon_launch_reduce(rowloss, meta, loss_out, s);
+  return check_launch(fn);
+}
+
+}  // namespace ucd

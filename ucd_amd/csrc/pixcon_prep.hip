@@ -208,7 +208,9 @@ __global__ __launch_bounds__(kBlock) void gather_normalize_kernel(const T* __res
                                                                  const float* __restrict__ prob, int K,
                                                                  const ucd_pixcon_meta* __restrict__ meta,
                                                                  float* __restrict__ chat, int ldc, float* __restrict__ pcat,
-                                                                 int ldp, float* __restrict__ inv_norm) {
+                                                                 int ldp, _Float16* __restrict__ ch16,
+                                                                 _Float16* __restrict__ p16, int KP16,
+                                                                 float* __restrict__ inv_norm) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * (kBlock / 64) + wave;
   const int A = meta->A, Apad = meta->Apad, Co = meta->Co, Cpad = meta->Cpad;
@@ -219,9 +221,13 @@ __global__ __launch_bounds__(kBlock) void gather_normalize_kernel(const T* __res
   else if (r >= Apad && r < Apad + Co) { pix = old_pix[r - Apad]; src = f_o + (size_t)pix * ld_o; }
   float* dst = chat + (size_t)r * ldc;
   float* pdst = pcat ? pcat + (size_t)r * ldp : nullptr;
+  _Float16* hdst = ch16 ? ch16 + (size_t)r * ldc : nullptr;
+  _Float16* qdst = p16 ? p16 + (size_t)r * 2 * KP16 : nullptr;
   if (!src) {
     for (int c = lane; c < ldc; c += 64) dst[c] = 0.f;
     if (pdst) for (int k = lane; k < ldp; k += 64) pdst[k] = 0.f;
+    if (hdst) for (int c = lane; c < ldc; c += 64) hdst[c] = (_Float16)0.f;
+    if (qdst) for (int k = lane; k < 2 * KP16; k += 64) qdst[k] = (_Float16)0.f;
     return;
   }
   float ss = 0.f;
@@ -231,11 +237,21 @@ __global__ __launch_bounds__(kBlock) void gather_normalize_kernel(const T* __res
   }
   ss = wave_sum(ss);
   const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize: x / max(||x||, eps)
-  for (int c = lane; c < ldc; c += 64) dst[c] = c < N ? (float)src[c] * inv : 0.f;
-  if (pdst) {
-    const float* pp = prob + (size_t)pix * K;
-    for (int k = lane; k < ldp; k += 64) pdst[k] = k < K ? pp[k] : 0.f;
+  for (int c = lane; c < ldc; c += 64) {
+    const float v = c < N ? (float)src[c] * inv : 0.f;
+    dst[c] = v;
+    if (hdst) hdst[c] = (_Float16)v;
   }
+  const float* pp = prob ? prob + (size_t)pix * K : nullptr;
+  if (pdst)
+    for (int k = lane; k < ldp; k += 64) pdst[k] = k < K ? pp[k] : 0.f;
+  if (qdst)  // hi | lo split: p = hi + lo to ~2^-22
+    for (int k = lane; k < KP16; k += 64) {
+      const float v = k < K ? pp[k] : 0.f;
+      const _Float16 hi = (_Float16)v;
+      qdst[k] = hi;
+      qdst[KP16 + k] = (_Float16)(v - (float)hi);
+    }
   if (r < A && lane == 0) inv_norm[r] = inv;
 }
 
@@ -322,12 +338,14 @@ int ucd_pixcon_prep(const int64_t* labels, int B, int H, int W, int h, int w, in
 
 int ucd_pixcon_gather(const void* f_n, int ld_n, const void* f_o, int ld_o, int dtype, int BHW, int N,
                       const int32_t* anchor_pix, const int32_t* old_pix, const float* prob, int K,
-                      const ucd_pixcon_meta* meta, float* chat, int ldc, float* pcat, int ldp, float* inv_norm,
-                      ucd_stream_t stream) {
+                      const ucd_pixcon_meta* meta, float* chat, int ldc, float* pcat, int ldp, void* ch16, void* p16,
+                      float* inv_norm, ucd_stream_t stream) {
   static const char* fn = "ucd_pixcon_gather";
   UCD_REQUIRE(f_n && f_o && anchor_pix && old_pix && meta && chat && inv_norm, UCD_EINVAL, "%s: NULL argument", fn);
   UCD_REQUIRE(BHW > 0 && N > 0 && ldc >= N && ld_n >= N && ld_o >= N, UCD_EINVAL, "%s: bad sizes", fn);
   UCD_REQUIRE(!pcat || (prob && K > 0 && ldp >= K), UCD_EINVAL, "%s: pcat needs prob, K and ldp >= K", fn);
+  UCD_REQUIRE(!p16 || (prob && K > 0), UCD_EINVAL, "%s: p16 needs prob and K", fn);
+  const int KP16 = (K + 15) / 16 * 16;
   UCD_REQUIRE(dtype == UCD_F32 || dtype == UCD_BF16, UCD_EINVAL, "%s: unknown dtype", fn);
   hipStream_t s = (hipStream_t)stream;
   const int max_rows = 2 * BHW + 2 * kPixTile;  // worst case; rows past meta->Cpad exit at once
@@ -335,11 +353,12 @@ int ucd_pixcon_gather(const void* f_n, int ld_n, const void* f_o, int ld_o, int 
   if (dtype == UCD_BF16)
     gather_normalize_kernel<__hip_bfloat16><<<blocks, kBlock, 0, s>>>((const __hip_bfloat16*)f_n, ld_n,
                                                                      (const __hip_bfloat16*)f_o, ld_o, N, anchor_pix,
-                                                                     old_pix, prob, K, meta, chat, ldc, pcat, ldp, inv_norm);
+                                                                     old_pix, prob, K, meta, chat, ldc, pcat, ldp,
+                                                                     (_Float16*)ch16, (_Float16*)p16, KP16, inv_norm);
   else
     gather_normalize_kernel<float><<<blocks, kBlock, 0, s>>>((const float*)f_n, ld_n, (const float*)f_o, ld_o, N,
                                                             anchor_pix, old_pix, prob, K, meta, chat, ldc, pcat, ldp,
-                                                            inv_norm);
+                                                            (_Float16*)ch16, (_Float16*)p16, KP16, inv_norm);
   return check_launch(fn);
 }
 

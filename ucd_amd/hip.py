@@ -19,6 +19,8 @@ ACT_IDENTITY, ACT_LEAKY_RELU = 0, 1
 ACT_CODES = {"identity": ACT_IDENTITY, "leaky_relu": ACT_LEAKY_RELU}
 PIX_TILE = 128          # kPixTile of csrc/pixcon.h
 PIXCON_LD = 256         # feature rows of the contrast matrix are padded to 256 columns
+PIXCON_F32, PIXCON_F16 = 0, 1
+PIXCON_PRECISION = {"f32": PIXCON_F32, "fp32": PIXCON_F32, "f16": PIXCON_F16, "fp16": PIXCON_F16}
 
 
 class PixconMeta(C.Structure):
@@ -50,9 +52,9 @@ SIGNATURES = {
     "ucd_attmap": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "ucd_pixcon_prep_workspace_bytes": (_z, [_i, _i]),
     "ucd_pixcon_prep": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
-    "ucd_pixcon_gather": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p]),
+    "ucd_pixcon_gather": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p]),
     "ucd_pixcon_loss_workspace_bytes": (_z, [_i, _i, _i]),
-    "ucd_pixcon_loss": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _i, _f, _i, _i, _p, _p, _i, _p, _p, _z, _p]),
+    "ucd_pixcon_loss": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _i, _f, _i, _i, _p, _p, _i, _p, _p, _z, _p]),
     "ucd_pixcon_scatter_grad": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
 }
 

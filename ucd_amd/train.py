@@ -66,6 +66,8 @@ class Trainer:
         self.regularizer, self.regularizer_flag = None, False
         self.ret_intermediate = self.lde
         self.amp = getattr(opts, "opt_level", "O0") != "O0"
+        # contrastive arithmetic: exact fp32 MFMA with fp32 activations (O0), fp16 operands otherwise
+        self.pixcon_precision = getattr(opts, "pixcon_precision", None) or ("f16" if self.amp else "f32")
         self.last = {}
 
     # ------------------------------------------------------------------------------------------
@@ -100,7 +102,8 @@ class Trainer:
         con = zero
         if model_old is not None:
             con = ucd_contrastive_loss(_raw(features, "pre_logits"), labels, features_old["sem"],
-                                       _raw(features_old, "pre_logits"), self.temperature, self.max_label)
+                                       _raw(features_old, "pre_logits"), self.temperature, self.max_label,
+                                       self.pixcon_precision)
         loss = ce + con / 100                                                     # train.py:116
         if self.lde_flag:
             lde = self.lde * (self.lde_loss(features["body"].float(), features_old["body"].float())
