@@ -54,43 +54,48 @@ const char* ucd_last_error(void);
  * runs as separate kernels around it: residual add + activation (modules/residual.py:90-97), channel
  * concatenation (modules/deeplab.py:56) and the pooled-branch broadcast add (modules/deeplab.py:65-68).
  *
- *   z = (x [+ plane_bias[b, c]]) * scale[c] + shift[c] [+ residual]      y = act(z)
+ *   z = (x [+ plane_bias[b, c]] - mean[c]) * scale[c] + shift[c] [+ residual]      y = act(z)
  * ---------------------------------------------------------------------------------------------- */
 
 /* bytes of scratch needed by ucd_abn_stats / ucd_abn_bwd_reduce for an [M, C] map */
 size_t ucd_abn_workspace_bytes(int M, int C);
 
-/* Per-channel sums over the M rows: sums[0:C] = sum x', sums[C:2C] = sum x'^2 with
- * x' = x + plane_bias[row / HW, c] (plane_bias may be NULL).  Deterministic two-stage reduction. */
+/* Per-channel sums over the M rows, taken about k[c] = x'[row 0, c] ("shifted data": E[x^2] - E[x]^2
+ * cancels catastrophically in float32 when |mean| >> std):
+ *   sums[0:C] = sum (x' - k), sums[C:2C] = sum (x' - k)^2, kshift[0:C] = k,
+ * with x' = x + plane_bias[row / HW, c] (plane_bias may be NULL).  Deterministic two-stage reduction. */
 int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C,
                   const float* plane_bias, int HW,
-                  float* sums /* [2*C] */, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+                  float* sums /* [2*C] */, float* kshift /* [C] */,
+                  void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
-/* Batch statistics -> affine form.  count = rows behind `sums` (after a cross-rank all-reduce of
- * sums: the global count).  mean = s/n, var = ss/n - mean^2 (biased), invstd = rsqrt(var + eps);
- * running_mean/var are updated in place with `momentum` (unbiased variance) unless NULL;
- * scale = weight * invstd, shift = bias - mean * scale.  weight/bias NULL mean 1 / 0. */
-int ucd_abn_finalize(const float* sums, float count, int C,
-                     const float* weight, const float* bias,
+/* Batch statistics -> normalisation constants.  With d = sums[c]/count:
+ *   mean = kshift + d,  var = (sums[C+c] - sums[c]*d)/count (biased),  invstd = 1/sqrt(var + eps),
+ *   scale = weight * invstd;  running_mean / running_var are updated in place with `momentum`
+ *   (unbiased variance) unless NULL.  kshift NULL means 0; weight NULL means 1.
+ * For statistics combined across ranks pass kshift = global mean, sums[0:C] = 0, sums[C:2C] = global M2. */
+int ucd_abn_finalize(const float* sums, const float* kshift, float count, int C, const float* weight,
                      float* running_mean, float* running_var, float momentum, float eps,
-                     float* mean, float* invstd, float* scale, float* shift, ucd_stream_t stream);
+                     float* mean, float* invstd, float* scale, ucd_stream_t stream);
 
-/* Evaluation-mode affine form from the running statistics (teacher; --fix_bn). */
-int ucd_abn_eval_params(const float* weight, const float* bias, const float* running_mean,
-                        const float* running_var, float eps, int C,
-                        float* scale, float* shift, ucd_stream_t stream);
+/* Evaluation mode (teacher; --fix_bn): invstd = 1/sqrt(running_var + eps), scale = weight * invstd; the
+ * mean is running_mean itself. */
+int ucd_abn_eval_params(const float* weight, const float* running_var, float eps, int C,
+                        float* invstd, float* scale, ucd_stream_t stream);
 
-/* y = act((x + plane_bias) * scale + shift + residual); y may alias x (in place) or be a channel
- * slice of a wider buffer (ld_y > C).  residual / plane_bias may be NULL. */
+/* y = act((x + plane_bias - mean) * scale + shift + residual); shift is the affine bias (NULL = 0);
+ * y may alias x (in place) or be a channel slice of a wider buffer (ld_y > C); residual / plane_bias
+ * may be NULL.  Subtracting the mean first keeps the result exact when x is close to it. */
 int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r,
                   int dtype, int M, int C, const float* plane_bias, int HW,
-                  const float* scale, const float* shift, int act, float slope, ucd_stream_t stream);
+                  const float* mean, const float* scale, const float* shift, int act, float slope,
+                  ucd_stream_t stream);
 
 /* Backward, stage 1: dz = dy * act'(z) and the two per-channel sums
  *   sums[0:C] = sum dz            (= d bias)
  *   sums[C:2C] = sum dz * xhat    (= d weight),   xhat = (x' - mean) * invstd.
- * The sign of z is taken from y when y != NULL (needed when a residual was fused), else z is
- * recomputed from x. */
+ * The sign of z is taken from y when y != NULL (needed when a residual was fused), else z =
+ * (x' - mean) * scale + shift is recomputed from x (shift = the affine bias, NULL = 0). */
 int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
                        int dtype, int M, int C, const float* plane_bias, int HW,
                        const float* mean, const float* invstd, const float* scale, const float* shift,
@@ -212,6 +217,23 @@ int ucd_pixcon_scatter_grad(const float* grad_a, const float* chat, int ldc, con
                             const int32_t* anchor_pix, const ucd_pixcon_meta* meta,
                             const float* grad_scale, void* d_f_n, int ld_d, int dtype, int BHW, int N,
                             ucd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused full-resolution logit losses.  Replaces, in one pass over the label map,
+ * the bilinear up-sampling of the student and teacher logits (segmentation_module.py:133),
+ * UnbiasedCrossEntropy (utils/loss.py:96-109; reduction 'none' then .mean() over ALL pixels, train.py:116)
+ * and UnbiasedKnowledgeDistillationLoss (utils/loss.py:148-184, alpha = 1, reduction 'mean').
+ *   sem_s [B*h*w, Ctot] / sem_t [B*h*w, K] : low-resolution student / teacher logits, float32 rows
+ *   (sem_t may be NULL: cross entropy only; K = number of old classes incl. background, >= 1)
+ *   loss_out[0] = mean CE, loss_out[1] = mean KD
+ *   d_sem [B*h*w, ld_d] = d(ce_weight * CE + kd_weight * KD) / d sem_s   (overwritten)
+ * The gradient is accumulated with float atomics (LDS, then global): its last bits depend on the
+ * execution order; the loss values are summed in a fixed order. */
+size_t ucd_seg_losses_workspace_bytes(int B, int H, int W);
+int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, const int64_t* labels,
+                   int B, int H, int W, int h, int w, int Ctot, int K, int ignore_index,
+                   float ce_weight, float kd_weight, float* loss_out, float* d_sem, int ld_d,
+                   void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,50 @@
+"""GPU: fused bilinear up-sampling + UnbiasedCE + UnbiasedKD (ucd_seg_losses, through the C ABI) against
+the CPU oracle, which up-samples with F.interpolate and applies the reference's loss restatements."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import losses as OL
+from ucd_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,Ctot,K,h,H,with_kd", [
+    (2, 21, 16, 9, 129, True),       # VOC 15-5
+    (3, 21, 16, 33, 513, True),      # full-size crop
+    (2, 20, 14, 12, 190, True),      # Cityscapes 13-6, non-integer scale
+    (2, 151, 101, 8, 128, True),     # ADE 100-50
+    (2, 21, 16, 9, 129, False),      # cross entropy only
+    (2, 21, 1, 9, 129, False),       # step 0: plain cross entropy (old_cl = 1)
+])
+def test_fused_seg_losses_vs_oracle(B, Ctot, K, h, H, with_kd):
+    from ucd_amd.loss import fused_seg_losses
+    seed = 7000 + Ctot + h
+    sem = synth.t_normal(seed, (B, Ctot, h, h), stream=1, scale=2.0)
+    sem_t = synth.t_normal(seed, (B, K, h, h), stream=2, scale=2.0)
+    labels = synth.seg_labels(seed, B, H, H, range(K, Ctot) if K < Ctot else [1], rects=4)
+    if K == 1:
+        labels = torch.from_numpy(np.where(synth.randint(seed, (B, H, H), 0, Ctot + 2, stream=5) >= Ctot, 255,
+                                           synth.randint(seed, (B, H, H), 0, Ctot, stream=6)))
+    kd_w = 10.0 if with_kd else 0.0
+    # oracle
+    s_ref = sem.clone().requires_grad_(True)
+    up = F.interpolate(s_ref, size=(H, H), mode="bilinear", align_corners=False)
+    ce_ref = OL.unbiased_cross_entropy(up, labels, K).mean()
+    kd_ref = OL.unbiased_kd(up, F.interpolate(sem_t, size=(H, H), mode="bilinear", align_corners=False)) if with_kd \
+        else torch.zeros(())
+    (ce_ref + kd_w * kd_ref).backward()
+    # HIP
+    dev = torch.device("cuda:0")
+    s_dev = sem.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    total, ce, kd = fused_seg_losses(s_dev, sem_t.to(dev) if with_kd else None, labels.to(dev), K, 1.0, kd_w)
+    total.backward()
+    assert ce.item() == pytest.approx(ce_ref.item(), rel=1e-4)
+    if with_kd:
+        assert kd.item() == pytest.approx(kd_ref.item(), rel=1e-4)
+    assert total.item() == pytest.approx((ce_ref + kd_w * kd_ref).item(), rel=1e-4)
+    g, gr = s_dev.grad.cpu(), s_ref.grad
+    assert (g - gr).abs().max().item() / gr.abs().max().item() < 1e-3
+    assert (g - gr).norm().item() / gr.norm().item() < 1e-4

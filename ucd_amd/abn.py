@@ -42,6 +42,21 @@ def _group_size(group):
     return dist.get_world_size(group if group is not None else None)
 
 
+def _combine_stats_across_ranks(sums, kshift, M, Cc, world, group):
+    """Chan's parallel combination of per-rank (count, mean, M2) - equal counts per rank (DistributedSampler
+    with drop_last, run.py:147-149) - written back in the form ucd_abn_finalize takes:
+    kshift = global mean, sums = [0, global M2]."""
+    d = sums[:Cc] / M
+    pack = torch.cat((kshift + d, sums[Cc:] - sums[:Cc] * d))          # [mean_r | M2_r]
+    gathered = torch.empty(world, 2 * Cc, dtype=torch.float32, device=sums.device)
+    dist.all_gather_into_tensor(gathered, pack, group=group if group is not None else None)
+    mean_g = gathered[:, :Cc].mean(dim=0)
+    m2 = gathered[:, Cc:].sum(dim=0) + M * ((gathered[:, :Cc] - mean_g) ** 2).sum(dim=0)
+    kshift.copy_(mean_g)
+    sums[:Cc].zero_()
+    sums[Cc:].copy_(m2)
+
+
 class _ABNFunction(torch.autograd.Function):
     """y = act(BN(x [+ plane_bias]) [+ residual]) with batch (training) or running (eval) statistics."""
 
@@ -56,23 +71,20 @@ class _ABNFunction(torch.autograd.Function):
             residual, _, _, _, ld_r = hip.rows_view(residual)
         if plane_bias is not None:
             plane_bias = plane_bias.reshape(x.shape[0], Cc).float().contiguous()
-        # [sums(2C) | pad | mean | invstd | scale | shift]
-        buf = torch.empty(6 * Cc + 1, dtype=torch.float32, device=dev)
-        sums, mean, invstd = buf[:2 * Cc], buf[2 * Cc + 1:3 * Cc + 1], buf[3 * Cc + 1:4 * Cc + 1]
-        scale, shift = buf[4 * Cc + 1:5 * Cc + 1], buf[5 * Cc + 1:]
+        # [sums(2C) | kshift | mean | invstd | scale]
+        buf = torch.empty(6 * Cc, dtype=torch.float32, device=dev)
+        sums, kshift, mean, invstd, scale = buf[:2 * Cc], buf[2 * Cc:3 * Cc], buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:]
         world = 1
         if training:
-            hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums)
+            hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums, kshift)
             world = _group_size(group)
-            if world > 1:   # equal shards on every rank (DistributedSampler with drop_last, run.py:147-149)
-                dist.all_reduce(sums, group=group if group is not None else None)
-            hip.abn_finalize(sums, float(M * world), Cc, weight, bias, running_mean, running_var, momentum, eps, mean,
-                             invstd, scale, shift)
+            if world > 1:
+                _combine_stats_across_ranks(sums, kshift, M, Cc, world, group)
+            hip.abn_finalize(sums, kshift, float(M * world), Cc, weight, running_mean, running_var, momentum, eps, mean,
+                             invstd, scale)
         else:
-            hip.abn_eval_params(weight, bias, running_mean, running_var, eps, Cc, scale, shift)
-            if weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-                mean.copy_(running_mean)                      # d weight under frozen statistics needs xhat
-                torch.rsqrt(running_var + eps, out=invstd)
+            mean = running_mean
+            hip.abn_eval_params(weight, running_var, eps, Cc, invstd, scale)
         count = float(M * world)
         if out is not None:
             y = out
@@ -84,9 +96,9 @@ class _ABNFunction(torch.autograd.Function):
         else:
             y = hip.empty_like_rows(x)
             ld_y = Cc
-        hip.abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, scale, shift, act, slope)
+        hip.abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, scale, bias, act, slope)
         needs_y = residual is not None and act != hip.ACT_IDENTITY
-        ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, buf)
+        ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, bias, buf, mean if not training else None)
         ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, residual is not None,
                    plane_bias is not None, x.shape[0])
         if y is x_in:
@@ -95,11 +107,11 @@ class _ABNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, plane_bias, weight, buf = ctx.saved_tensors
+        x, y, plane_bias, weight, shift, buf, mean_eval = ctx.saved_tensors
         M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, has_res, has_pb, B = ctx.cfg
         dy, _, _, _, ld_dy = hip.rows_view(dy if dy.dtype == x.dtype else dy.to(x.dtype))
-        mean, invstd = buf[2 * Cc + 1:3 * Cc + 1], buf[3 * Cc + 1:4 * Cc + 1]
-        scale, shift = buf[4 * Cc + 1:5 * Cc + 1], buf[5 * Cc + 1:]
+        mean = buf[3 * Cc:4 * Cc] if training else mean_eval
+        invstd, scale = buf[4 * Cc:5 * Cc], buf[5 * Cc:]
         sums = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
         need_param_grad = weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         if training or need_param_grad:
@@ -137,42 +149,44 @@ class _ABNBranchesFunction(torch.autograd.Function):
         Ct = sum(chans)
         dev = x0.device
         out = hip.empty_like_rows(x0, channels=Ct)
-        buf = torch.empty(6 * Ct + 1, dtype=torch.float32, device=dev)
-        sums, mean, invstd = buf[:2 * Ct], buf[2 * Ct + 1:3 * Ct + 1], buf[3 * Ct + 1:4 * Ct + 1]
-        scale, shift = buf[4 * Ct + 1:5 * Ct + 1], buf[5 * Ct + 1:]
+        # per-branch [sums(2c) | kshift(c)] blocks first, then full-width mean | invstd | scale
+        buf = torch.empty(6 * Ct, dtype=torch.float32, device=dev)
+        mean, invstd, scale = buf[3 * Ct:4 * Ct], buf[4 * Ct:5 * Ct], buf[5 * Ct:]
         world = _group_size(group) if training else 1
         count = float(M * world)
         offs, o = [], 0
         for c in chans:
             offs.append(o)
             o += c
-        if training:
-            # per-branch [sum | sum_sq] blocks, laid out so that one all-reduce covers all branches
-            for (x, _, c, _, ld), o in zip(views, offs):
-                hip.abn_stats(x, ld, M, c, None, HW, sums[2 * o:2 * (o + c)])
-            if world > 1:
-                dist.all_reduce(sums, group=group if group is not None else None)
         for (x, _, c, _, ld), o in zip(views, offs):
             sl = slice(o, o + c)
+            sums, kshift = buf[3 * o:3 * o + 2 * c], buf[3 * o + 2 * c:3 * (o + c)]
             w, b = (weight[sl], bias[sl]) if weight is not None else (None, None)
             if training:
-                hip.abn_finalize(sums[2 * o:2 * (o + c)], count, c, w, b, running_mean[sl], running_var[sl], momentum,
-                                 eps, mean[sl], invstd[sl], scale[sl], shift[sl])
+                hip.abn_stats(x, ld, M, c, None, HW, sums, kshift)
+                if world > 1:
+                    _combine_stats_across_ranks(sums, kshift, M, c, world, group)
+                hip.abn_finalize(sums, kshift, count, c, w, running_mean[sl], running_var[sl], momentum, eps, mean[sl],
+                                 invstd[sl], scale[sl])
+                mu = mean[sl]
             else:
-                hip.abn_eval_params(w, b, running_mean[sl], running_var[sl], eps, c, scale[sl], shift[sl])
-            hip.abn_apply(x, ld, out[:, sl], Ct, None, 0, M, c, None, HW, scale[sl], shift[sl], act, slope)
-        ctx.save_for_backward(weight, buf, *[v[0] for v in views])
+                mu = running_mean[sl]
+                hip.abn_eval_params(w, running_var[sl], eps, c, invstd[sl], scale[sl])
+            hip.abn_apply(x, ld, out[:, sl], Ct, None, 0, M, c, None, HW, mu, scale[sl], b, act, slope)
+        if not training:
+            mean.copy_(running_mean)
+        ctx.save_for_backward(weight, bias, buf, *[v[0] for v in views])
         ctx.cfg = (M, HW, chans, offs, [v[4] for v in views], training, act, slope, group, count, world)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        weight, buf, *xs = ctx.saved_tensors
+        weight, bias, buf, *xs = ctx.saved_tensors
         M, HW, chans, offs, lds, training, act, slope, group, count, world = ctx.cfg
         Ct = sum(chans)
         dy, _, _, _, ld_dy = hip.rows_view(dy if dy.dtype == xs[0].dtype else dy.to(xs[0].dtype))
-        mean, invstd = buf[2 * Ct + 1:3 * Ct + 1], buf[3 * Ct + 1:4 * Ct + 1]
-        scale, shift = buf[4 * Ct + 1:5 * Ct + 1], buf[5 * Ct + 1:]
+        mean, invstd, scale = buf[3 * Ct:4 * Ct], buf[4 * Ct:5 * Ct], buf[5 * Ct:]
+        shift = bias if bias is not None else torch.zeros(Ct, dtype=torch.float32, device=dy.device)
         sums = torch.empty(2 * Ct, dtype=torch.float32, device=dy.device)
         if training:
             for x, c, o, ld in zip(xs, chans, offs, lds):

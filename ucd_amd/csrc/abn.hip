@@ -70,7 +70,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__ x, int ld_x, int M, int C,
                                                           const float* __restrict__ plane_bias, int HW,
                                                           int TX, int TY, int rows_per_band,
-                                                          float* __restrict__ partial) {
+                                                          float* __restrict__ partial, float* __restrict__ kshift) {
   constexpr int VEC = Vec<T>::N;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -83,6 +83,19 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
   const int r_end = min(M, r_begin + rows_per_band);
   if (live) {
     const T* xp = x + (size_t)cg * VEC;
+    // Sums are taken about k[c] = the channel's value in row 0 ("shifted data" variance): E[x^2]-E[x]^2
+    // cancels catastrophically in fp32 when |mean| >> std, e.g. the 1x1 pooled ASPP branch at small batch.
+    float k[VEC];
+    {
+      Vec<T> v0;
+      v0.load(xp);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) k[i] = v0.get(i) + (plane_bias ? plane_bias[cg * VEC + i] : 0.f);
+      if (blockIdx.y == 0 && ty == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) kshift[cg * VEC + i] = k[i];
+      }
+    }
     for (int r = r_begin + ty; r < r_end; r += TY) {
       Vec<T> v;
       v.load(xp + (size_t)r * ld_x);
@@ -90,14 +103,14 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
         const float* pb = plane_bias + (size_t)(r / HW) * C + cg * VEC;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          float f = v.get(i) + pb[i];
+          float f = (v.get(i) + pb[i]) - k[i];
           acc[i] += f;
           acc[VEC + i] += f * f;
         }
       } else {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          float f = v.get(i);
+          float f = v.get(i) - k[i];
           acc[i] += f;
           acc[VEC + i] += f * f;
         }
@@ -145,40 +158,35 @@ __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __res
   }
 }
 
-__global__ void abn_finalize_kernel(const float* __restrict__ sums, float count, int C,
-                                    const float* __restrict__ weight, const float* __restrict__ bias,
+__global__ void abn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ kshift, float count, int C,
+                                    const float* __restrict__ weight,
                                     float* __restrict__ running_mean, float* __restrict__ running_var,
                                     float momentum, float eps, float* __restrict__ mean_o,
-                                    float* __restrict__ invstd_o, float* __restrict__ scale_o,
-                                    float* __restrict__ shift_o) {
+                                    float* __restrict__ invstd_o, float* __restrict__ scale_o) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float inv_n = 1.f / count;
-  float mean = sums[c] * inv_n;
-  float var = fmaxf(sums[C + c] * inv_n - mean * mean, 0.f);
-  float invstd = rsqrtf(var + eps);
+  float d = sums[c] * inv_n;                       // mean - k
+  float mean = (kshift ? kshift[c] : 0.f) + d;
+  float var = fmaxf((sums[C + c] - sums[c] * d) * inv_n, 0.f);
+  float invstd = 1.f / sqrtf(var + eps);
   if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
   if (running_var) {
     float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
   }
-  float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
-  float sc = w * invstd;
-  if (mean_o) mean_o[c] = mean;
-  if (invstd_o) invstd_o[c] = invstd;
-  scale_o[c] = sc;
-  shift_o[c] = b - mean * sc;
+  mean_o[c] = mean;
+  invstd_o[c] = invstd;
+  scale_o[c] = (weight ? weight[c] : 1.f) * invstd;
 }
 
-__global__ void abn_eval_params_kernel(const float* __restrict__ weight, const float* __restrict__ bias,
-                                       const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
-                                       float* __restrict__ scale, float* __restrict__ shift) {
+__global__ void abn_eval_params_kernel(const float* __restrict__ weight, const float* __restrict__ rv, float eps, int C,
+                                       float* __restrict__ invstd, float* __restrict__ scale) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
-  float sc = w * rsqrtf(rv[c] + eps);
-  scale[c] = sc;
-  shift[c] = b - rm[c] * sc;
+  float is = 1.f / sqrtf(rv[c] + eps);
+  invstd[c] = is;
+  scale[c] = (weight ? weight[c] : 1.f) * is;
 }
 
 // ---- forward apply ------------------------------------------------------------------------------
@@ -186,17 +194,19 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(kBlock) void abn_apply_kernel(const T* x, int ld_x, T* y, int ld_y,
                                                           const T* __restrict__ res, int ld_r, int M, int C,
                                                           const float* __restrict__ plane_bias, int HW,
-                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ mean, const float* __restrict__ scale,
+                                                          const float* __restrict__ beta,
                                                           float slope, int TX, int TY, int rows_per_band) {
   constexpr int VEC = Vec<T>::N;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cg = blockIdx.x * TX + tx;
   if (ty >= TY || cg * VEC >= C) return;
-  float sc[VEC], sh[VEC];
+  float mu[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
+    mu[i] = mean[cg * VEC + i];
     sc[i] = scale[cg * VEC + i];
-    sh[i] = shift[cg * VEC + i];
+    sh[i] = beta ? beta[cg * VEC + i] : 0.f;
   }
   const int r_begin = blockIdx.y * rows_per_band;
   const int r_end = min(M, r_begin + rows_per_band);
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void abn_apply_kernel(const T* x, int ld_x,
     for (int i = 0; i < VEC; ++i) {
       float f = v.get(i);
       if (pb) f += pb[i];
-      float z = f * sc[i] + sh[i];
+      float z = (f - mu[i]) * sc[i] + sh[i];     // subtract first: exact when x is close to the mean
       if (res) z += rv.get(i);
       o.set(i, act_fwd<ACT>(z, slope));
     }
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
       mu[i] = mean[cg * VEC + i];
       is[i] = invstd[cg * VEC + i];
       sc[i] = scale[cg * VEC + i];
-      sh[i] = shift[cg * VEC + i];
+      sh[i] = shift ? shift[cg * VEC + i] : 0.f;
     }
     const int r_begin = blockIdx.y * rows_per_band;
     const int r_end = min(M, r_begin + rows_per_band);
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
       for (int i = 0; i < VEC; ++i) {
         float f = v.get(i);
         if (pb) f += pb[i];
-        float sgn = yout ? yo.get(i) : f * sc[i] + sh[i];
+        float sgn = yout ? yo.get(i) : (f - mu[i]) * sc[i] + sh[i];
         float dz = g.get(i) * act_grad<ACT>(sgn, slope);
         float xh = (f - mu[i]) * is[i];
         acc[i] += dz;
@@ -291,12 +301,12 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
   for (int i = 0; i < VEC; ++i) {
     const int c = cg * VEC + i;
     sc[i] = scale[c];
-    sh[i] = shift[c];
+    sh[i] = shift ? shift[c] : 0.f;
+    mu[i] = mean[c];
     if (frozen) {
-      mu[i] = 0.f; is[i] = 0.f; k0[i] = 0.f; k1[i] = 0.f;
+      is[i] = 0.f; k0[i] = 0.f; k1[i] = 0.f;
       gw[i] = sc[i];
     } else {
-      mu[i] = mean[c];
       is[i] = invstd[c];
       k0[i] = sums[c] * inv_count;       // mean(dz)
       k1[i] = sums[C + c] * inv_count;   // mean(dz * xhat)
@@ -316,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
     for (int i = 0; i < VEC; ++i) {
       float f = v.get(i);
       if (pb) f += pb[i];
-      float sgn = yout ? yo.get(i) : f * sc[i] + sh[i];
+      float sgn = yout ? yo.get(i) : (f - mu[i]) * sc[i] + sh[i];
       float dz = g.get(i) * act_grad<ACT>(sgn, slope);
       float xh = (f - mu[i]) * is[i];
       o.set(i, (dz - k0[i] - xh * k1[i]) * gw[i]);
@@ -451,11 +461,11 @@ size_t ucd_abn_workspace_bytes(int M, int C) {
 }
 
 int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW, float* sums,
-                  void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+                  float* kshift, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_stats";
   UCD_TRY(check_common(fn, dtype, M, C, UCD_ACT_IDENTITY));
   UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
-  UCD_REQUIRE(sums && workspace, UCD_EINVAL, "%s: sums/workspace is NULL", fn);
+  UCD_REQUIRE(sums && kshift && workspace, UCD_EINVAL, "%s: sums/kshift/workspace is NULL", fn);
   UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
@@ -464,47 +474,45 @@ int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float*
     g = make_geom<8>(M, C, 2048, 8);
     UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
     abn_stats_kernel<__hip_bfloat16><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>(
-        (const __hip_bfloat16*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial);
+        (const __hip_bfloat16*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial, kshift);
   } else {
     g = make_geom<4>(M, C, 2048, 8);
     UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
     abn_stats_kernel<float><<<dim3(g.gx, g.gy), kBlock, kBlock * 8 * 4, s>>>(
-        (const float*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial);
+        (const float*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial, kshift);
   }
   UCD_TRY(check_launch(fn));
   reduce_bands_kernel<<<ceil_div(2 * C, 16), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
   return check_launch(fn);
 }
 
-int ucd_abn_finalize(const float* sums, float count, int C, const float* weight, const float* bias,
+int ucd_abn_finalize(const float* sums, const float* kshift, float count, int C, const float* weight,
                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                     float* scale, float* shift, ucd_stream_t stream) {
+                     float* scale, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_finalize";
-  UCD_REQUIRE(sums && scale && shift && C > 0 && count > 0.f, UCD_EINVAL, "%s: bad arguments", fn);
-  abn_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, count, C, weight, bias, running_mean,
-                                                                        running_var, momentum, eps, mean, invstd,
-                                                                        scale, shift);
+  UCD_REQUIRE(sums && mean && invstd && scale && C > 0 && count > 0.f, UCD_EINVAL, "%s: bad arguments", fn);
+  abn_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, kshift, count, C, weight, running_mean,
+                                                                        running_var, momentum, eps, mean, invstd, scale);
   return check_launch(fn);
 }
 
-int ucd_abn_eval_params(const float* weight, const float* bias, const float* running_mean, const float* running_var,
-                        float eps, int C, float* scale, float* shift, ucd_stream_t stream) {
+int ucd_abn_eval_params(const float* weight, const float* running_var, float eps, int C, float* invstd, float* scale,
+                        ucd_stream_t stream) {
   static const char* fn = "ucd_abn_eval_params";
-  UCD_REQUIRE(running_mean && running_var && scale && shift && C > 0, UCD_EINVAL, "%s: bad arguments", fn);
-  abn_eval_params_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(weight, bias, running_mean, running_var,
-                                                                           eps, C, scale, shift);
+  UCD_REQUIRE(running_var && invstd && scale && C > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  abn_eval_params_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(weight, running_var, eps, C, invstd, scale);
   return check_launch(fn);
 }
 
 int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r, int dtype, int M, int C,
-                  const float* plane_bias, int HW, const float* scale, const float* shift, int act, float slope,
-                  ucd_stream_t stream) {
+                  const float* plane_bias, int HW, const float* mean, const float* scale, const float* shift, int act,
+                  float slope, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_apply";
   UCD_TRY(check_common(fn, dtype, M, C, act));
   UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
   UCD_TRY(check_act_tensor(fn, "y", y, ld_y, dtype, C, false));
   UCD_TRY(check_act_tensor(fn, "residual", residual, ld_r, dtype, C, true));
-  UCD_REQUIRE(scale && shift, UCD_EINVAL, "%s: scale/shift is NULL", fn);
+  UCD_REQUIRE(mean && scale, UCD_EINVAL, "%s: mean/scale is NULL", fn);
   UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_APPLY(T, VECN, ACT)                                                                             \
@@ -512,7 +520,7 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
     Geom g = make_geom<VECN>(M, C, 2048, 4);                                                                   \
     abn_apply_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, 0, s>>>((const T*)x, ld_x, (T*)y, ld_y,               \
                                                                  (const T*)residual, ld_r, M, C, plane_bias,   \
-                                                                 HW, scale, shift, slope, g.TX, g.TY,          \
+                                                                 HW, mean, scale, shift, slope, g.TX, g.TY,    \
                                                                  g.rows_per_band);                             \
   }
   if (dtype == UCD_BF16) {
@@ -535,7 +543,7 @@ int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const
   UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
   UCD_TRY(check_act_tensor(fn, "dy", dy, ld_dy, dtype, C, false));
   UCD_TRY(check_act_tensor(fn, "y", y, ld_y, dtype, C, true));
-  UCD_REQUIRE(mean && invstd && scale && shift && sums && workspace, UCD_EINVAL, "%s: NULL argument", fn);
+  UCD_REQUIRE(mean && invstd && scale && sums && workspace, UCD_EINVAL, "%s: NULL argument", fn);
   UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
   hipStream_t s = (hipStream_t)stream;
   float* partial = (float*)workspace;
@@ -573,8 +581,8 @@ int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const 
   UCD_TRY(check_act_tensor(fn, "y", y, ld_y, dtype, C, true));
   UCD_TRY(check_act_tensor(fn, "dx", dx, ld_dx, dtype, C, false));
   UCD_TRY(check_act_tensor(fn, "dz_out", dz_out, ld_dz, dtype, C, true));
-  UCD_REQUIRE(scale && shift, UCD_EINVAL, "%s: scale/shift is NULL", fn);
-  UCD_REQUIRE(frozen || (mean && invstd && sums && count > 0.f), UCD_EINVAL, "%s: training statistics missing", fn);
+  UCD_REQUIRE(scale && mean, UCD_EINVAL, "%s: scale/mean is NULL", fn);
+  UCD_REQUIRE(frozen || (invstd && sums && count > 0.f), UCD_EINVAL, "%s: training statistics missing", fn);
   UCD_REQUIRE(!plane_bias || HW > 0, UCD_EINVAL, "%s: plane_bias needs HW > 0", fn);
   hipStream_t s = (hipStream_t)stream;
   const float inv_count = frozen ? 0.f : 1.f / count;

@@ -1,0 +1,221 @@
+// Fused full-resolution logit losses: bilinear x16 up-sampling of the student and
+// teacher logits (segmentation_module.py:133) + UnbiasedCrossEntropy (utils/loss.py:96-109) +
+// UnbiasedKnowledgeDistillationLoss (utils/loss.py:148-184) + their gradient w.r.t. the LOW-resolution
+// student logits, in one pass.  The reference materialises [B, Ctot, H, W] float32 logits for student and
+// teacher (22 MB / image each at VOC 513^2, 158 MB at ADE) and then ~10 full-resolution temporaries per loss;
+// here a full-resolution logit only ever exists in a register.
+//
+// Per full-resolution pixel: z_c = sum of 4 weighted low-res neighbours (torch's align_corners=False
+// source-index arithmetic), three log-sum-exps of the student (all classes / old classes [0,K) /
+// background + new classes), the teacher soft-max, the two losses and
+//   dCE/dz_c = softmax(z)_c - [label is bkg/old] [c < K] exp(z_c - LSE_old) - [label new] [c == label]
+//   dKD/dz_c = (softmax(z)_c - q_0 [c in {0} U [K,Ctot)] exp(z_c - LSE_bkgnew) - [1 <= c < K] q_c) / K
+// scattered to the 4 neighbours with their bilinear weights.  A 256-thread block owns a 16 x 64 pixel
+// tile; the <= 3 x 7 low-res cells under it are staged in LDS (logits in, gradient accumulators out, LDS
+// float atomics), then flushed with one global float atomic per cell and class (the summation order of
+// float atomics makes the last bits of the gradient run-dependent; the loss sums use a fixed order).
+#include "common.h"
+
+namespace ucd {
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTileY = 16, kTileX = 64;
+constexpr int kMaxCells = 4 * 8;  // low-res rows x cols that a tile can touch (scale >= 8)
+
+__device__ __forceinline__ void up_src(int dst, int in_size, float scale, int& i0, int& i1, float& l0, float& l1) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  i0 = min((int)src, in_size - 1);
+  i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  l1 = src - (float)i0;
+  l0 = 1.f - l1;
+}
+
+// loss_part: [blocks][2] (ce sum, kd sum) ; d_sem accumulates ce_scale*dCE + kd_scale*dKD
+__global__ __launch_bounds__(kThreads) void seg_losses_kernel(
+    const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
+    int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
+    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.z, ty0 = blockIdx.y * kTileY, tx0 = blockIdx.x * kTileX;
+  // low-res footprint of the tile
+  int ya, yb, xa, xb, dummy;
+  float f0, f1;
+  up_src(ty0, h, scale_h, ya, dummy, f0, f1);
+  up_src(min(ty0 + kTileY, H) - 1, h, scale_h, dummy, yb, f0, f1);
+  up_src(tx0, w, scale_w, xa, dummy, f0, f1);
+  up_src(min(tx0 + kTileX, W) - 1, w, scale_w, dummy, xb, f0, f1);
+  const int ny = yb - ya + 1, nx = xb - xa + 1, ncell = ny * nx;
+  float* s_log = smem;                      // [ncell][Ctot] student logits
+  float* t_log = s_log + ncell * Ctot;      // [ncell][K]    teacher logits
+  float* g_acc = t_log + ncell * K;         // [ncell][Ctot] gradient accumulators
+  for (int i = threadIdx.x; i < ncell * Ctot; i += kThreads) {
+    const int cell = i / Ctot, c = i - cell * Ctot;
+    const int cy = ya + cell / nx, cx = xa + cell % nx;
+    s_log[i] = sem_s[((size_t)(b * h + cy) * w + cx) * ld_s + c];
+    g_acc[i] = 0.f;
+  }
+  if (sem_t)
+    for (int i = threadIdx.x; i < ncell * K; i += kThreads) {
+      const int cell = i / K, c = i - cell * K;
+      const int cy = ya + cell / nx, cx = xa + cell % nx;
+      t_log[i] = sem_t[((size_t)(b * h + cy) * w + cx) * ld_t + c];
+    }
+  __syncthreads();
+
+  float ce_sum = 0.f, kd_sum = 0.f;
+  const int X = tx0 + (threadIdx.x & 63);
+  const float invK = K > 0 ? 1.f / (float)K : 0.f;
+  for (int it = 0; it < kTileY / 4; ++it) {
+    const int Y = ty0 + (threadIdx.x >> 6) + 4 * it;
+    if (X >= W || Y >= H) continue;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    up_src(Y, h, scale_h, y0, y1, ly0, ly1);
+    up_src(X, w, scale_w, x0, x1, lx0, lx1);
+    const int c00 = (y0 - ya) * nx + (x0 - xa), c01 = (y0 - ya) * nx + (x1 - xa);
+    const int c10 = (y1 - ya) * nx + (x0 - xa), c11 = (y1 - ya) * nx + (x1 - xa);
+    // torch's up-sampling arithmetic: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+    auto interp = [&](const float* base, int stride, int c) {
+      return ly0 * (lx0 * base[c00 * stride + c] + lx1 * base[c01 * stride + c]) +
+             ly1 * (lx0 * base[c10 * stride + c] + lx1 * base[c11 * stride + c]);
+    };
+    const int64_t lab64 = labels[((size_t)b * H + Y) * W + X];
+    const bool ignored = lab64 == ignore_index;
+    int lab = ignored ? 0 : (int)lab64;
+    if (lab < K) lab = 0;                                    // loss.py:104-105
+    // pass A: maxima
+    float mz = -INFINITY;
+    for (int c = 0; c < Ctot; ++c) mz = fmaxf(mz, interp(s_log, Ctot, c));
+    // pass B: the three sums, the labelled logit
+    float s_all = 0.f, s_old = 0.f, s_bn = 0.f, z_lab = 0.f;
+    for (int c = 0; c < Ctot; ++c) {
+      const float z = interp(s_log, Ctot, c);
+      const float e = __expf(z - mz);
+      s_all += e;
+      if (c < K) s_old += e;
+      if (c == 0 || c >= K) s_bn += e;
+      if (c == lab) z_lab = z;
+    }
+    const float den = mz + __logf(s_all);
+    const float lse_old = mz + __logf(s_old), lse_bn = mz + __logf(s_bn);
+    const float logp = lab == 0 ? lse_old - den : z_lab - den;
+    if (!ignored) ce_sum += -logp;
+    // teacher soft-max
+    float mt = -INFINITY, st = 0.f, q0 = 0.f, kd_pix = 0.f;
+    if (sem_t) {
+      for (int c = 0; c < K; ++c) mt = fmaxf(mt, interp(t_log, K, c));
+      for (int c = 0; c < K; ++c) st += __expf(interp(t_log, K, c) - mt);
+      q0 = __expf(interp(t_log, K, 0) - mt) / st;
+      kd_pix = q0 * (lse_bn - den);
+    }
+    // pass C: gradients (and the old-class part of the KD loss)
+    const float ce_w = ignored ? 0.f : ce_scale;
+    const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+    for (int c = 0; c < Ctot; ++c) {
+      const float z = interp(s_log, Ctot, c);
+      const float p = __expf(z - den);
+      float g = ce_w * (p - (lab == 0 ? (c < K ? __expf(z - lse_old) : 0.f) : (c == lab ? 1.f : 0.f)));
+      if (sem_t) {
+        float qc = 0.f;
+        if (c >= 1 && c < K) {
+          qc = __expf(interp(t_log, K, c) - mt) / st;
+          kd_pix += qc * (z - den);
+        }
+        const float bn = (c == 0 || c >= K) ? q0 * __expf(z - lse_bn) : 0.f;
+        g += kd_scale * invK * (p - bn - qc);
+      }
+      atomicAdd(&g_acc[c00 * Ctot + c], w00 * g);
+      atomicAdd(&g_acc[c01 * Ctot + c], w01 * g);
+      atomicAdd(&g_acc[c10 * Ctot + c], w10 * g);
+      atomicAdd(&g_acc[c11 * Ctot + c], w11 * g);
+    }
+    kd_sum += -kd_pix * invK;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncell * Ctot; i += kThreads) {
+    const float v = g_acc[i];
+    if (v != 0.f) {
+      const int cell = i / Ctot, c = i - cell * Ctot;
+      const int cy = ya + cell / nx, cx = xa + cell % nx;
+      atomicAdd(&d_sem[((size_t)(b * h + cy) * w + cx) * ld_d + c], v);
+    }
+  }
+  // block loss sums (fixed order)
+  __shared__ float red[2][kThreads / 64];
+  ce_sum = wave_sum(ce_sum);
+  kd_sum = wave_sum(kd_sum);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ce_sum; red[1][threadIdx.x >> 6] = kd_sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int blk = (blockIdx.z * tiles_y + blockIdx.y) * tiles_x + blockIdx.x;
+    loss_part[2 * blk + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    loss_part[2 * blk + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ __launch_bounds__(1024) void seg_losses_reduce_kernel(const float* __restrict__ part, int n, float inv_pix,
+                                                                float* __restrict__ out) {
+  __shared__ double red[2][16];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) { a += part[2 * i]; b += part[2 * i + 1]; }
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < 16; ++i) { sa += red[0][i]; sb += red[1][i]; }
+    out[0] = (float)(sa * inv_pix);   // mean over ALL pixels, ignored ones count as 0 (train.py:116 .mean())
+    out[1] = (float)(sb * inv_pix);   // KD mean over all pixels (loss.py:178)
+  }
+}
+
+}  // namespace
+}  // namespace ucd
+
+using namespace ucd;
+
+extern "C" {
+
+size_t ucd_seg_losses_workspace_bytes(int B, int H, int W) {
+  return (size_t)B * ceil_div(H, kTileY) * ceil_div(W, kTileX) * 2 * sizeof(float);
+}
+
+int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, const int64_t* labels, int B, int H, int W,
+                   int h, int w, int Ctot, int K, int ignore_index, float ce_weight, float kd_weight, float* loss_out,
+                   float* d_sem, int ld_d, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_seg_losses";
+  UCD_REQUIRE(sem_s && labels && loss_out && d_sem && workspace, UCD_EINVAL, "%s: NULL argument", fn);
+  UCD_REQUIRE(B > 0 && H > 0 && W > 0 && h > 0 && w > 0 && Ctot > 0 && K >= 1 && K <= Ctot, UCD_EINVAL, "%s: bad sizes", fn);
+  UCD_REQUIRE(ld_s >= Ctot && ld_d >= Ctot && (!sem_t || ld_t >= K), UCD_EINVAL, "%s: bad leading dimension", fn);
+  UCD_REQUIRE(H >= 8 * h || H >= h, UCD_EINVAL, "%s: bad scale", fn);
+  UCD_REQUIRE((float)H / h >= 4.f && (float)W / w >= 4.f, UCD_EUNSUPPORTED,
+              "%s: built for up-sampling factors >= 4 (the model's is 16)", fn);
+  UCD_REQUIRE(workspace_bytes >= ucd_seg_losses_workspace_bytes(B, H, W), UCD_EWORKSPACE, "%s: workspace too small", fn);
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles_x = ceil_div(W, kTileX), tiles_y = ceil_div(H, kTileY);
+  // worst-case LDS: (tile/scale + 3) cells per dimension
+  const int ny = (int)(kTileY * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
+  const size_t lds = (size_t)ny * nx * (2 * Ctot + (sem_t ? K : 0)) * sizeof(float);
+  UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)seg_losses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipError_t e = hipMemsetAsync(d_sem, 0, (size_t)B * h * w * ld_d * sizeof(float), s);
+  if (e != hipSuccess) { set_error("%s: %s", fn, hipGetErrorString(e)); return (int)e; }
+  const float inv_pix = 1.f / ((float)B * H * W);
+  float* part = (float*)workspace;
+  // torch computes the up-sampling scale as float(in) / out
+  seg_losses_kernel<<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
+      sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
+      ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
+  int rc = check_launch(fn);
+  if (rc) return rc;
+  seg_losses_reduce_kernel<<<1, 1024, 0, s>>>(part, B * tiles_x * tiles_y, inv_pix, loss_out);
+  return check_launch(fn);
+}
+
+}  // extern "C"

@@ -40,10 +40,10 @@ SIGNATURES = {
     "ucd_version": (_i, []),
     "ucd_last_error": (C.c_char_p, []),
     "ucd_abn_workspace_bytes": (_z, [_i, _i]),
-    "ucd_abn_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _z, _p]),
-    "ucd_abn_finalize": (_i, [_p, _f, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
-    "ucd_abn_eval_params": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
-    "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _i, _f, _p]),
+    "ucd_abn_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
+    "ucd_abn_finalize": (_i, [_p, _p, _f, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p]),
+    "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _p]),
+    "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
     "ucd_abn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p,
                                _f, _i, _i, _f, _p]),
@@ -56,6 +56,8 @@ SIGNATURES = {
     "ucd_pixcon_loss_workspace_bytes": (_z, [_i, _i, _i]),
     "ucd_pixcon_loss": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _i, _f, _i, _i, _p, _p, _i, _p, _p, _z, _p]),
     "ucd_pixcon_scatter_grad": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ucd_seg_losses_workspace_bytes": (_z, [_i, _i, _i]),
+    "ucd_seg_losses": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _i, _p, _z, _p]),
 }
 
 _lib = None
@@ -202,31 +204,31 @@ def empty_like_rows(x, channels=None, dtype=None):
 # ---------------------------------------------------------------------------------------------
 # thin wrappers (no autograd)
 # ---------------------------------------------------------------------------------------------
-def abn_stats(x, ld, M, Cc, plane_bias, HW, sums):
+def abn_stats(x, ld, M, Cc, plane_bias, HW, sums, kshift):
     lib = load()
     nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
     ws = workspace(nbytes, x.device)
     with _timed("ucd_abn_stats", M * Cc * x.element_size()):
-        _check(lib.ucd_abn_stats(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(ws), nbytes,
-                                 stream()), "ucd_abn_stats")
+        _check(lib.ucd_abn_stats(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(kshift),
+                                 ptr(ws), nbytes, stream()), "ucd_abn_stats")
 
 
-def abn_finalize(sums, count, Cc, weight, bias, running_mean, running_var, momentum, eps, mean, invstd, scale, shift):
-    _check(load().ucd_abn_finalize(ptr(sums), float(count), Cc, ptr(weight), ptr(bias), ptr(running_mean),
+def abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale):
+    _check(load().ucd_abn_finalize(ptr(sums), ptr(kshift), float(count), Cc, ptr(weight), ptr(running_mean),
                                    ptr(running_var), float(momentum), float(eps), ptr(mean), ptr(invstd), ptr(scale),
-                                   ptr(shift), stream()), "ucd_abn_finalize")
+                                   stream()), "ucd_abn_finalize")
 
 
-def abn_eval_params(weight, bias, running_mean, running_var, eps, Cc, scale, shift):
-    _check(load().ucd_abn_eval_params(ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), float(eps), Cc,
-                                      ptr(scale), ptr(shift), stream()), "ucd_abn_eval_params")
+def abn_eval_params(weight, running_var, eps, Cc, invstd, scale):
+    _check(load().ucd_abn_eval_params(ptr(weight), ptr(running_var), float(eps), Cc, ptr(invstd), ptr(scale),
+                                      stream()), "ucd_abn_eval_params")
 
 
-def abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, scale, shift, act, slope):
+def abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, scale, shift, act, slope):
     with _timed("ucd_abn_apply", M * Cc * x.element_size() * (2 + (residual is not None))):
         _check(load().ucd_abn_apply(ptr(x), ld_x, ptr(y), ld_y, ptr(residual), ld_r, dtype_code(x), M, Cc,
-                                    ptr(plane_bias), HW, ptr(scale), ptr(shift), act, float(slope), stream()),
-               "ucd_abn_apply")
+                                    ptr(plane_bias), HW, ptr(mean), ptr(scale), ptr(shift), act, float(slope),
+                                    stream()), "ucd_abn_apply")
 
 
 def abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope, sums):

@@ -11,7 +11,55 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import hip
 from .contrastive import PixelConLossV2, pre_contractive_pixel, ucd_contrastive_loss  # noqa: F401
+
+
+class _FusedSegLosses(torch.autograd.Function):
+    """total = ce_weight * mean(UnbiasedCE) + kd_weight * mean(UnbiasedKD) from the LOW-resolution logits;
+    the up-sampled [B, Ctot, H, W] tensors never exist (ucd_seg_losses)."""
+
+    @staticmethod
+    def forward(ctx, sem, sem_old, labels, old_cl, ce_weight, kd_weight, ignore_index):
+        lib = hip.load()
+        B, Ctot, h, w = sem.shape
+        H, W = labels.shape[-2:]
+        s = sem.detach().permute(0, 2, 3, 1).reshape(B * h * w, Ctot).float().contiguous()
+        t, K = None, int(old_cl)
+        if sem_old is not None:
+            K = sem_old.shape[1]
+            t = sem_old.detach().permute(0, 2, 3, 1).reshape(B * h * w, K).float().contiguous()
+        labels = labels.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=sem.device)
+        d = torch.empty(B * h * w, Ctot, dtype=torch.float32, device=sem.device)
+        nbytes = lib.ucd_seg_losses_workspace_bytes(B, H, W)
+        ws = hip.workspace(nbytes, sem.device, "seglosses")
+        with hip._timed("ucd_seg_losses", B * H * W * 8 + 2 * B * h * w * (2 * Ctot + K) * 4):
+            hip._check(lib.ucd_seg_losses(hip.ptr(s), Ctot, hip.ptr(t), K, hip.ptr(labels), B, H, W, h, w, Ctot, max(K, 1),
+                                          int(ignore_index), float(ce_weight), float(kd_weight), hip.ptr(out), hip.ptr(d),
+                                          Ctot, hip.ptr(ws), nbytes, hip.stream()), "ucd_seg_losses")
+        ctx.save_for_backward(d)
+        ctx.meta = (B, Ctot, h, w, sem.dtype)
+        ce, kd = out[0], out[1]
+        total = ce_weight * ce + kd_weight * kd
+        ctx.mark_non_differentiable(ce, kd)
+        return total, ce, kd
+
+    @staticmethod
+    def backward(ctx, g, _gce, _gkd):
+        (d,) = ctx.saved_tensors
+        B, Ctot, h, w, dtype = ctx.meta
+        grad = (d * g).view(B, h, w, Ctot).permute(0, 3, 1, 2).to(dtype)
+        return grad, None, None, None, None, None, None
+
+
+def fused_seg_losses(sem, sem_old, labels, old_cl, ce_weight=1.0, kd_weight=0.0, ignore_index=255):
+    """Returns (ce_weight*CE + kd_weight*KD [differentiable w.r.t. ``sem``], CE, KD) where CE / KD are the
+    reference's ``UnbiasedCrossEntropy(...)(up(sem), labels).mean()`` and
+    ``UnbiasedKnowledgeDistillationLoss()(up(sem), up(sem_old))`` (``up`` = bilinear to the label size)."""
+    if not sem.is_cuda:
+        raise RuntimeError("ucd_amd.loss.fused_seg_losses runs on the GPU only (there is no CPU fallback)")
+    return _FusedSegLosses.apply(sem, sem_old, labels, old_cl, ce_weight, kd_weight, ignore_index)
 
 
 class UnbiasedCrossEntropy(nn.Module):

@@ -127,12 +127,14 @@ class IncrementalSegmentationModule(nn.Module):
             cls.bias.fill_(new_bias.item())
             self.cls[0].bias[0] = new_bias.item()
 
-    def forward(self, x, x_b_old=None, x_pl_old=None, ret_intermediate=False):
+    def forward(self, x, x_b_old=None, x_pl_old=None, ret_intermediate=False, upsample=True):
+        """``upsample=False`` (not in the reference) skips the x16 bilinear up-sampling and returns ``None``
+        for the full-resolution logits: the trainer's fused losses read ``features["sem"]`` instead."""
         out_size = x.shape[-2:]
         if x.is_cuda and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
         sem, x_b, x_pl = self._network(x, x_b_old, x_pl_old, ret_intermediate)
-        logits = F.interpolate(sem, size=out_size, mode="bilinear", align_corners=False)
+        logits = F.interpolate(sem, size=out_size, mode="bilinear", align_corners=False) if upsample else None
         return logits, Features(x_b, x_pl, sem)
 
     def fix_bn(self):

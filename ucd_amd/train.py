@@ -28,7 +28,8 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from .contrastive import ucd_contrastive_loss
-from .loss import KnowledgeDistillationLoss, UnbiasedCrossEntropy, UnbiasedKnowledgeDistillationLoss
+from .loss import (KnowledgeDistillationLoss, UnbiasedCrossEntropy, UnbiasedKnowledgeDistillationLoss,
+                   fused_seg_losses)
 
 
 def _raw(features, name):
@@ -65,6 +66,11 @@ class Trainer:
         self.lkd_loss = (UnbiasedKnowledgeDistillationLoss if opts.unkd else KnowledgeDistillationLoss)(alpha=opts.alpha)
         self.regularizer, self.regularizer_flag = None, False
         self.ret_intermediate = self.lde
+        self.unce = bool(opts.unce and self.old_classes != 0)
+        # fused up-sampling + CE + KD kernel whenever the loss pair is one it implements:
+        # (unbiased or plain) CE, optionally with the unbiased KD
+        self.fuse_logit_losses = (getattr(opts, "fused_logit_losses", True) and device.type == "cuda"
+                                  and (not self.lkd_flag or (opts.unkd and self.unce)))
         self.amp = getattr(opts, "opt_level", "O0") != "O0"
         # contrastive arithmetic: exact fp32 MFMA with fp32 activations (O0), fp16 operands otherwise
         self.pixcon_precision = getattr(opts, "pixcon_precision", None) or ("f16" if self.amp else "f32")
@@ -83,22 +89,30 @@ class Trainer:
             images = images.contiguous(memory_format=torch.channels_last)
         zero = torch.zeros((), device=self.device)
         lkd = lde = zero
+        fuse = self.fuse_logit_losses
+        up = {} if not fuse else {"upsample": False}
         if model_old is not None:
             with torch.no_grad(), self._autocast():
                 outputs_old, features_old = model_old(images, x_b_old=None, x_pl_old=None,
-                                                      ret_intermediate=self.ret_intermediate)
+                                                      ret_intermediate=self.ret_intermediate, **up)
         if hasattr(model, "zero_grad") and hasattr(model, "finish_grad_sync"):
             model.zero_grad()
         else:
             optim.zero_grad(set_to_none=True)
         with self._autocast():
             if model_old is None:
-                outputs, features = model(images, ret_intermediate=self.ret_intermediate)
+                outputs, features = model(images, ret_intermediate=self.ret_intermediate, **up)
             else:
                 outputs, features = model(images, x_b_old=_raw(features_old, "body"),
                                           x_pl_old=_raw(features_old, "pre_logits"),
-                                          ret_intermediate=self.ret_intermediate)
-        ce = self.criterion(outputs.float() if outputs.dtype != torch.float32 else outputs, labels).mean()
+                                          ret_intermediate=self.ret_intermediate, **up)
+        if fuse:
+            # one pass over the label map: bilinear up-sampling + CE (+ KD) + gradient w.r.t. the low-res logits
+            total, ce, kd = fused_seg_losses(features["sem"], features_old["sem"] if self.lkd_flag else None, labels,
+                                             self.old_classes if self.unce else 1, 1.0,
+                                             self.lkd if self.lkd_flag else 0.0)
+        else:
+            ce = self.criterion(outputs.float() if outputs.dtype != torch.float32 else outputs, labels).mean()
         con = zero
         if model_old is not None:
             con = ucd_contrastive_loss(_raw(features, "pre_logits"), labels, features_old["sem"],
@@ -109,8 +123,8 @@ class Trainer:
             lde = self.lde * (self.lde_loss(features["body"].float(), features_old["body"].float())
                               + self.lde_loss(features["pre_logits"].float(), features_old["pre_logits"].float()))
         if self.lkd_flag:
-            lkd = self.lkd * self.lkd_loss(outputs, outputs_old)                  # train.py:131-133
-        loss_tot = loss + lkd + lde
+            lkd = self.lkd * (kd if fuse else self.lkd_loss(outputs, outputs_old))   # train.py:131-133
+        loss_tot = (total + con / 100 + lde) if fuse else (loss + lkd + lde)
         loss_tot.backward()
         if hasattr(model, "finish_grad_sync"):
             model.finish_grad_sync()
