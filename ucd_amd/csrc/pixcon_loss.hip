@@ -492,6 +492,7 @@ int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label,
     // opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per workgroup)
     hipFuncSetAttribute((const void*)pixcon_neg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute((const void*)pixcon_pos_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
     attr_set = true;
   }
   pixcon_neg_kernel<<<dim3(p.nt_i, p.nsplit1), kThreads, lds1, s>>>(chat, ldc, row_label, meta, inv_T, p.nsplit1, maxA,

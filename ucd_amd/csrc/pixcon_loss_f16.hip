@@ -453,6 +453,7 @@ int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)pixcon16_neg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)pixcon16_pos_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
     attr_set = true;
   }
   const size_t lds1 = (size_t)2 * kTJ * kPitchH * 2 + 2 * kTJ * 4;

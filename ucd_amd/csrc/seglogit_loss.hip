@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   float* s_log = smem;                      // [ncell][Ctot] student logits
   float* t_log = s_log + ncell * Ctot;      // [ncell][K]    teacher logits
   float* g_acc = t_log + ncell * K;         // [ncell][Ctot] gradient accumulators
+  float* red = g_acc + ncell * Ctot;        // [2][4] block loss partials
   for (int i = threadIdx.x; i < ncell * Ctot; i += kThreads) {
     const int cell = i / Ctot, c = i - cell * Ctot;
     const int cy = ya + cell / nx, cx = xa + cell % nx;
@@ -143,15 +144,14 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
     }
   }
   // block loss sums (fixed order)
-  __shared__ float red[2][kThreads / 64];
   ce_sum = wave_sum(ce_sum);
   kd_sum = wave_sum(kd_sum);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ce_sum; red[1][threadIdx.x >> 6] = kd_sum; }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = ce_sum; red[4 + (threadIdx.x >> 6)] = kd_sum; }
   __syncthreads();
   if (threadIdx.x == 0) {
     const int blk = (blockIdx.z * tiles_y + blockIdx.y) * tiles_x + blockIdx.x;
-    loss_part[2 * blk + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    loss_part[2 * blk + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    loss_part[2 * blk + 0] = red[0] + red[1] + red[2] + red[3];
+    loss_part[2 * blk + 1] = red[4] + red[5] + red[6] + red[7];
   }
 }
 
@@ -197,11 +197,12 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const int tiles_x = ceil_div(W, kTileX), tiles_y = ceil_div(H, kTileY);
   // worst-case LDS: (tile/scale + 3) cells per dimension
   const int ny = (int)(kTileY * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
-  const size_t lds = (size_t)ny * nx * (2 * Ctot + (sem_t ? K : 0)) * sizeof(float);
+  const size_t lds = ((size_t)ny * nx * (2 * Ctot + K) + 8) * sizeof(float);
   UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)seg_losses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t ea = hipFuncSetAttribute((const void*)seg_losses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (ea != hipSuccess) { (void)hipGetLastError(); set_error("%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(ea)); return (int)ea; }
     attr_set = true;
   }
   hipError_t e = hipMemsetAsync(d_sem, 0, (size_t)B * h * w * ld_d * sizeof(float), s);
