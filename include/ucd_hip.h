@@ -69,6 +69,14 @@ int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C,
                   float* sums /* [2*C] */, float* kshift /* [C] */,
                   void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
+/* ucd_abn_stats followed by ucd_abn_finalize with count = M, in one launch sequence less (the stage-2
+ * reduction finalises its own channels): the single-process training forward. */
+int ucd_abn_stats_finalize(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW,
+                           float* sums, float* kshift, const float* weight,
+                           float* running_mean, float* running_var, float momentum, float eps,
+                           float* mean, float* invstd, float* scale,
+                           void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
 /* Batch statistics -> normalisation constants.  With d = sums[c]/count:
  *   mean = kshift + d,  var = (sums[C+c] - sums[c]*d)/count (biased),  invstd = 1/sqrt(var + eps),
  *   scale = weight * invstd;  running_mean / running_var are updated in place with `momentum`

@@ -102,7 +102,7 @@ def segmentation_forward(x, P, n_heads, training, pooling_size=32):
     x_pl = deeplab_head(x_b, P, training, pooling_size=pooling_size)
     sem = torch.cat([F.conv2d(x_pl, P[f"cls.{i}.weight"], P[f"cls.{i}.bias"]) for i in range(n_heads)], dim=1)
     logits = F.interpolate(sem, size=x.shape[-2:], mode="bilinear", align_corners=False)
-    return logits, {"body": att_map(x_b), "pre_logits": att_map(x_pl), "sem": sem}
+    return logits, {"body": att_map(x_b), "pre_logits": att_map(x_pl), "sem": sem, "raw_body": x_b, "raw_pre_logits": x_pl}
 
 
 def init_new_classifier(P, n_heads, n_new):

@@ -1,0 +1,75 @@
+"""GPU diagnostic: forward activations and activation gradients of the product's fp32 student (train mode)
+vs the CPU oracle at the body / head / logits boundaries, plus the head's internal tensors."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from ucd_amd import argparser, synth
+from ucd_amd.run import build_models, load_step_checkpoint
+from oracle import step as OS, model as OM, losses as OL
+from oracle.params import template_state
+
+dev = torch.device("cuda:0")
+opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
+    ["--method", "UCD", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained"]))
+classes = [16, 5]
+model, model_old = build_models(opts, dev, classes)
+state = synth.fill_state_dict({k: v.cpu() for k, v in model_old.state_dict().items()}, 42)
+load_step_checkpoint(opts, model, model_old, state, dev)
+st = template_state(classes); st.update({k: v.clone() for k, v in state.items()})
+Ps = OS.make_params(st); OM.init_new_classifier(Ps, 2, 5)
+torch.set_num_threads(16)
+S = 129
+img = synth.images(501, 2, S); labels = synth.seg_labels(501, 2, S, S, range(16, 21))
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().double()
+    return (a - b).norm().item() / max(b.norm().item(), 1e-30)
+
+# ---- product with hooks
+acts = {}
+def keep(name):
+    def hook(mod, inp, out):
+        if torch.is_tensor(out) and out.requires_grad:
+            out.retain_grad()
+        acts[name] = out
+    return hook
+model.train()
+h = model.head
+for name, mod in [("body", model.body), ("map_bn", h.map_bn), ("red_conv", h.red_conv), ("gp_conv", h.global_pooling_conv),
+                  ("gp_bn", h.global_pooling_bn), ("pool_red_conv", h.pool_red_conv), ("red_bn", h.red_bn)]:
+    mod.register_forward_hook(keep(name))
+for i in (0, 1, 2, 3):
+    h.map_convs[i].register_forward_hook(keep(f"map_conv{i}"))
+logits, feats = model(img.to(dev))
+sem = feats["sem"]; sem.retain_grad()
+ce = OL.unbiased_cross_entropy(logits.float(), labels.to(dev), 16).mean()
+ce.backward()
+
+# ---- oracle, same loss
+x = img
+Pb = Ps
+xb = OM.resnet_body(x, Pb, True); xb.retain_grad()
+# head, spelled out to keep the intermediates
+dils = (6, 12, 18)
+br = [F.conv2d(xb, Pb["head.map_convs.0.weight"])] + [F.conv2d(xb, Pb[f"head.map_convs.{i}.weight"], padding=d, dilation=d) for i, d in enumerate(dils, 1)]
+for t in br: t.retain_grad()
+mb = OM.abn(torch.cat(br, 1), Pb, "head.map_bn", True); mb.retain_grad()
+rc = F.conv2d(mb, Pb["head.red_conv.weight"]); rc.retain_grad()
+pool0 = xb.reshape(xb.shape[0], xb.shape[1], -1).mean(-1)[:, :, None, None]
+gpc = F.conv2d(pool0, Pb["head.global_pooling_conv.weight"]); gpc.retain_grad()
+gpb = OM.abn(gpc, Pb, "head.global_pooling_bn", True); gpb.retain_grad()
+prc = F.conv2d(gpb, Pb["head.pool_red_conv.weight"]); prc.retain_grad()
+xpl = OM.abn(rc + prc.repeat(1, 1, xb.shape[2], xb.shape[3]), Pb, "head.red_bn", True); xpl.retain_grad()
+semr = torch.cat([F.conv2d(xpl, Pb[f"cls.{i}.weight"], Pb[f"cls.{i}.bias"]) for i in range(2)], 1); semr.retain_grad()
+lr = F.interpolate(semr, size=(S, S), mode="bilinear", align_corners=False)
+cer = OL.unbiased_cross_entropy(lr, labels, 16).mean()
+cer.backward()
+print("ce", ce.item(), cer.item())
+pairs = [("body", xb), ("map_conv0", br[0]), ("map_conv1", br[1]), ("map_conv3", br[3]), ("map_bn", mb), ("red_conv", rc),
+         ("gp_conv", gpc), ("gp_bn", gpb), ("pool_red_conv", prc), ("red_bn", xpl)]
+print("%-16s %12s %12s" % ("tensor", "fwd rel", "grad rel"))
+for name, ref in pairs:
+    a = acts[name]
+    g = rel(a.grad, ref.grad) if a.grad is not None and ref.grad is not None else float("nan")
+    print("%-16s %12.3e %12.3e   |grad| %.3e" % (name, rel(a, ref), g, ref.grad.norm().item() if ref.grad is not None else 0))
+print("%-16s %12.3e %12.3e" % ("sem", rel(sem, semr), rel(sem.grad, semr.grad)))

@@ -62,7 +62,7 @@ class _ABNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual, plane_bias, running_mean, running_var, training, momentum, eps,
-                act, slope, group, out, inplace):
+                act, slope, group, out, inplace, eval_cache=None):
         x_in = x
         x, M, Cc, HW, ld_x = hip.rows_view(x)
         dev = x.device
@@ -76,15 +76,22 @@ class _ABNFunction(torch.autograd.Function):
         sums, kshift, mean, invstd, scale = buf[:2 * Cc], buf[2 * Cc:3 * Cc], buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:]
         world = 1
         if training:
-            hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums, kshift)
             world = _group_size(group)
             if world > 1:
+                hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums, kshift)
                 _combine_stats_across_ranks(sums, kshift, M, Cc, world, group)
-            hip.abn_finalize(sums, kshift, float(M * world), Cc, weight, running_mean, running_var, momentum, eps, mean,
-                             invstd, scale)
+                hip.abn_finalize(sums, kshift, float(M * world), Cc, weight, running_mean, running_var, momentum, eps,
+                                 mean, invstd, scale)
+            else:
+                hip.abn_stats_finalize(x, ld_x, M, Cc, plane_bias, HW, sums, kshift, weight, running_mean, running_var,
+                                       momentum, eps, mean, invstd, scale)
         else:
             mean = running_mean
-            hip.abn_eval_params(weight, running_var, eps, Cc, invstd, scale)
+            if eval_cache is not None:      # frozen layer: invstd / scale computed once
+                invstd, scale = eval_cache[0], eval_cache[1]
+                buf = None
+            else:
+                hip.abn_eval_params(weight, running_var, eps, Cc, invstd, scale)
         count = float(M * world)
         if out is not None:
             y = out
@@ -98,6 +105,9 @@ class _ABNFunction(torch.autograd.Function):
             ld_y = Cc
         hip.abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, scale, bias, act, slope)
         needs_y = residual is not None and act != hip.ACT_IDENTITY
+        if buf is None:
+            buf = torch.cat((torch.empty(4 * Cc, dtype=torch.float32, device=dev), invstd, scale)) if ctx.needs_input_grad[0] \
+                else invstd
         ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, bias, buf, mean if not training else None)
         ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, residual is not None,
                    plane_bias is not None, x.shape[0])
@@ -133,7 +143,7 @@ class _ABNFunction(torch.autograd.Function):
             dpb = torch.empty(B, Cc, dtype=torch.float32, device=x.device)
             hip.plane_sum(dx, Cc, B, HW, Cc, 1.0, dpb)
             dpb = dpb.view(B, Cc, 1, 1)
-        return (dx, dweight, dbias, dz, dpb) + (None,) * 10
+        return (dx, dweight, dbias, dz, dpb) + (None,) * 11
 
 
 class _ABNBranchesFunction(torch.autograd.Function):
@@ -272,7 +282,21 @@ class ABN(nn.Module):
         inplace = self._inplace_contract and not torch.is_grad_enabled() and out is None
         return _ABNFunction.apply(x, self.weight, self.bias, residual, plane_bias, self.running_mean,
                                   self.running_var, self.training, self.momentum, self.eps, act, slope,
-                                  self._group(), out, inplace)
+                                  self._group(), out, inplace, None if self.training else self._eval_constants())
+
+    def _eval_constants(self):
+        """invstd / scale of the running statistics, cached until a parameter or buffer changes (the frozen
+        teacher never recomputes them)."""
+        key = (self.running_var._version, self.running_var.data_ptr(), self.eps,
+               None if self.weight is None else (self.weight._version, self.weight.data_ptr()))
+        cache = self.__dict__.get("_eval_cache")
+        if cache is None or cache[0] != key:
+            Cc = self.num_features
+            c = torch.empty(2, Cc, dtype=torch.float32, device=self.running_var.device)
+            hip.abn_eval_params(self.weight, self.running_var, self.eps, Cc, c[0], c[1])
+            cache = (key, c)
+            self.__dict__["_eval_cache"] = cache
+        return cache[1]
 
     def forward_branches(self, xs):
         """``self(torch.cat(xs, 1))`` without the concatenation."""

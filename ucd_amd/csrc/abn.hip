@@ -129,16 +129,48 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
   }
 }
 
-// Stage 2 of both reductions: sums[k] = sum over bands of partial[band][k], k in [0, 2C).
-// 16 outputs x 16 band-lanes per block, four independent loads in flight per thread (the loop is
-// latency-bound: a partial row is only 2C floats), fixed combination order (deterministic).
-__global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int n,
-                                                              float* __restrict__ sums) {
+// Stage 2 of both reductions: sums[c] / sums[C+c] = sum over bands of the two partial rows of channel c.
+// A block owns 8 channels (16 outputs) x 16 band-lanes, four independent loads in flight per thread (the
+// loop is latency-bound: a partial row is only 2C floats), fixed combination order (deterministic).
+// With FINALIZE the same block turns the two sums into the normalisation constants (one launch less per
+// layer than a separate finalize kernel).
+struct FinalizeArgs {
+  const float* kshift;
+  const float* weight;
+  float* running_mean;
+  float* running_var;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float count, momentum, eps;
+};
+
+__device__ __forceinline__ void finalize_channel(int c, float s, float ss, const FinalizeArgs& f) {
+  const float inv_n = 1.f / f.count;
+  const float d = s * inv_n;                       // mean - k
+  const float mean = (f.kshift ? f.kshift[c] : 0.f) + d;
+  const float var = fmaxf((ss - s * d) * inv_n, 0.f);
+  const float invstd = 1.f / sqrtf(var + f.eps);
+  if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+  if (f.running_var) {
+    const float unbiased = f.count > 1.f ? var * (f.count / (f.count - 1.f)) : var;
+    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+  }
+  f.mean[c] = mean;
+  f.invstd[c] = invstd;
+  f.scale[c] = (f.weight ? f.weight[c] : 1.f) * invstd;
+}
+
+template <bool FINALIZE>
+__global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int C,
+                                                              float* __restrict__ sums, FinalizeArgs fin) {
   __shared__ float lds[16][17];
   const int kl = threadIdx.x & 15, lane = threadIdx.x >> 4;
-  const int k = blockIdx.x * 16 + kl;
+  const int c = blockIdx.x * 8 + (kl & 7);
+  const int k = (kl < 8 ? 0 : C) + c;   // row index inside a [2C] partial
+  const int n = 2 * C;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (k < n) {
+  if (c < C) {
     int b = lane;
     for (; b + 48 < bands; b += 64) {
       s0 += partial[(size_t)b * n + k];
@@ -150,34 +182,23 @@ __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __res
   }
   lds[lane][kl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (lane == 0 && k < n) {
+  if (lane == 0 && c < C) {
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += lds[i][kl];
     sums[k] = t;
+    lds[0][kl] = t;
+  }
+  if (FINALIZE) {
+    __syncthreads();
+    if (lane == 0 && kl < 8 && c < C) finalize_channel(c, lds[0][kl], lds[0][kl + 8], fin);
   }
 }
 
-__global__ void abn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ kshift, float count, int C,
-                                    const float* __restrict__ weight,
-                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                    float momentum, float eps, float* __restrict__ mean_o,
-                                    float* __restrict__ invstd_o, float* __restrict__ scale_o) {
+__global__ void abn_finalize_kernel(const float* __restrict__ sums, int C, FinalizeArgs fin) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float inv_n = 1.f / count;
-  float d = sums[c] * inv_n;                       // mean - k
-  float mean = (kshift ? kshift[c] : 0.f) + d;
-  float var = fmaxf((sums[C + c] - sums[c] * d) * inv_n, 0.f);
-  float invstd = 1.f / sqrtf(var + eps);
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-  if (running_var) {
-    float unbiased = count > 1.f ? var * (count / (count - 1.f)) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
-  }
-  mean_o[c] = mean;
-  invstd_o[c] = invstd;
-  scale_o[c] = (weight ? weight[c] : 1.f) * invstd;
+  finalize_channel(c, sums[c], sums[C + c], fin);
 }
 
 __global__ void abn_eval_params_kernel(const float* __restrict__ weight, const float* __restrict__ rv, float eps, int C,
@@ -460,8 +481,9 @@ size_t ucd_abn_workspace_bytes(int M, int C) {
   return (size_t)kMaxBands * 2 * (size_t)C * sizeof(float);
 }
 
-int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW, float* sums,
-                  float* kshift, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+static int abn_stats_impl(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW, float* sums,
+                          float* kshift, void* workspace, size_t workspace_bytes, ucd_stream_t stream,
+                          const FinalizeArgs* fin) {
   static const char* fn = "ucd_abn_stats";
   UCD_TRY(check_common(fn, dtype, M, C, UCD_ACT_IDENTITY));
   UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
@@ -482,8 +504,25 @@ int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float*
         (const float*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial, kshift);
   }
   UCD_TRY(check_launch(fn));
-  reduce_bands_kernel<<<ceil_div(2 * C, 16), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
+  if (fin)
+    reduce_bands_kernel<true><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, *fin);
+  else
+    reduce_bands_kernel<false><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{});
   return check_launch(fn);
+}
+
+int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW, float* sums,
+                  float* kshift, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  return abn_stats_impl(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, workspace, workspace_bytes, stream, nullptr);
+}
+
+int ucd_abn_stats_finalize(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW,
+                           float* sums, float* kshift, const float* weight, float* running_mean, float* running_var,
+                           float momentum, float eps, float* mean, float* invstd, float* scale, void* workspace,
+                           size_t workspace_bytes, ucd_stream_t stream) {
+  UCD_REQUIRE(mean && invstd && scale && kshift, UCD_EINVAL, "ucd_abn_stats_finalize: NULL output");
+  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, (float)M, momentum, eps};
+  return abn_stats_impl(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, workspace, workspace_bytes, stream, &fin);
 }
 
 int ucd_abn_finalize(const float* sums, const float* kshift, float count, int C, const float* weight,
@@ -491,8 +530,8 @@ int ucd_abn_finalize(const float* sums, const float* kshift, float count, int C,
                      float* scale, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_finalize";
   UCD_REQUIRE(sums && mean && invstd && scale && C > 0 && count > 0.f, UCD_EINVAL, "%s: bad arguments", fn);
-  abn_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, kshift, count, C, weight, running_mean,
-                                                                        running_var, momentum, eps, mean, invstd, scale);
+  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, count, momentum, eps};
+  abn_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, C, fin);
   return check_launch(fn);
 }
 
@@ -565,7 +604,7 @@ int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const
   }
 #undef LAUNCH_RED
   UCD_TRY(check_launch(fn));
-  reduce_bands_kernel<<<ceil_div(2 * C, 16), kBlock, 0, s>>>(partial, g.gy, 2 * C, sums);
+  reduce_bands_kernel<false><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{});
   return check_launch(fn);
 }
 

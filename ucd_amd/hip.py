@@ -41,6 +41,7 @@ SIGNATURES = {
     "ucd_last_error": (C.c_char_p, []),
     "ucd_abn_workspace_bytes": (_z, [_i, _i]),
     "ucd_abn_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
+    "ucd_abn_stats_finalize": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _z, _p]),
     "ucd_abn_finalize": (_i, [_p, _p, _f, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p]),
     "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _p]),
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
@@ -211,6 +212,18 @@ def abn_stats(x, ld, M, Cc, plane_bias, HW, sums, kshift):
     with _timed("ucd_abn_stats", M * Cc * x.element_size()):
         _check(lib.ucd_abn_stats(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(kshift),
                                  ptr(ws), nbytes, stream()), "ucd_abn_stats")
+
+
+def abn_stats_finalize(x, ld, M, Cc, plane_bias, HW, sums, kshift, weight, running_mean, running_var, momentum, eps,
+                       mean, invstd, scale):
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    with _timed("ucd_abn_stats", M * Cc * x.element_size()):
+        _check(lib.ucd_abn_stats_finalize(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(kshift),
+                                          ptr(weight), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
+                                          ptr(mean), ptr(invstd), ptr(scale), ptr(ws), nbytes, stream()),
+               "ucd_abn_stats_finalize")
 
 
 def abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale):
