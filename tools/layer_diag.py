@@ -42,7 +42,7 @@ for i in (0, 1, 2, 3):
     h.map_convs[i].register_forward_hook(keep(f"map_conv{i}"))
 logits, feats = model(img.to(dev))
 sem = feats["sem"]; sem.retain_grad()
-ce = OL.unbiased_cross_entropy(logits.float(), labels.to(dev), 16).mean()
+ce = OL.unbiased_cross_entropy(logits.float().contiguous(), labels.to(dev), 16).mean()
 ce.backward()
 
 # ---- oracle, same loss
@@ -65,11 +65,12 @@ lr = F.interpolate(semr, size=(S, S), mode="bilinear", align_corners=False)
 cer = OL.unbiased_cross_entropy(lr, labels, 16).mean()
 cer.backward()
 print("ce", ce.item(), cer.item())
-pairs = [("body", xb), ("map_conv0", br[0]), ("map_conv1", br[1]), ("map_conv3", br[3]), ("map_bn", mb), ("red_conv", rc),
+pairs = [("body", xb), ("map_conv0", br[0]), ("map_conv1", br[1]), ("map_conv3", br[3]), ("red_conv", rc),
          ("gp_conv", gpc), ("gp_bn", gpb), ("pool_red_conv", prc), ("red_bn", xpl)]
 print("%-16s %12s %12s" % ("tensor", "fwd rel", "grad rel"))
-for name, ref in pairs:
+print("%-16s %12.3e %12.3e" % ("sem", rel(sem, semr), rel(sem.grad, semr.grad)))
+for name, ref in pairs[::-1]:
     a = acts[name]
     g = rel(a.grad, ref.grad) if a.grad is not None and ref.grad is not None else float("nan")
     print("%-16s %12.3e %12.3e   |grad| %.3e" % (name, rel(a, ref), g, ref.grad.norm().item() if ref.grad is not None else 0))
-print("%-16s %12.3e %12.3e" % ("sem", rel(sem, semr), rel(sem.grad, semr.grad)))
+
