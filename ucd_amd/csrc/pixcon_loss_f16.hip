@@ -61,21 +61,26 @@ __device__ __forceinline__ void load_anchor_frags(f16x8 (&a16)[16], const _Float
   }
 }
 
-__device__ __forceinline__ void tile_fetch(uint4 (&stage)[4], const _Float16* __restrict__ ch16, int j0) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = threadIdx.x + kThreads * q;  // 0..1023 x 16 B
-    const int row = idx >> 5, c = idx & 31;
-    stage[q] = *reinterpret_cast<const uint4*>(ch16 + (size_t)(j0 + row) * kN + c * 8);
-  }
+// 32 x 256 fp16 contrast tile = 1024 x 16 B: four 16-byte pieces per thread, kept in four named registers
+// (an indexed array ends up in scratch memory)
+struct Stage {
+  uint4 a, b, c, d;
+};
+__device__ __forceinline__ void tile_fetch(Stage& st, const _Float16* __restrict__ ch16, int j0) {
+  const int row = threadIdx.x >> 5, c = threadIdx.x & 31;   // piece q covers rows 8q + row
+  const _Float16* p = ch16 + (size_t)(j0 + row) * kN + c * 8;
+  st.a = *reinterpret_cast<const uint4*>(p);
+  st.b = *reinterpret_cast<const uint4*>(p + 8 * kN);
+  st.c = *reinterpret_cast<const uint4*>(p + 16 * kN);
+  st.d = *reinterpret_cast<const uint4*>(p + 24 * kN);
 }
-__device__ __forceinline__ void tile_commit(const uint4 (&stage)[4], _Float16* __restrict__ cs) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int idx = threadIdx.x + kThreads * q;
-    const int row = idx >> 5, c = idx & 31;
-    *reinterpret_cast<uint4*>(cs + row * kPitchH + c * 8) = stage[q];
-  }
+__device__ __forceinline__ void tile_commit(const Stage& st, _Float16* __restrict__ cs) {
+  const int row = threadIdx.x >> 5, c = threadIdx.x & 31;
+  _Float16* p = cs + row * kPitchH + c * 8;
+  *reinterpret_cast<uint4*>(p) = st.a;
+  *reinterpret_cast<uint4*>(p + 8 * kPitchH) = st.b;
+  *reinterpret_cast<uint4*>(p + 16 * kPitchH) = st.c;
+  *reinterpret_cast<uint4*>(p + 24 * kPitchH) = st.d;
 }
 
 __device__ __forceinline__ f32x16 gemm_scores(const _Float16* __restrict__ cs, const f16x8 (&a16)[16], int lane) {
@@ -125,6 +130,38 @@ __device__ __forceinline__ void store_values(const f32x16 (&acc)[8], float* __re
 }
 
 // ---- sweep 1 --------------------------------------------------------------------------------------------
+// Software pipeline over the contrast tiles of one split (t = tile index), three LDS buffers:
+//   block A:  x_next = S^T(tile t+1)   [16 MFMA + 16 ds_read_b128]   ||   s2 / masks / tile max of tile t  [VALU]
+//   (rare, wave-uniform) rescale when the running negative maximum jumps by more than 2^8
+//   block B:  E = exp2(s2 - m_run), row sums, fp16 pack [VALU]  ->  U^T += C_t^T . E   [16 MFMA + 32 tr reads]
+//   commit tile t+2 (fetched into registers at the top) to the third buffer; one barrier per tile.
+// The MFMAs of block A and the VALU work on the previous tile are independent, so the scheduler interleaves
+// them in one basic block.
+struct EpiA {
+  float tmax, mx_all;
+};
+
+template <bool PURE_NEG>
+__device__ __forceinline__ void epilogue_a(f32x16& x, const int* __restrict__ labs, int la, int half, float k2, float& tmax,
+                                           float& mx_all) {
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const float s2 = x[reg] * k2;
+    if (PURE_NEG) {  // every row of the tile is a valid negative for every anchor of this wave
+      mx_all = fmaxf(mx_all, s2);
+      tmax = fmaxf(tmax, s2);
+      x[reg] = s2;
+    } else {
+      const int lc = labs[tile_row(reg, half)];
+      const bool valid = lc != kPadLabel;
+      mx_all = valid ? fmaxf(mx_all, s2) : mx_all;
+      const float sn = (valid && lc != la) ? s2 : -INFINITY;
+      tmax = fmaxf(tmax, sn);
+      x[reg] = sn;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float16* __restrict__ ch16,
                                                                   const uint8_t* __restrict__ row_label,
                                                                   const ucd_pixcon_meta* __restrict__ meta, float k2,
@@ -132,8 +169,9 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
                                                                   float* __restrict__ mrunp, float* __restrict__ maxp,
                                                                   float* __restrict__ Up) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  _Float16* cs0 = reinterpret_cast<_Float16*>(smem_raw);                       // [2][32][kPitchH]
-  int* labs0 = reinterpret_cast<int*>(smem_raw + 2 * kTJ * kPitchH * 2);       // [2][32]
+  _Float16* cs0 = reinterpret_cast<_Float16*>(smem_raw);                       // [3][32][kPitchH]
+  int* labs0 = reinterpret_cast<int*>(smem_raw + 3 * kTJ * kPitchH * 2);       // [3][32 labels + min + max]
+  constexpr int kLabStride = kTJ + 4;
   const int A = meta->A, Cpad = meta->Cpad;
   const int i_base = blockIdx.x * kBI;
   if (i_base >= A) return;
@@ -142,9 +180,17 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
   const bool row_ok = i_row < A;
   const bool wave_ok = i_base + wave * kTI < A;
   const int la = row_ok ? row_label[i_row] : -1;
+  // label range of this wave's anchors (for the pure-negative fast path)
+  int w_lo = row_ok ? la : 255, w_hi = row_ok ? la : -1;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    w_lo = min(w_lo, __shfl_xor(w_lo, off, 64));
+    w_hi = max(w_hi, __shfl_xor(w_hi, off, 64));
+  }
   const int ntiles = Cpad / kTJ;
   const int per = (ntiles + nsplit - 1) / nsplit;
   const int v_begin = blockIdx.y * per, v_end = min(ntiles, v_begin + per);
+  const int nt_loc = v_end - v_begin;
 
   f16x8 a16[16];
   load_anchor_frags(a16, ch16, i_row, row_ok, half);
@@ -155,35 +201,54 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
     for (int r = 0; r < 16; ++r) U[nt][r] = 0.f;
   float neg = 0.f, m_run = -1e30f, mx_all = -INFINITY;
 
-  uint4 stage[4];
-  int cur = 0;
-  if (v_begin < v_end) {
+  auto commit_labels = [&](int buf, int tile) {
+    if (threadIdx.x < 64) {   // wave 0: 32 labels + their min / max over the valid rows
+      const int lc = threadIdx.x < kTJ ? (int)row_label[tile * kTJ + threadIdx.x] : kPadLabel;
+      int lo = lc, hi = lc == kPadLabel ? 256 : lc;   // a padding row forces the slow path (hi = 256)
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, 64));
+        hi = max(hi, __shfl_xor(hi, off, 64));
+      }
+      if (threadIdx.x < kTJ) labs0[buf * kLabStride + threadIdx.x] = lc;
+      if (threadIdx.x == 0) { labs0[buf * kLabStride + kTJ] = lo; labs0[buf * kLabStride + kTJ + 1] = hi; }
+    }
+  };
+
+  Stage stage;
+  if (nt_loc > 0) {
     tile_fetch(stage, ch16, v_begin * kTJ);
     tile_commit(stage, cs0);
-    if (threadIdx.x < kTJ) labs0[threadIdx.x] = row_label[v_begin * kTJ + threadIdx.x];
+    commit_labels(0, v_begin);
+  }
+  if (nt_loc > 1) {
+    tile_fetch(stage, ch16, (v_begin + 1) * kTJ);
+    tile_commit(stage, cs0 + kTJ * kPitchH);
+    commit_labels(1, v_begin + 1);
   }
   __syncthreads();
-  for (int v = v_begin; v < v_end; ++v) {
-    const bool has_next = v + 1 < v_end;
-    if (has_next) tile_fetch(stage, ch16, (v + 1) * kTJ);
-    const _Float16* cs = cs0 + cur * kTJ * kPitchH;
-    const int* labs = labs0 + cur * kTJ;
+  f32x16 x_cur;
+  if (nt_loc > 0 && wave_ok) x_cur = gemm_scores(cs0, a16, lane);
+  for (int t = 0; t < nt_loc; ++t) {
+    const int b_cur = t % 3, b_nxt = (t + 1) % 3, b_new = (t + 2) % 3;
+    const bool has_next = t + 1 < nt_loc;
+    // unconditional (clamped) prefetch two tiles ahead: no branch inside the pipelined body; past the end it
+    // re-fetches the last tile into a slot nobody reads again
+    const int t_new = min(v_begin + t + 2, v_end - 1);
+    tile_fetch(stage, ch16, t_new * kTJ);
+    const _Float16* cs = cs0 + b_cur * kTJ * kPitchH;
+    const int* labs = labs0 + b_cur * kLabStride;
     if (wave_ok) {
-      f32x16 x = gemm_scores(cs, a16, lane);
+      // ---- block A
+      f32x16 x_next;
+      if (has_next) x_next = gemm_scores(cs0 + b_nxt * kTJ * kPitchH, a16, lane);
       float tmax = -INFINITY;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int lc = labs[tile_row(reg, half)];
-        const float s2 = x[reg] * k2;
-        const bool valid = lc != kPadLabel;
-        mx_all = valid ? fmaxf(mx_all, s2) : mx_all;
-        const float sn = (valid && lc != la) ? s2 : -INFINITY;
-        tmax = fmaxf(tmax, sn);
-        x[reg] = sn;
-      }
+      const bool pure = labs[kTJ] > w_hi || labs[kTJ + 1] < w_lo;   // wave-uniform (LDS broadcast values)
+      if (pure) epilogue_a<true>(x_cur, labs, la, half, k2, tmax, mx_all);
+      else epilogue_a<false>(x_cur, labs, la, half, k2, tmax, mx_all);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float m_new = tmax > m_run + kRescaleTh ? tmax : m_run;
-      if (__any(m_new != m_run)) {   // wave-uniform branch; lanes that keep their maximum scale by 1
+      if (__any(m_new != m_run)) {   // rare: lanes that keep their maximum scale by 1
         const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
         neg *= sc;
 #pragma unroll
@@ -192,20 +257,19 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
           for (int r = 0; r < 16; ++r) U[nt][r] *= sc;
         m_run = m_new;
       }
+      // ---- block B
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const float e = __builtin_amdgcn_exp2f(x[reg] - m_run);   // exp2(-inf) = 0 for masked entries
+        const float e = __builtin_amdgcn_exp2f(x_cur[reg] - m_run);   // exp2(-inf) = 0 for masked entries
         neg += e;
-        x[reg] = e;
+        x_cur[reg] = e;
       }
-      gemm_values(U, cs, x, lane);
+      gemm_values(U, cs, x_cur, lane);
+      if (has_next) x_cur = x_next;
     }
-    if (has_next) {
-      tile_commit(stage, cs0 + (cur ^ 1) * kTJ * kPitchH);
-      if (threadIdx.x < kTJ) labs0[(cur ^ 1) * kTJ + threadIdx.x] = row_label[(v + 1) * kTJ + threadIdx.x];
-    }
+    tile_commit(stage, cs0 + b_new * kTJ * kPitchH);
+    commit_labels(b_new, t_new);
     __syncthreads();
-    cur ^= 1;
   }
   neg += __shfl_xor(neg, 32, 64);
   mx_all = fmaxf(mx_all, __shfl_xor(mx_all, 32, 64));
@@ -292,7 +356,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
     }
   };
 
-  uint4 stage[4];
+  Stage stage;
   int cur = 0;
   if (v_begin < v_end) {
     const int j0 = tl.at(v_begin) * kTJ;
@@ -456,8 +520,9 @@ int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float
     (void)hipGetLastError();
     attr_set = true;
   }
+  const size_t lds1n = (size_t)3 * kTJ * kPitchH * 2 + 3 * (kTJ + 4) * 4;
   const size_t lds1 = (size_t)2 * kTJ * kPitchH * 2 + 2 * kTJ * 4;
-  pixcon16_neg_kernel<<<dim3(nt_i, ns), kThreads, lds1, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
+  pixcon16_neg_kernel<<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
   int rc = check_launch(fn);
   if (rc) return rc;
   const size_t lds2 = lds1 + (size_t)2 * kTJ * (2 * KP16 + 8) * 2;
