@@ -141,43 +141,6 @@ struct EpiA {
   float tmax, mx_all;
 };
 
-// partial (fixed scale 2^-k2)  (+)=  accumulators (scale 2^-m_run per anchor); the first flush of a wave stores,
-// later ones read-modify-write (same wave, program order: deterministic)
-__device__ __forceinline__ void flush_partial(const f32x16 (&U)[8], float neg, float m_run, float k2, bool row_ok, int half,
-                                              bool first, float* __restrict__ negp_row, float* __restrict__ Up_row) {
-  const float sc = __builtin_amdgcn_exp2f(m_run - k2);   // m_run = -1e30 (nothing accumulated yet) -> 0
-  const float nsum = (neg + __shfl_xor(neg, 32, 64)) * sc;
-  if (!row_ok) return;
-  if (half == 0) negp_row[0] = first ? nsum : negp_row[0] + nsum;
-#pragma unroll
-  for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      float4* dst = reinterpret_cast<float4*>(Up_row + 32 * nt + 8 * g + 4 * half);
-      float4 v = {U[nt][4 * g + 0] * sc, U[nt][4 * g + 1] * sc, U[nt][4 * g + 2] * sc, U[nt][4 * g + 3] * sc};
-      if (!first) {
-        const float4 o = *dst;
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-      }
-      *dst = v;
-    }
-}
-
-// The accumulators are loop-carried values whose only in-loop consumer is the MFMA C operand; if a VALU
-// instruction reads them directly (here or after the loop) the compiler types the loop PHI as an arch-VGPR
-// value and copies all 128 registers out of the AGPR half at the top of EVERY iteration.  Reading them through
-// an "a"-constrained copy keeps the PHI in AGPRs and confines the AGPR->VGPR moves to this cold path.
-__device__ __forceinline__ void flush_pinned(const f32x16 (&U)[8], float neg, float m_run, float k2, bool row_ok, int half,
-                                             bool first, float* __restrict__ negp_row, float* __restrict__ Up_row) {
-  f32x16 Uc[8];
-#pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
-    Uc[nt] = U[nt];
-    asm volatile("" : "+a"(Uc[nt]));
-  }
-  flush_partial(Uc, neg, m_run, k2, row_ok, half, first, negp_row, Up_row);
-}
-
 template <bool PURE_NEG>
 __device__ __forceinline__ void epilogue_a(f32x16& x, const int* __restrict__ labs, int la, int half, float k2, float& tmax,
                                            float& mx_all) {
@@ -203,7 +166,8 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
                                                                   const uint8_t* __restrict__ row_label,
                                                                   const ucd_pixcon_meta* __restrict__ meta, float k2,
                                                                   int nsplit, int maxA, float* __restrict__ negp,
-                                                                  float* __restrict__ maxp, float* __restrict__ Up) {
+                                                                  float* __restrict__ mrunp, float* __restrict__ maxp,
+                                                                  float* __restrict__ Up) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   _Float16* cs0 = reinterpret_cast<_Float16*>(smem_raw);                       // [3][32][kPitchH]
   int* labs0 = reinterpret_cast<int*>(smem_raw + 3 * kTJ * kPitchH * 2);       // [3][32 labels + min + max]
@@ -236,9 +200,6 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
 #pragma unroll
     for (int r = 0; r < 16; ++r) U[nt][r] = 0.f;
   float neg = 0.f, m_run = -1e30f, mx_all = -INFINITY;
-  bool first_flush = true;
-  float* negp_row = negp + (size_t)blockIdx.y * maxA + (row_ok ? i_row : 0);
-  float* Up_row = Up + ((size_t)blockIdx.y * maxA + (row_ok ? i_row : 0)) * kN;
 
   auto commit_labels = [&](int buf, int tile) {
     if (threadIdx.x < 64) {   // wave 0: 32 labels + their min / max over the valid rows
@@ -267,7 +228,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
   }
   __syncthreads();
   f32x16 x_cur;
-  if (nt_loc > 0) x_cur = gemm_scores(cs0, a16, lane);
+  if (nt_loc > 0 && wave_ok) x_cur = gemm_scores(cs0, a16, lane);
   for (int t = 0; t < nt_loc; ++t) {
     const int b_cur = t % 3, b_nxt = (t + 1) % 3, b_new = (t + 2) % 3;
     const bool has_next = t + 1 < nt_loc;
@@ -277,35 +238,25 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
     tile_fetch(stage, ch16, t_new * kTJ);
     const _Float16* cs = cs0 + b_cur * kTJ * kPitchH;
     const int* labs = labs0 + b_cur * kLabStride;
-    {
-      // ---- block A: scores of the NEXT tile (MFMA) beside the mask / maximum pass over the CURRENT one (VALU).
-      // The score GEMM is issued inside both arms of the branch so that each arm is one basic block the
-      // scheduler can interleave; past the last tile it recomputes a tile whose result is dropped.
-      const _Float16* cs_n = cs0 + (has_next ? b_nxt : b_cur) * kTJ * kPitchH;
+    if (wave_ok) {
+      // ---- block A
       f32x16 x_next;
+      if (has_next) x_next = gemm_scores(cs0 + b_nxt * kTJ * kPitchH, a16, lane);
       float tmax = -INFINITY;
       // wave-uniform (LDS broadcast values); hi == 256 marks a tile with padding rows
       const bool pure = labs[kTJ + 1] < 256 && (labs[kTJ] > w_hi || labs[kTJ + 1] < w_lo);
-      if (pure) {
-        x_next = gemm_scores(cs_n, a16, lane);
-        epilogue_a<true>(x_cur, labs, la, half, k2, tmax, mx_all);
-      } else {
-        x_next = gemm_scores(cs_n, a16, lane);
-        epilogue_a<false>(x_cur, labs, la, half, k2, tmax, mx_all);
-      }
+      if (pure) epilogue_a<true>(x_cur, labs, la, half, k2, tmax, mx_all);
+      else epilogue_a<false>(x_cur, labs, la, half, k2, tmax, mx_all);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      if (__any(tmax > m_run + kRescaleTh)) {
-        // Rare: some anchor's negative maximum jumped by more than 2^8.  Instead of rescaling the 128
-        // accumulators in registers (VALU writes would drag them out of the AGPR half of the file for the
-        // whole loop), flush them to the global partial in the FIXED scale 2^-k2 and restart at the new scale.
-        flush_pinned(U, neg, m_run, k2, row_ok, half, first_flush, negp_row, Up_row);
-        first_flush = false;
-        neg = 0.f;
+      const float m_new = tmax > m_run + kRescaleTh ? tmax : m_run;
+      if (__any(m_new != m_run)) {   // rare: lanes that keep their maximum scale by 1
+        const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+        neg *= sc;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) U[nt][r] = 0.f;
-        m_run = fmaxf(m_run, tmax);
+          for (int r = 0; r < 16; ++r) U[nt][r] *= sc;
+        m_run = m_new;
       }
       // ---- block B
 #pragma unroll
@@ -315,15 +266,23 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
         x_cur[reg] = e;
       }
       gemm_values(U, cs, x_cur, lane);
-      x_cur = x_next;
+      if (has_next) x_cur = x_next;
     }
     tile_commit(stage, cs0 + b_new * kTJ * kPitchH);
     commit_labels(b_new, t_new);
     __syncthreads();
   }
-  flush_pinned(U, neg, m_run, k2, row_ok, half, first_flush, negp_row, Up_row);
+  neg += __shfl_xor(neg, 32, 64);
   mx_all = fmaxf(mx_all, __shfl_xor(mx_all, 32, 64));
-  if (row_ok && half == 0) maxp[(size_t)blockIdx.y * maxA + i_row] = mx_all;   // log2 domain
+  if (row_ok) {
+    if (half == 0) {
+      const size_t o = (size_t)blockIdx.y * maxA + i_row;
+      negp[o] = neg;       // in units of 2^m_run
+      mrunp[o] = m_run;    // log2 domain
+      maxp[o] = mx_all;    // log2 domain
+    }
+    store_values(U, Up + ((size_t)blockIdx.y * maxA + i_row) * kN, half);
+  }
 }
 
 // ---- sweep 2 --------------------------------------------------------------------------------------------
@@ -331,7 +290,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
 __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
     const _Float16* __restrict__ ch16, const uint8_t* __restrict__ row_label, const _Float16* __restrict__ p16, int KP16,
     const ucd_pixcon_meta* __restrict__ meta, float k2, int shift_pos, int use_prob, int nsplit1, int nsplit2, int maxA,
-    const float* __restrict__ negp, const float* __restrict__ maxp,
+    const float* __restrict__ negp, const float* __restrict__ mrunp, const float* __restrict__ maxp,
     float* __restrict__ lossp, float* __restrict__ qsump, float* __restrict__ Vp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ppitch = 2 * KP16 + 8;                                              // halfs per row: hi | lo | pad
@@ -362,15 +321,17 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
   const int per = (nv + nsplit2 - 1) / nsplit2;
   const int v_begin = blockIdx.y * per, v_end = min(nv, v_begin + per);
 
-  // row constants from sweep 1 (partials are in the fixed scale 2^-k2)
+  // row constants from sweep 1: combine the split partials at a common scale
   float neg_true = 0.f, m2 = -INFINITY;
   if (row_ok) {
+    float M = -1e30f;
+    for (int s = 0; s < nsplit1; ++s) M = fmaxf(M, mrunp[(size_t)s * maxA + i_row]);
     float acc = 0.f;
     for (int s = 0; s < nsplit1; ++s) {
-      acc += negp[(size_t)s * maxA + i_row];
+      acc += negp[(size_t)s * maxA + i_row] * exp2f(mrunp[(size_t)s * maxA + i_row] - M);
       m2 = fmaxf(m2, maxp[(size_t)s * maxA + i_row]);
     }
-    neg_true = acc * exp2f(k2);
+    neg_true = acc > 0.f ? acc * exp2f(M) : 0.f;
   }
   if (!shift_pos) m2 = 0.f;
 
@@ -469,7 +430,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
 // ---- combine ----------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void pixcon16_finalize_kernel(
     const uint8_t* __restrict__ row_label, const ucd_pixcon_meta* __restrict__ meta, float inv_T, int nsplit1, int nsplit2,
-    int maxA, const float* __restrict__ negp, float k2, const float* __restrict__ lossp,
+    int maxA, const float* __restrict__ negp, const float* __restrict__ mrunp, const float* __restrict__ lossp,
     const float* __restrict__ qsump, const float* __restrict__ Up, const float* __restrict__ Vp,
     float* __restrict__ grad_a, int ldg, float* __restrict__ row_stats, float* __restrict__ row_loss) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -478,22 +439,25 @@ __global__ __launch_bounds__(kThreads) void pixcon16_finalize_kernel(
   if (i >= A) return;
   const int num = meta->label_count_c[row_label[i]] - 1;
   const float R = (float)meta->n_valid;
-  float negs = 0.f, la = 0.f, qs = 0.f;   // negs (and U) in units of 2^k2: the scale cancels in U / neg
-  for (int s = 0; s < nsplit1; ++s) negs += negp[(size_t)s * maxA + i];
+  float M = -1e30f;
+  for (int s = 0; s < nsplit1; ++s) M = fmaxf(M, mrunp[(size_t)s * maxA + i]);
+  float negs = 0.f, la = 0.f, qs = 0.f;   // negs in units of 2^M
+  for (int s = 0; s < nsplit1; ++s) negs += negp[(size_t)s * maxA + i] * exp2f(mrunp[(size_t)s * maxA + i] - M);
   for (int s = 0; s < nsplit2; ++s) {
     la += lossp[(size_t)s * maxA + i];
     qs += qsump[(size_t)s * maxA + i];
   }
   const float coef = num > 0 ? inv_T / ((float)num * R) : 0.f;
-  const float ratio = negs > 0.f ? qs / negs : 0.f;
+  const float ratio = negs > 0.f ? qs / negs : 0.f;   // U is in the same 2^M units: the scale cancels
   const float rl = num > 0 ? -la / (float)num : 0.f;
   if (grad_a) {
     for (int c = lane * 4; c < ldg; c += 256) {
       float4 u = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
       if (c < kN) {
         for (int s = 0; s < nsplit1; ++s) {
+          const float w = exp2f(mrunp[(size_t)s * maxA + i] - M);
           const float4 t = *reinterpret_cast<const float4*>(Up + ((size_t)s * maxA + i) * kN + c);
-          u.x += t.x; u.y += t.y; u.z += t.z; u.w += t.w;
+          u.x += w * t.x; u.y += w * t.y; u.z += w * t.z; u.w += w * t.w;
         }
         for (int s = 0; s < nsplit2; ++s) {
           const float4 t = *reinterpret_cast<const float4*>(Vp + ((size_t)s * maxA + i) * kN + c);
@@ -508,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void pixcon16_finalize_kernel(
   if (lane == 0) {
     row_loss[i] = rl;
     if (row_stats) {
-      row_stats[i] = negs * exp2f(k2);
+      row_stats[i] = negs > 0.f ? negs * exp2f(M) : 0.f;
       row_stats[(size_t)maxA + i] = (float)num;
       row_stats[(size_t)2 * maxA + i] = rl;
     }
@@ -524,7 +488,7 @@ size_t pixcon16_workspace_bytes(int BHW) {
   if (ns > kMaxSplit) ns = kMaxSplit;
   if (ns < 1) ns = 1;
   const size_t rowvec = align_up((size_t)BHW * 4, 256);
-  return rowvec * ns * 4 + rowvec + (size_t)2 * ns * BHW * kN * 4;
+  return rowvec * ns * 5 + rowvec + (size_t)2 * ns * BHW * kN * 4;
 }
 
 int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float16* p16, int K,
@@ -540,6 +504,7 @@ int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float
   const size_t rowvec = align_up((size_t)BHW * 4, 256);
   char* ws = (char*)workspace;
   float* negp = (float*)ws; ws += rowvec * ns;
+  float* mrunp = (float*)ws; ws += rowvec * ns;
   float* maxp = (float*)ws; ws += rowvec * ns;
   float* lossp = (float*)ws; ws += rowvec * ns;
   float* qsump = (float*)ws; ws += rowvec * ns;
@@ -558,16 +523,16 @@ int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float
   }
   const size_t lds1n = (size_t)3 * kTJ * kPitchH * 2 + 3 * (kTJ + 4) * 4;
   const size_t lds1 = (size_t)2 * kTJ * kPitchH * 2 + 2 * kTJ * 4;
-  pixcon16_neg_kernel<<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, maxp, Up);
+  pixcon16_neg_kernel<<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
   int rc = check_launch(fn);
   if (rc) return rc;
   const size_t lds2 = lds1 + (size_t)2 * kTJ * (2 * KP16 + 8) * 2;
   pixcon16_pos_kernel<<<dim3(nt_i, ns), kThreads, lds2, s>>>(ch16, row_label, p16, KP16, meta, k2, shift_pos, use_prob, ns,
-                                                            ns, maxA, negp, maxp, lossp, qsump, Vp);
+                                                            ns, maxA, negp, mrunp, maxp, lossp, qsump, Vp);
   rc = check_launch(fn);
   if (rc) return rc;
   pixcon16_finalize_kernel<<<ceil_div(BHW, kThreads / 64), kThreads, 0, s>>>(row_label, meta, 1.f / temperature, ns, ns,
-                                                                             maxA, negp, k2, lossp, qsump, Up, Vp,
+                                                                             maxA, negp, mrunp, lossp, qsump, Up, Vp,
                                                                              grad_a, ldg, row_stats, rowloss);
   rc = check_launch(fn);
   if (rc) return rc;
