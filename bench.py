@@ -100,7 +100,7 @@ def cpu_baseline(args, classes):
     from oracle import step as OS
     from oracle.params import student_teacher_params
     from ucd_amd import synth, tasks
-    B = 2
+    B = 8
     # measured on the GPU box (tools/cpu_thread_probe.py): the oracle's convolutions are fastest at 16
     # threads (0.32 s teacher forward) and 7x slower at 128 - more threads only add contention
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -119,7 +119,7 @@ def cpu_baseline(args, classes):
         opt.step()
         dt = time.time() - t0
     return {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 full UCD step (teacher fwd + student fwd/bwd + CE + contrastive + KD + SGD), {B} images "
+            "sample": f"1 full UCD step after 1 warm-up step (teacher fwd + student fwd/bwd + CE + contrastive + KD + SGD), {B} images "
                       f"{args.crop}x{args.crop}, fp32 PyTorch-CPU oracle, {dt:.1f} s",
             "loss": float((r["loss"] + r["lkd"]).detach())}
 

@@ -55,8 +55,9 @@ def test_full_step_matches_reference_golden_fp32():
     names = [k.split("::")[1] for k in g if k.startswith("grad_abs::")]
     for n in names:
         assert params[n].grad.double().abs().sum().item() == pytest.approx(float(g[f"grad_abs::{n}"]), rel=0.1), n
+        # lr = 1e-3: a 5 % gradient difference moves a parameter by <= 5e-5 * |grad element|
         np.testing.assert_allclose(params[n].detach().flatten()[:16].cpu().numpy(), g[f"after_step::{n}"],
-                                   rtol=1e-3, atol=1e-5)
+                                   rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(model.body.mod1.bn1.running_mean.cpu().numpy(), g["running_mean_after"],
                                rtol=1e-4, atol=1e-6)
 

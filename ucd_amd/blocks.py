@@ -35,6 +35,29 @@ def try_index(scalar_or_list, i):
         return scalar_or_list
 
 
+class Conv1x1(nn.Conv2d):
+    """1x1 stride-1 convolution with the reference's parameter shape ([Cout, Cin, 1, 1]).  On the GPU, for
+    the wide layers of the network (mod4 / mod5 / ASPP at the stride-16 resolution), it runs as ONE plain
+    GEMM on the channels-last row matrix [B*H*W, Cin] x [Cin, Cout] (hipBLASLt) instead of an MIOpen
+    implicit-GEMM convolution: measured on MI355X (tools/gemm_vs_conv_probe.py, bf16, forward+backward,
+    B=24 at 33x33) 1.2x faster at 1024<->256, 1.5-1.7x at 2048<->512, 2.4x at 1024->2048; the narrow early
+    layers (<= 512 channels at 65x65 / 129x129) stay with MIOpen, which wins there."""
+
+    def __init__(self, in_channels, out_channels, bias=False):
+        super().__init__(in_channels, out_channels, 1, stride=1, padding=0, bias=bias)
+        self.as_gemm = min(in_channels, out_channels) >= 256 and max(in_channels, out_channels) >= 1024
+
+    def forward(self, x):
+        if not (self.as_gemm and x.is_cuda and x.dim() == 4):
+            return super().forward(x)
+        B, C, H, W = x.shape
+        rows = x.permute(0, 2, 3, 1)                      # a view of a channels-last tensor
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        y = F.linear(rows.reshape(B * H * W, C), self.weight.view(self.out_channels, C), self.bias)
+        return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
+
+
 def _is_fused_abn(m) -> bool:
     return getattr(m, "ucd_fused_abn", False)
 
@@ -65,6 +88,8 @@ class ResidualBlock(nn.Module):
             raise ValueError("groups > 1 are only valid if len(channels) == 3")
 
         def conv(cin, cout, k, s=1, g=1):
+            if k == 1 and s == 1 and g == 1:
+                return Conv1x1(cin, cout)
             pad = dilation if k == 3 else 0
             return nn.Conv2d(cin, cout, k, stride=s, padding=pad, dilation=dilation if k == 3 else 1,
                              groups=g, bias=False)
@@ -85,7 +110,8 @@ class ResidualBlock(nn.Module):
         self._last_bn = f"bn{len(spec)}"
 
         if stride != 1 or in_channels != channels[-1]:
-            self.proj_conv = nn.Conv2d(in_channels, channels[-1], 1, stride=stride, padding=0, bias=False)
+            self.proj_conv = (Conv1x1(in_channels, channels[-1]) if stride == 1 else
+                              nn.Conv2d(in_channels, channels[-1], 1, stride=stride, padding=0, bias=False))
             self.proj_bn = norm_act(channels[-1])
             self.proj_bn.activation = "identity"
 
@@ -126,7 +152,7 @@ class DeeplabV3(nn.Module):
             raise ValueError("out_stride must be 8 or 16")
         self.hidden_channels = hidden_channels
 
-        branches = [nn.Conv2d(in_channels, hidden_channels, 1, bias=False)]
+        branches = [Conv1x1(in_channels, hidden_channels)]
         branches += [nn.Conv2d(in_channels, hidden_channels, 3, bias=False, dilation=d, padding=d)
                      for d in dilations]
         self.map_convs = nn.ModuleList(branches)
@@ -135,7 +161,7 @@ class DeeplabV3(nn.Module):
         self.global_pooling_conv = nn.Conv2d(in_channels, hidden_channels, 1, bias=False)
         self.global_pooling_bn = norm_act(hidden_channels)
 
-        self.red_conv = nn.Conv2d(hidden_channels * len(branches), out_channels, 1, bias=False)
+        self.red_conv = Conv1x1(hidden_channels * len(branches), out_channels)
         self.pool_red_conv = nn.Conv2d(hidden_channels, out_channels, 1, bias=False)
         self.red_bn = norm_act(out_channels)
 

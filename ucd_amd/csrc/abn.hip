@@ -20,14 +20,14 @@ namespace ucd {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxBands = 256;  // row bands (= partial sums per channel) of the two-stage reductions
+constexpr int kMaxBands = 512;  // row bands (= partial sums per channel) of the two-stage reductions
 
 struct Geom {
   int TX, TY, gx, gy, rows_per_band;
 };
 
 template <int VEC>
-Geom make_geom(int M, int C, int target_blocks, int min_iters) {
+Geom make_geom(int M, int C, int target_blocks, int min_iters, int max_bands = 4096) {
   Geom g;
   int CG = C / VEC;
   g.TX = CG < 64 ? CG : 64;
@@ -36,7 +36,7 @@ Geom make_geom(int M, int C, int target_blocks, int min_iters) {
   int by_rows = M / (g.TY * min_iters);
   int gy = target_blocks / g.gx;
   if (gy > by_rows) gy = by_rows;
-  if (gy > kMaxBands) gy = kMaxBands;
+  if (gy > max_bands) gy = max_bands;
   if (gy < 1) gy = 1;
   g.rows_per_band = ceil_div(M, gy);
   g.gy = ceil_div(M, g.rows_per_band);
@@ -96,9 +96,7 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
         for (int i = 0; i < VEC; ++i) kshift[cg * VEC + i] = k[i];
       }
     }
-    for (int r = r_begin + ty; r < r_end; r += TY) {
-      Vec<T> v;
-      v.load(xp + (size_t)r * ld_x);
+    auto accumulate = [&](const Vec<T>& v, int r) {
       if (plane_bias) {
         const float* pb = plane_bias + (size_t)(r / HW) * C + cg * VEC;
 #pragma unroll
@@ -115,6 +113,25 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
           acc[VEC + i] += f * f;
         }
       }
+    };
+    int r = r_begin + ty;
+    // four independent 16-byte loads in flight per lane: with <= 512 row bands (2 blocks per CU) the loop
+    // is latency-bound otherwise
+    for (; r + 3 * TY < r_end; r += 4 * TY) {
+      Vec<T> v0, v1, v2, v3;
+      v0.load(xp + (size_t)r * ld_x);
+      v1.load(xp + (size_t)(r + TY) * ld_x);
+      v2.load(xp + (size_t)(r + 2 * TY) * ld_x);
+      v3.load(xp + (size_t)(r + 3 * TY) * ld_x);
+      accumulate(v0, r);
+      accumulate(v1, r + TY);
+      accumulate(v2, r + 2 * TY);
+      accumulate(v3, r + 3 * TY);
+    }
+    for (; r < r_end; r += TY) {
+      Vec<T> v;
+      v.load(xp + (size_t)r * ld_x);
+      accumulate(v, r);
     }
   }
   // idle tail threads (TX does not divide 256) carry zeros through the reduction: ty*TX+tx == threadIdx.x
@@ -276,11 +293,7 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
     const int r_begin = blockIdx.y * rows_per_band;
     const int r_end = min(M, r_begin + rows_per_band);
     const size_t coff = (size_t)cg * VEC;
-    for (int r = r_begin + ty; r < r_end; r += TY) {
-      Vec<T> v, g, yo;
-      v.load(x + (size_t)r * ld_x + coff);
-      g.load(dy + (size_t)r * ld_dy + coff);
-      if (yout) yo.load(yout + (size_t)r * ld_y + coff);
+    auto accumulate = [&](const Vec<T>& v, const Vec<T>& g, const Vec<T>& yo, int r) {
       const float* pb = plane_bias ? plane_bias + (size_t)(r / HW) * C + coff : nullptr;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
@@ -292,6 +305,27 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
         acc[i] += dz;
         acc[VEC + i] += dz * xh;
       }
+    };
+    int r = r_begin + ty;
+    for (; r + TY < r_end; r += 2 * TY) {   // two rows (4-6 independent loads) in flight per lane
+      Vec<T> v0, g0, y0, v1, g1, y1;
+      v0.load(x + (size_t)r * ld_x + coff);
+      g0.load(dy + (size_t)r * ld_dy + coff);
+      v1.load(x + (size_t)(r + TY) * ld_x + coff);
+      g1.load(dy + (size_t)(r + TY) * ld_dy + coff);
+      if (yout) {
+        y0.load(yout + (size_t)r * ld_y + coff);
+        y1.load(yout + (size_t)(r + TY) * ld_y + coff);
+      }
+      accumulate(v0, g0, y0, r);
+      accumulate(v1, g1, y1, r + TY);
+    }
+    for (; r < r_end; r += TY) {
+      Vec<T> v, g, yo;
+      v.load(x + (size_t)r * ld_x + coff);
+      g.load(dy + (size_t)r * ld_dy + coff);
+      if (yout) yo.load(yout + (size_t)r * ld_y + coff);
+      accumulate(v, g, yo, r);
     }
   }
   block_reduce_rows<2 * VEC>(acc, tx, ty, TX, TY, lds);
@@ -493,12 +527,12 @@ static int abn_stats_impl(const void* x, int ld_x, int dtype, int M, int C, cons
   float* partial = (float*)workspace;
   Geom g;
   if (dtype == UCD_BF16) {
-    g = make_geom<8>(M, C, 2048, 8);
+    g = make_geom<8>(M, C, 2048, 8, kMaxBands);
     UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
     abn_stats_kernel<__hip_bfloat16><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>(
         (const __hip_bfloat16*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial, kshift);
   } else {
-    g = make_geom<4>(M, C, 2048, 8);
+    g = make_geom<4>(M, C, 2048, 8, kMaxBands);
     UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
     abn_stats_kernel<float><<<dim3(g.gx, g.gy), kBlock, kBlock * 8 * 4, s>>>(
         (const float*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial, kshift);
@@ -589,7 +623,7 @@ int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const
   Geom g;
 #define LAUNCH_RED(T, VECN, ACT)                                                                                   \
   {                                                                                                                \
-    g = make_geom<VECN>(M, C, 2048, 8);                                                                            \
+    g = make_geom<VECN>(M, C, 2048, 8, kMaxBands);                                                                 \
     UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);       \
     abn_bwd_reduce_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, kBlock * 2 * VECN * 4, s>>>(                         \
         (const T*)x, ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, M, C, plane_bias, HW, mean, invstd, scale,     \

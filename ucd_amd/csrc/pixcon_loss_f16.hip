@@ -294,16 +294,15 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
     float* __restrict__ lossp, float* __restrict__ qsump, float* __restrict__ Vp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int ppitch = 2 * KP16 + 8;                                              // halfs per row: hi | lo | pad
-  _Float16* cs0 = reinterpret_cast<_Float16*>(smem_raw);                        // [2][32][kPitchH]
-  int* labs0 = reinterpret_cast<int*>(smem_raw + 2 * kTJ * kPitchH * 2);        // [2][32]
-  _Float16* ps0 = reinterpret_cast<_Float16*>(smem_raw + 2 * kTJ * kPitchH * 2 + 2 * kTJ * 4);  // [2][32][ppitch]
+  _Float16* cs0 = reinterpret_cast<_Float16*>(smem_raw);                        // [3][32][kPitchH]
+  int* labs0 = reinterpret_cast<int*>(smem_raw + 3 * kTJ * kPitchH * 2);        // [3][32]
+  _Float16* ps0 = reinterpret_cast<_Float16*>(smem_raw + 3 * kTJ * kPitchH * 2 + 3 * kTJ * 4);  // [3][32][ppitch]
   const int A = meta->A, Apad = meta->Apad, Cpad = meta->Cpad, min_new = meta->min_new;
   const int i_base = blockIdx.x * kBI;
   if (i_base >= A) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
   const int i_row = i_base + wave * kTI + (lane & 31);
   const bool row_ok = i_row < A;
-  const bool wave_ok = i_base + wave * kTI < A;
   const int la = row_ok ? row_label[i_row] : -1;
   const bool gt_i = la >= min_new;
 
@@ -357,40 +356,58 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
     }
   };
 
+  // P^T tile of contrast tile `buf`: pm[j][i] = sum_k pc[j][k] pa[i][k]  (hi/lo split: 3 MFMAs per 16 classes)
+  auto prob_tile = [&](int buf) {
+    f32x16 pm = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const _Float16* pc = ps0 + (buf * kTJ + (lane & 31)) * ppitch + 8 * half;
+    const _Float16* pa = p16 + (size_t)(row_ok ? i_row : 0) * 2 * KP16 + 8 * half;
+    for (int kk = 0; kk < nk; ++kk) {
+      const f16x8 ch = *reinterpret_cast<const f16x8*>(pc + 16 * kk);
+      const f16x8 cl = *reinterpret_cast<const f16x8*>(pc + KP16 + 16 * kk);
+      const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + 16 * kk);
+      const f16x8 al = *reinterpret_cast<const f16x8*>(pa + KP16 + 16 * kk);
+      pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, ah, pm, 0, 0, 0);
+      pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, al, pm, 0, 0, 0);
+      pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, ah, pm, 0, 0, 0);
+    }
+    return pm;
+  };
+
+  // three-buffer software pipeline (same schedule as sweep 1): scores / probabilities of tile t+1 are issued
+  // beside the epilogue of tile t; tile t+2 travels global -> registers -> LDS meanwhile
+  const int nt_loc = v_end - v_begin;
   Stage stage;
-  int cur = 0;
-  if (v_begin < v_end) {
+  if (nt_loc > 0) {
     const int j0 = tl.at(v_begin) * kTJ;
     tile_fetch(stage, ch16, j0);
     tile_commit(stage, cs0);
     commit_side(0, j0);
   }
+  if (nt_loc > 1) {
+    const int j0 = tl.at(v_begin + 1) * kTJ;
+    tile_fetch(stage, ch16, j0);
+    tile_commit(stage, cs0 + kTJ * kPitchH);
+    commit_side(1, j0);
+  }
   __syncthreads();
-  for (int v = v_begin; v < v_end; ++v) {
-    const bool has_next = v + 1 < v_end;
-    const int j0 = tl.at(v) * kTJ;
-    const int j0n = has_next ? tl.at(v + 1) * kTJ : 0;
-    if (has_next) tile_fetch(stage, ch16, j0n);
-    const _Float16* cs = cs0 + cur * kTJ * kPitchH;
-    const int* labs = labs0 + cur * kTJ;
-    if (wave_ok) {
-      f32x16 x = gemm_scores(cs, a16, lane);
-      f32x16 pm;
-      if (use_prob) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pm[r] = 0.f;
-        const _Float16* pc = ps0 + (cur * kTJ + (lane & 31)) * ppitch + 8 * half;
-        const _Float16* pa = p16 + (size_t)(row_ok ? i_row : 0) * 2 * KP16 + 8 * half;
-        for (int kk = 0; kk < nk; ++kk) {
-          const f16x8 ch = *reinterpret_cast<const f16x8*>(pc + 16 * kk);
-          const f16x8 cl = *reinterpret_cast<const f16x8*>(pc + KP16 + 16 * kk);
-          const f16x8 ah = *reinterpret_cast<const f16x8*>(pa + 16 * kk);
-          const f16x8 al = *reinterpret_cast<const f16x8*>(pa + KP16 + 16 * kk);
-          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, ah, pm, 0, 0, 0);
-          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, al, pm, 0, 0, 0);
-          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, ah, pm, 0, 0, 0);
-        }
-      }
+  f32x16 x_cur, pm_cur;
+  if (nt_loc > 0) {
+    x_cur = gemm_scores(cs0, a16, lane);
+    if (use_prob) pm_cur = prob_tile(0);
+  }
+  for (int t = 0; t < nt_loc; ++t) {
+    const int b_cur = t % 3, b_nxt = (t + 1) % 3, b_new = (t + 2) % 3;
+    const bool has_next = t + 1 < nt_loc;
+    const int j0 = tl.at(v_begin + t) * kTJ;
+    const int j0n = tl.at(min(v_begin + t + 2, v_end - 1)) * kTJ;
+    tile_fetch(stage, ch16, j0n);
+    const _Float16* cs = cs0 + b_cur * kTJ * kPitchH;
+    const int* labs = labs0 + b_cur * kTJ;
+    {
+      const int bn = has_next ? b_nxt : b_cur;
+      f32x16 x_next = gemm_scores(cs0 + bn * kTJ * kPitchH, a16, lane);
+      f32x16 pm_next;
+      if (use_prob) pm_next = prob_tile(bn);
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int jl = tile_row(reg, half);
@@ -398,23 +415,22 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
         const bool pos = row_ok && lc == la && (j0 + jl) != i_row;
         float q = 0.f;
         if (pos) {
-          const float pw = (use_prob && !(gt_i && lc >= min_new)) ? pm[reg] : 1.f;
-          const float sp2 = x[reg] * k2 - m2;
+          const float pw = (use_prob && !(gt_i && lc >= min_new)) ? pm_cur[reg] : 1.f;
+          const float sp2 = x_cur[reg] * k2 - m2;
           const float d = __builtin_amdgcn_exp2f(sp2) + neg_true;
           lossacc += pw * (sp2 * kLn2 - __logf(d));
           q = pw * (neg_true / d);
           qsum += q;
         }
-        x[reg] = q;
+        x_cur[reg] = q;
       }
-      gemm_values(V, cs, x, lane);
+      gemm_values(V, cs, x_cur, lane);
+      x_cur = x_next;
+      if (use_prob) pm_cur = pm_next;
     }
-    if (has_next) {
-      tile_commit(stage, cs0 + (cur ^ 1) * kTJ * kPitchH);
-      commit_side(cur ^ 1, j0n);
-    }
+    tile_commit(stage, cs0 + b_new * kTJ * kPitchH);
+    commit_side(b_new, j0n);
     __syncthreads();
-    cur ^= 1;
   }
   lossacc += __shfl_xor(lossacc, 32, 64);
   qsum += __shfl_xor(qsum, 32, 64);
@@ -522,11 +538,10 @@ int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float
     attr_set = true;
   }
   const size_t lds1n = (size_t)3 * kTJ * kPitchH * 2 + 3 * (kTJ + 4) * 4;
-  const size_t lds1 = (size_t)2 * kTJ * kPitchH * 2 + 2 * kTJ * 4;
   pixcon16_neg_kernel<<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
   int rc = check_launch(fn);
   if (rc) return rc;
-  const size_t lds2 = lds1 + (size_t)2 * kTJ * (2 * KP16 + 8) * 2;
+  const size_t lds2 = (size_t)3 * kTJ * kPitchH * 2 + 3 * kTJ * 4 + (size_t)3 * kTJ * (2 * KP16 + 8) * 2;
   pixcon16_pos_kernel<<<dim3(nt_i, ns), kThreads, lds2, s>>>(ch16, row_label, p16, KP16, meta, k2, shift_pos, use_prob, ns,
                                                             ns, maxA, negp, mrunp, maxp, lossp, qsump, Vp);
   rc = check_launch(fn);
