@@ -20,8 +20,8 @@ namespace ucd {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTileY = 16, kTileX = 64;
-constexpr int kMaxCells = 4 * 8;  // low-res rows x cols that a tile can touch (scale >= 8)
+constexpr int kTileY = 32, kTileX = 64;     // a thread walks kRows consecutive rows of one pixel column
+constexpr int kRows = kTileY / 4;
 
 __device__ __forceinline__ void up_src(int dst, int in_size, float scale, int& i0, int& i1, float& l0, float& l1) {
   float src = scale * ((float)dst + 0.5f) - 0.5f;
@@ -33,6 +33,10 @@ __device__ __forceinline__ void up_src(int dst, int in_size, float scale, int& i
 }
 
 // loss_part: [blocks][2] (ce sum, kd sum) ; d_sem accumulates ce_scale*dCE + kd_scale*dKD
+// CT > 0: Ctot <= CT and the per-class gradient of a thread's pixel column is accumulated in 2*CT registers
+// over consecutive rows that share the same low-res row pair (8x fewer LDS atomics); CT == 0: any Ctot,
+// four LDS atomics per pixel and class.
+template <int CT>
 __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
     const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
     int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
@@ -68,13 +72,36 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   float ce_sum = 0.f, kd_sum = 0.f;
   const int X = tx0 + (threadIdx.x & 63);
   const float invK = K > 0 ? 1.f / (float)K : 0.f;
-  for (int it = 0; it < kTileY / 4; ++it) {
-    const int Y = ty0 + (threadIdx.x >> 6) + 4 * it;
+  constexpr int CTA = CT > 0 ? CT : 1;
+  float acc0[CTA], acc1[CTA];          // sum over rows of ly0*g / ly1*g for the current low-res row pair
+  int cur_y0 = -1, cur_y1 = -1, x0 = 0, x1 = 0;
+  float lx0 = 0.f, lx1 = 0.f;
+  if (X < W) up_src(X, w, scale_w, x0, x1, lx0, lx1);
+  auto flush = [&]() {
+    if (CT > 0 && cur_y0 >= 0) {
+      const int r0 = (cur_y0 - ya) * nx, r1 = (cur_y1 - ya) * nx;
+#pragma unroll
+      for (int c = 0; c < CTA; ++c)
+        if (c < Ctot) {
+          atomicAdd(&g_acc[(r0 + x0 - xa) * Ctot + c], lx0 * acc0[c]);
+          atomicAdd(&g_acc[(r0 + x1 - xa) * Ctot + c], lx1 * acc0[c]);
+          atomicAdd(&g_acc[(r1 + x0 - xa) * Ctot + c], lx0 * acc1[c]);
+          atomicAdd(&g_acc[(r1 + x1 - xa) * Ctot + c], lx1 * acc1[c]);
+        }
+    }
+  };
+  for (int it = 0; it < kRows; ++it) {
+    const int Y = ty0 + (threadIdx.x >> 6) * kRows + it;
     if (X >= W || Y >= H) continue;
-    int y0, y1, x0, x1;
-    float ly0, ly1, lx0, lx1;
+    int y0, y1;
+    float ly0, ly1;
     up_src(Y, h, scale_h, y0, y1, ly0, ly1);
-    up_src(X, w, scale_w, x0, x1, lx0, lx1);
+    if (CT > 0 && (y0 != cur_y0 || y1 != cur_y1)) {
+      flush();
+      cur_y0 = y0; cur_y1 = y1;
+#pragma unroll
+      for (int c = 0; c < CTA; ++c) { acc0[c] = 0.f; acc1[c] = 0.f; }
+    }
     const int c00 = (y0 - ya) * nx + (x0 - xa), c01 = (y0 - ya) * nx + (x1 - xa);
     const int c10 = (y1 - ya) * nx + (x0 - xa), c11 = (y1 - ya) * nx + (x1 - xa);
     // torch's up-sampling arithmetic: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
@@ -113,8 +140,7 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
     }
     // pass C: gradients (and the old-class part of the KD loss)
     const float ce_w = ignored ? 0.f : ce_scale;
-    const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
-    for (int c = 0; c < Ctot; ++c) {
+    auto grad_c = [&](int c) {
       const float z = interp(s_log, Ctot, c);
       const float p = __expf(z - den);
       float g = ce_w * (p - (lab == 0 ? (c < K ? __expf(z - lse_old) : 0.f) : (c == lab ? 1.f : 0.f)));
@@ -127,13 +153,29 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
         const float bn = (c == 0 || c >= K) ? q0 * __expf(z - lse_bn) : 0.f;
         g += kd_scale * invK * (p - bn - qc);
       }
-      atomicAdd(&g_acc[c00 * Ctot + c], w00 * g);
-      atomicAdd(&g_acc[c01 * Ctot + c], w01 * g);
-      atomicAdd(&g_acc[c10 * Ctot + c], w10 * g);
-      atomicAdd(&g_acc[c11 * Ctot + c], w11 * g);
+      return g;
+    };
+    if (CT > 0) {
+#pragma unroll
+      for (int c = 0; c < CTA; ++c)
+        if (c < Ctot) {
+          const float g = grad_c(c);
+          acc0[c] += ly0 * g;
+          acc1[c] += ly1 * g;
+        }
+    } else {
+      const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
+      for (int c = 0; c < Ctot; ++c) {
+        const float g = grad_c(c);
+        atomicAdd(&g_acc[c00 * Ctot + c], w00 * g);
+        atomicAdd(&g_acc[c01 * Ctot + c], w01 * g);
+        atomicAdd(&g_acc[c10 * Ctot + c], w10 * g);
+        atomicAdd(&g_acc[c11 * Ctot + c], w11 * g);
+      }
     }
     kd_sum += -kd_pix * invK;
   }
+  flush();
   __syncthreads();
   for (int i = threadIdx.x; i < ncell * Ctot; i += kThreads) {
     const float v = g_acc[i];
@@ -201,7 +243,9 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t ea = hipFuncSetAttribute((const void*)seg_losses_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipError_t ea = hipFuncSetAttribute((const void*)seg_losses_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (ea == hipSuccess)
+      ea = hipFuncSetAttribute((const void*)seg_losses_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (ea != hipSuccess) { (void)hipGetLastError(); set_error("%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(ea)); return (int)ea; }
     attr_set = true;
   }
@@ -210,9 +254,14 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const float inv_pix = 1.f / ((float)B * H * W);
   float* part = (float*)workspace;
   // torch computes the up-sampling scale as float(in) / out
-  seg_losses_kernel<<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
-      sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
-      ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
+  if (Ctot <= 24)
+    seg_losses_kernel<24><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
+        sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
+        ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
+  else
+    seg_losses_kernel<0><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
+        sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
+        ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
   int rc = check_launch(fn);
   if (rc) return rc;
   seg_losses_reduce_kernel<<<1, 1024, 0, s>>>(part, B * tiles_x * tiles_y, inv_pix, loss_out);
