@@ -1,0 +1,38 @@
+"""Summarise a rocprofv3 --kernel-trace CSV of bench.py into a small per-kernel table of the LAST two steps
+(step boundaries = pixcon_reduce_kernel launches).  usage: trace_summary.py <kernel_trace.csv> <out.txt> [title]"""
+import collections, csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "pixcon_reduce_kernel" in r["Kernel_Name"]]
+a, b = idx[-3], idx[-1]
+win = rows[a:b]
+t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
+def short(n):
+    if "ucd" in n and ("N_1" in n or "ucd::" in n):
+        m = re.search(r"(pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|plane_sum_kernel|prep_\w+kernel|"
+                      r"gather_normalize_kernel|scatter_grad_kernel|seg_losses\w*kernel|attmap\w+)", n)
+        t = "<bf16>" if "bfloat16" in n else ("<f32>" if "<float" in n or "IfE" in n else "")
+        return "UCD   " + (m.group(1) if m else n[:60]) + t
+    if "at::native" in n:
+        m = re.search(r"at::native::(?:\(anonymous namespace\)::)?(\w+)", n)
+        m2 = re.findall(r"native::(\w+?)(?:_kernel_cuda|Functor|_kernel)", n)
+        return "ATEN  " + m.group(1) + " " + " ".join(m2[1:3]) + (" bf16" if "BFloat16" in n else "")
+    if n.startswith("igemm") or "ck::" in n or "Cijk" in n or "naive_conv" in n or "conv" in n.lower() or "gemm" in n.lower() or "SubTensorOp" in n:
+        return "CONV  " + re.sub(r"\(.*", "", n)[:70]
+    return "OTHER " + re.sub(r"\(.*", "", n)[:60]
+agg = collections.defaultdict(lambda: [0, 0])
+for r in win:
+    k = short(r["Kernel_Name"])
+    agg[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); agg[k][1] += 1
+grp = collections.defaultdict(float)
+for k, (d, c) in agg.items():
+    grp[k.split()[0]] += d / 2e6
+with open(sys.argv[2], "w") as f:
+    f.write("# %s\n" % (sys.argv[3] if len(sys.argv) > 3 else ""))
+    f.write("# last two timed steps: wall %.3f ms/step, sum of kernel durations %.3f ms/step, %d launches/step\n" %
+            ((t1 - t0) / 2e6, sum(v[0] for v in agg.values()) / 2e6, len(win) // 2))
+    f.write("# by group (ms/step): " + ", ".join("%s %.2f" % kv for kv in sorted(grp.items(), key=lambda kv: -kv[1])) + "\n")
+    f.write("%10s %10s %10s  %s\n" % ("ms/step", "calls/step", "avg_us", "kernel"))
+    for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+        f.write("%10.3f %10.1f %10.2f  %s\n" % (d / 2e6, c / 2, d / c / 1e3, k))
+print(open(sys.argv[2]).read()[:6000])

@@ -48,8 +48,9 @@ def _combine_stats_across_ranks(sums, kshift, M, Cc, world, group):
     kshift = global mean, sums = [0, global M2]."""
     d = sums[:Cc] / M
     pack = torch.cat((kshift + d, sums[Cc:] - sums[:Cc] * d))          # [mean_r | M2_r]
-    gathered = torch.empty(world, 2 * Cc, dtype=torch.float32, device=sums.device)
-    dist.all_gather_into_tensor(gathered, pack, group=group if group is not None else None)
+    flat = torch.empty(world * 2 * Cc, dtype=torch.float32, device=sums.device)
+    dist.all_gather_into_tensor(flat, pack, group=group if group is not None else None)
+    gathered = flat.view(world, 2 * Cc)
     mean_g = gathered[:, :Cc].mean(dim=0)
     m2 = gathered[:, Cc:].sum(dim=0) + M * ((gathered[:, :Cc] - mean_g) ** 2).sum(dim=0)
     kshift.copy_(mean_g)

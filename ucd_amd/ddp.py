@@ -30,8 +30,13 @@ class _Bucket:
 
 class GradReducer:
     def __init__(self, params, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True):
-        self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # gradient buckets get a communicator of their own: they are launched from autograd hooks on a side
+        # stream while InPlaceABNSync issues its statistics collectives on the compute stream - two independent
+        # orderings that must not share one RCCL communicator
+        if group is None and self.world > 1 and dist.get_backend() == "nccl":
+            group = dist.new_group(backend="nccl")
+        self.group = group
         self.wire_dtype = wire_dtype
         params = [p for p in params if p.requires_grad]
         self.params = params
