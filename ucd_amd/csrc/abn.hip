@@ -249,10 +249,8 @@ __global__ __launch_bounds__(kBlock) void abn_apply_kernel(const T* x, int ld_x,
   const int r_begin = blockIdx.y * rows_per_band;
   const int r_end = min(M, r_begin + rows_per_band);
   const size_t coff = (size_t)cg * VEC;
-  for (int r = r_begin + ty; r < r_end; r += TY) {
-    Vec<T> v, rv, o;
-    v.load(x + (size_t)r * ld_x + coff);
-    if (res) rv.load(res + (size_t)r * ld_r + coff);
+  auto emit = [&](const Vec<T>& v, const Vec<T>& rv, int r) {
+    Vec<T> o;
     const float* pb = plane_bias ? plane_bias + (size_t)(r / HW) * C + coff : nullptr;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -263,6 +261,32 @@ __global__ __launch_bounds__(kBlock) void abn_apply_kernel(const T* x, int ld_x,
       o.set(i, act_fwd<ACT>(z, slope));
     }
     o.store(y + (size_t)r * ld_y + coff);
+  };
+  int r = r_begin + ty;
+  // four rows (4-8 independent 16-byte loads) in flight per lane: the small stride-16 layers are a handful
+  // of rows per thread, so a one-row-at-a-time loop is a chain of exposed HBM round trips
+  for (; r + 3 * TY < r_end; r += 4 * TY) {
+    Vec<T> v0, v1, v2, v3, q0, q1, q2, q3;
+    v0.load(x + (size_t)r * ld_x + coff);
+    v1.load(x + (size_t)(r + TY) * ld_x + coff);
+    v2.load(x + (size_t)(r + 2 * TY) * ld_x + coff);
+    v3.load(x + (size_t)(r + 3 * TY) * ld_x + coff);
+    if (res) {
+      q0.load(res + (size_t)r * ld_r + coff);
+      q1.load(res + (size_t)(r + TY) * ld_r + coff);
+      q2.load(res + (size_t)(r + 2 * TY) * ld_r + coff);
+      q3.load(res + (size_t)(r + 3 * TY) * ld_r + coff);
+    }
+    emit(v0, q0, r);
+    emit(v1, q1, r + TY);
+    emit(v2, q2, r + 2 * TY);
+    emit(v3, q3, r + 3 * TY);
+  }
+  for (; r < r_end; r += TY) {
+    Vec<T> v, q;
+    v.load(x + (size_t)r * ld_x + coff);
+    if (res) q.load(res + (size_t)r * ld_r + coff);
+    emit(v, q, r);
   }
 }
 
@@ -307,18 +331,26 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
       }
     };
     int r = r_begin + ty;
-    for (; r + TY < r_end; r += 2 * TY) {   // two rows (4-6 independent loads) in flight per lane
-      Vec<T> v0, g0, y0, v1, g1, y1;
+    for (; r + 3 * TY < r_end; r += 4 * TY) {   // four rows (8-12 independent loads) in flight per lane
+      Vec<T> v0, g0, y0, v1, g1, y1, v2, g2, y2, v3, g3, y3;
       v0.load(x + (size_t)r * ld_x + coff);
       g0.load(dy + (size_t)r * ld_dy + coff);
       v1.load(x + (size_t)(r + TY) * ld_x + coff);
       g1.load(dy + (size_t)(r + TY) * ld_dy + coff);
+      v2.load(x + (size_t)(r + 2 * TY) * ld_x + coff);
+      g2.load(dy + (size_t)(r + 2 * TY) * ld_dy + coff);
+      v3.load(x + (size_t)(r + 3 * TY) * ld_x + coff);
+      g3.load(dy + (size_t)(r + 3 * TY) * ld_dy + coff);
       if (yout) {
         y0.load(yout + (size_t)r * ld_y + coff);
         y1.load(yout + (size_t)(r + TY) * ld_y + coff);
+        y2.load(yout + (size_t)(r + 2 * TY) * ld_y + coff);
+        y3.load(yout + (size_t)(r + 3 * TY) * ld_y + coff);
       }
       accumulate(v0, g0, y0, r);
       accumulate(v1, g1, y1, r + TY);
+      accumulate(v2, g2, y2, r + 2 * TY);
+      accumulate(v3, g3, y3, r + 3 * TY);
     }
     for (; r < r_end; r += TY) {
       Vec<T> v, g, yo;
@@ -371,11 +403,8 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
   const int r_begin = blockIdx.y * rows_per_band;
   const int r_end = min(M, r_begin + rows_per_band);
   const size_t coff = (size_t)cg * VEC;
-  for (int r = r_begin + ty; r < r_end; r += TY) {
-    Vec<T> v, g, yo, o, oz;
-    v.load(x + (size_t)r * ld_x + coff);
-    g.load(dy + (size_t)r * ld_dy + coff);
-    if (yout) yo.load(yout + (size_t)r * ld_y + coff);
+  auto emit = [&](const Vec<T>& v, const Vec<T>& g, const Vec<T>& yo, int r) {
+    Vec<T> o, oz;
     const float* pb = plane_bias ? plane_bias + (size_t)(r / HW) * C + coff : nullptr;
 #pragma unroll
     for (int i = 0; i < VEC; ++i) {
@@ -389,6 +418,35 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
     }
     o.store(dx + (size_t)r * ld_dx + coff);
     if (dz_out) oz.store(dz_out + (size_t)r * ld_dz + coff);
+  };
+  int r = r_begin + ty;
+  for (; r + 3 * TY < r_end; r += 4 * TY) {   // four rows (8-12 independent loads) in flight per lane
+    Vec<T> v0, v1, v2, v3, g0, g1, g2, g3, y0, y1, y2, y3;
+    v0.load(x + (size_t)r * ld_x + coff);
+    g0.load(dy + (size_t)r * ld_dy + coff);
+    v1.load(x + (size_t)(r + TY) * ld_x + coff);
+    g1.load(dy + (size_t)(r + TY) * ld_dy + coff);
+    v2.load(x + (size_t)(r + 2 * TY) * ld_x + coff);
+    g2.load(dy + (size_t)(r + 2 * TY) * ld_dy + coff);
+    v3.load(x + (size_t)(r + 3 * TY) * ld_x + coff);
+    g3.load(dy + (size_t)(r + 3 * TY) * ld_dy + coff);
+    if (yout) {
+      y0.load(yout + (size_t)r * ld_y + coff);
+      y1.load(yout + (size_t)(r + TY) * ld_y + coff);
+      y2.load(yout + (size_t)(r + 2 * TY) * ld_y + coff);
+      y3.load(yout + (size_t)(r + 3 * TY) * ld_y + coff);
+    }
+    emit(v0, g0, y0, r);
+    emit(v1, g1, y1, r + TY);
+    emit(v2, g2, y2, r + 2 * TY);
+    emit(v3, g3, y3, r + 3 * TY);
+  }
+  for (; r < r_end; r += TY) {
+    Vec<T> v, g, yo;
+    v.load(x + (size_t)r * ld_x + coff);
+    g.load(dy + (size_t)r * ld_dy + coff);
+    if (yout) yo.load(yout + (size_t)r * ld_y + coff);
+    emit(v, g, yo, r);
   }
 }
 
