@@ -48,7 +48,9 @@ class Conv1x1(nn.Conv2d):
         self.as_gemm = min(in_channels, out_channels) >= 256 and max(in_channels, out_channels) >= 1024
 
     def forward(self, x):
-        if not (self.as_gemm and x.is_cuda and x.dim() == 4):
+        # bf16 activations only: in the fp32 parity mode (--opt_level O0) every convolution stays on one code
+        # path (MIOpen), which is what the 1e-3 logit comparison with the reference was validated on
+        if not (self.as_gemm and x.is_cuda and x.dim() == 4 and (x.dtype != torch.float32 or torch.is_autocast_enabled())):
             return super().forward(x)
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1)                      # a view of a channels-last tensor
