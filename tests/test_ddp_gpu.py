@@ -1,0 +1,89 @@
+"""GPU, two processes on ONE device (gloo transports CUDA tensors; RCCL refuses two ranks per GPU): the
+multi-rank code paths - InPlaceABNSync statistics exchange (forward all-gather + backward all-reduce), bucketed
+gradient averaging on the side stream, rank-sharded batch - give the gradients of the single-process step on
+the concatenated batch.  The contrastive term is rank-local by design (the reference gathers no features,
+SURVEY.md section 8-e), so it is switched off for the equality check and exercised separately."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ucd_amd import argparser, synth, tasks
+from ucd_amd.ddp import DistributedDataParallel
+from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+from ucd_amd.train import Trainer
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+classes = [16, 5]
+def build(norm):
+    o = argparser.modify_command_options(argparser.get_argparser().parse_args(
+        ["--method", "UCD", "--task", "15-5", "--step", "1", "--lr", "0.0", "--no_pretrained", "--norm_act", norm]))
+    o.pixcon_weight = float(os.environ.get("PIXW", "0"))
+    m, mo = build_models(o, dev, classes)
+    st = synth.fill_state_dict({k: v.cpu() for k, v in mo.state_dict().items()}, 42)
+    load_step_checkpoint(o, m, mo, st, dev)
+    return o, m, mo
+B, S = 4, 97
+img = synth.images(900, B, S); lab = synth.seg_labels(900, B, S, S, range(16, 21))
+# 2-rank run: sync ABN + DDP, each rank its interleaved shard
+o, m, mo = build("iabn_sync")
+ddp = DistributedDataParallel(m, bucket_mb=4.0)
+tr = Trainer(ddp, mo, device=dev, opts=o, classes=classes)
+opt = make_optimizer(o, ddp)
+ddp.train()
+r = tr.train_step(img[rank::world], lab[rank::world], opt, None)
+torch.cuda.synchronize()
+grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+rm = m.body.mod1.bn1.running_mean.clone()
+if float(os.environ.get("PIXW", "0")) != 0:
+    assert torch.isfinite(r["con"]).item() and r["con"].item() > 0
+    print("DDP_GPU_OK", rank); dist.destroy_process_group(); sys.exit(0)
+# single-process reference on the whole batch (plain in-place ABN, no wrapper)
+o2, m2, mo2 = build("iabn")
+tr2 = Trainer(m2, mo2, device=dev, opts=o2, classes=classes)
+opt2 = make_optimizer(o2, m2)
+m2.train()
+r2 = tr2.train_step(torch.cat([img[k::world] for k in range(world)]), torch.cat([lab[k::world] for k in range(world)]), opt2, None)
+torch.cuda.synchronize()
+ce = r["ce"].clone(); dist.all_reduce(ce); ce /= world
+assert abs(ce.item() - r2["ce"].item()) / r2["ce"].item() < 1e-4, (ce.item(), r2["ce"].item())
+worst = 0.0
+for n, p in m2.named_parameters():
+    if p.grad is None: continue
+    g, gr = grads[n].double(), p.grad.double()
+    rel = (g - gr).norm().item() / max(gr.norm().item(), 1e-20)
+    worst = max(worst, rel)
+    assert rel < 2e-2, (n, rel)
+assert torch.allclose(rm, m2.body.mod1.bn1.running_mean, rtol=1e-4, atol=1e-6)
+print("DDP_GPU_OK", rank, "worst grad rel err %.2e" % worst)
+dist.destroy_process_group()
+"""
+
+
+def _run(tmp_path, pixw, port):
+    script = tmp_path / "ddp_gpu_worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PIXW=str(pixw), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("DDP_GPU_OK") == 2, r.stdout[-2000:]
+    return r.stdout
+
+
+def test_two_ranks_equal_single_process(tmp_path):
+    out = _run(tmp_path, 0, 29721)
+    print(out[-300:])
+
+
+def test_two_ranks_with_rank_local_contrastive(tmp_path):
+    _run(tmp_path, 0.01, 29722)

@@ -37,6 +37,7 @@ class GradReducer:
         if group is None and self.world > 1 and dist.get_backend() == "nccl":
             group = dist.new_group(backend="nccl")
         self.group = group
+        self.use_avg = self.world > 1 and dist.get_backend(group) == "nccl"   # RCCL reduces with AVG; gloo sums
         self.wire_dtype = wire_dtype
         params = [p for p in params if p.requires_grad]
         self.params = params
@@ -106,9 +107,9 @@ class GradReducer:
         if self.wire_dtype is not None and self.wire_dtype != buf.dtype:
             b.wire = buf.to(self.wire_dtype)
             buf = b.wire
-        if self.on_gpu:
+        if self.use_avg:
             b.work = dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        else:                                                   # gloo (CPU tests): no AVG
+        else:                                                   # gloo (tests): no AVG
             b.work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
@@ -124,11 +125,13 @@ class GradReducer:
                     b.work.wait()
                     if b.wire is not None:
                         b.flat.copy_(b.wire)
+                    if not self.use_avg:
+                        b.flat.div_(self.world)
             else:
                 b.work.wait()
                 if b.wire is not None:
                     b.flat.copy_(b.wire)
-                if not self.on_gpu:
+                if not self.use_avg:
                     b.flat.div_(self.world)
             b.work = b.wire = None
         if self.overlap:

@@ -51,6 +51,7 @@ class Trainer:
         if getattr(opts, "regularizer", None) is not None:
             raise NotImplementedError("EWC / RW / PI regularisers are outside the UCD hot path")
         self.temperature = opts.temperature
+        self.pixcon_weight = getattr(opts, "pixcon_weight", 0.01)      # the reference hard-codes /100 (train.py:116)
         # the reference clamps down-sampled labels at the VOC bound 20 (utils/utils.py:267-268); datasets
         # with more classes need the real bound
         self.max_label = max(20, self.tot_classes - 1)
@@ -114,17 +115,17 @@ class Trainer:
         else:
             ce = self.criterion(outputs.float() if outputs.dtype != torch.float32 else outputs, labels).mean()
         con = zero
-        if model_old is not None:
+        if model_old is not None and self.pixcon_weight != 0:
             con = ucd_contrastive_loss(_raw(features, "pre_logits"), labels, features_old["sem"],
                                        _raw(features_old, "pre_logits"), self.temperature, self.max_label,
                                        self.pixcon_precision)
-        loss = ce + con / 100                                                     # train.py:116
+        loss = ce + con * self.pixcon_weight                                      # train.py:116 (/100)
         if self.lde_flag:
             lde = self.lde * (self.lde_loss(features["body"].float(), features_old["body"].float())
                               + self.lde_loss(features["pre_logits"].float(), features_old["pre_logits"].float()))
         if self.lkd_flag:
             lkd = self.lkd * (kd if fuse else self.lkd_loss(outputs, outputs_old))   # train.py:131-133
-        loss_tot = (total + con / 100 + lde) if fuse else (loss + lkd + lde)
+        loss_tot = (total + con * self.pixcon_weight + lde) if fuse else (loss + lkd + lde)
         loss_tot.backward()
         if hasattr(model, "finish_grad_sync"):
             model.finish_grad_sync()
