@@ -120,6 +120,24 @@ int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const 
                       const float* weight, const float* sums, float count, int frozen,
                       int act, float slope, ucd_stream_t stream);
 
+/* Whole-layer forward in one call (single process): training != 0 -> ucd_abn_stats_finalize + ucd_abn_apply with
+ * buf = [sums(2C) | kshift(C) | mean(C) | invstd(C) | scale(C)] (kept for the backward); training == 0 ->
+ * running statistics, with [invstd | scale] taken from eval_consts when given (frozen teacher) or computed into buf. */
+int ucd_abn_forward(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r,
+                    int dtype, int M, int C, const float* plane_bias, int HW,
+                    const float* weight, const float* bias, float* running_mean, float* running_var,
+                    float momentum, float eps, int training, float* buf, const float* eval_consts,
+                    int act, float slope, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* Whole-layer backward in one call: ucd_abn_bwd_reduce (when training or need_sums) + ucd_abn_bwd_apply.
+ * sums[0:C] = d bias, sums[C:2C] = d weight on return. */
+int ucd_abn_backward(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
+                     void* dx, int ld_dx, void* dz_out, int ld_dz, int dtype, int M, int C,
+                     const float* plane_bias, int HW, const float* mean, const float* invstd,
+                     const float* scale, const float* bias, const float* weight, float* sums, float count,
+                     int training, int need_sums, int act, float slope,
+                     void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
 /* Per-(image, channel) reduction over the HW rows of each image: out[b, c] = alpha * sum_hw x.
  * Global average pooling of the ASPP image-level branch (modules/deeplab.py:72-76) with alpha = 1/HW,
  * and the gradient of a plane_bias (sum of dz over the plane) with alpha = 1. */

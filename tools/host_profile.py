@@ -1,0 +1,19 @@
+"""Host-side profile of the train step at a small per-rank batch (the 8-GPU regime): where does Python time go?"""
+import cProfile, pstats, sys, os, io, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+sys.argv = ["bench.py", "--global_batch", "3"]
+args = bench.parse()
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+torch.backends.cudnn.benchmark = True
+trainer, optimizer, scheduler, images, labels, classes = bench.build(args, dev, 3, 0)
+for _ in range(5): trainer.train_step(images, labels, optimizer, scheduler)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10): trainer.train_step(images, labels, optimizer, scheduler)
+torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) * 100)
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5): trainer.train_step(images, labels, optimizer, scheduler)
+torch.cuda.synchronize(); pr.disable()
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])

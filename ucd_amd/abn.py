@@ -72,27 +72,7 @@ class _ABNFunction(torch.autograd.Function):
             residual, _, _, _, ld_r = hip.rows_view(residual)
         if plane_bias is not None:
             plane_bias = plane_bias.reshape(x.shape[0], Cc).float().contiguous()
-        # [sums(2C) | kshift | mean | invstd | scale]
-        buf = torch.empty(6 * Cc, dtype=torch.float32, device=dev)
-        sums, kshift, mean, invstd, scale = buf[:2 * Cc], buf[2 * Cc:3 * Cc], buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:]
-        world = 1
-        if training:
-            world = _group_size(group)
-            if world > 1:
-                hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums, kshift)
-                _combine_stats_across_ranks(sums, kshift, M, Cc, world, group)
-                hip.abn_finalize(sums, kshift, float(M * world), Cc, weight, running_mean, running_var, momentum, eps,
-                                 mean, invstd, scale)
-            else:
-                hip.abn_stats_finalize(x, ld_x, M, Cc, plane_bias, HW, sums, kshift, weight, running_mean, running_var,
-                                       momentum, eps, mean, invstd, scale)
-        else:
-            mean = running_mean
-            if eval_cache is not None:      # frozen layer: invstd / scale computed once
-                invstd, scale = eval_cache[0], eval_cache[1]
-                buf = None
-            else:
-                hip.abn_eval_params(weight, running_var, eps, Cc, invstd, scale)
+        world = _group_size(group) if training else 1
         count = float(M * world)
         if out is not None:
             y = out
@@ -104,12 +84,25 @@ class _ABNFunction(torch.autograd.Function):
         else:
             y = hip.empty_like_rows(x)
             ld_y = Cc
-        hip.abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, scale, bias, act, slope)
+        # [sums(2C) | kshift | mean | invstd | scale]
+        use_cache = not training and eval_cache is not None
+        buf = None if use_cache else torch.empty(6 * Cc, dtype=torch.float32, device=dev)
+        if world == 1:
+            # one library call: statistics + finalize + apply (training) or running-statistics apply (eval)
+            hip.abn_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean,
+                            running_var, momentum, eps, training, buf, eval_cache if use_cache else None, act, slope)
+        else:
+            sums, kshift, mean, invstd, scale = buf[:2 * Cc], buf[2 * Cc:3 * Cc], buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:]
+            hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums, kshift)
+            _combine_stats_across_ranks(sums, kshift, M, Cc, world, group)
+            hip.abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale)
+            hip.abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, scale, bias, act, slope)
+        if use_cache:   # the backward (if any) reads invstd / scale from the same [.. | invstd | scale] layout
+            buf = torch.cat((torch.empty(4 * Cc, dtype=torch.float32, device=dev), eval_cache.reshape(-1))) \
+                if ctx.needs_input_grad[0] else eval_cache
+        mean = running_mean if not training else None
         needs_y = residual is not None and act != hip.ACT_IDENTITY
-        if buf is None:
-            buf = torch.cat((torch.empty(4 * Cc, dtype=torch.float32, device=dev), invstd, scale)) if ctx.needs_input_grad[0] \
-                else invstd
-        ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, bias, buf, mean if not training else None)
+        ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, bias, buf, mean)
         ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, residual is not None,
                    plane_bias is not None, x.shape[0])
         if y is x_in:
@@ -125,19 +118,24 @@ class _ABNFunction(torch.autograd.Function):
         invstd, scale = buf[4 * Cc:5 * Cc], buf[5 * Cc:]
         sums = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
         need_param_grad = weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        if training or need_param_grad:
-            hip.abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y if y is not None else 0, M, Cc, plane_bias, HW, mean,
-                               invstd, scale, shift, act, slope, sums)
-        dbias = dweight = None
-        if need_param_grad:
-            dbias, dweight = sums[:Cc].clone(), sums[Cc:].clone()
-        if training and world > 1:
-            dist.all_reduce(sums, group=group if group is not None else None)
         dx = hip.empty_like_rows(x)
         dz = hip.empty_like_rows(x) if has_res else None
-        hip.abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y if y is not None else 0, dx, Cc, dz, Cc if has_res else 0, M, Cc,
-                          plane_bias, HW, mean, invstd, scale, shift, weight, sums, count, 0 if training else 1, act,
-                          slope)
+        ld_yy = ld_y if y is not None else 0
+        if not (training and world > 1):
+            hip.abn_backward(x, ld_x, dy, ld_dy, y, ld_yy, dx, Cc, dz, Cc if has_res else 0, M, Cc, plane_bias, HW, mean,
+                             invstd, scale, shift, weight, sums, count, training, need_param_grad, act, slope)
+            dbias = dweight = None
+            if need_param_grad:
+                dbias, dweight = sums[:Cc], sums[Cc:]
+        else:
+            hip.abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_yy, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope,
+                               sums)
+            dbias = dweight = None
+            if need_param_grad:
+                dbias, dweight = sums[:Cc].clone(), sums[Cc:].clone()
+            dist.all_reduce(sums, group=group if group is not None else None)
+            hip.abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_yy, dx, Cc, dz, Cc if has_res else 0, M, Cc, plane_bias, HW, mean,
+                              invstd, scale, shift, weight, sums, count, 0, act, slope)
         dpb = None
         if has_pb:
             # plane_bias enters like x: its gradient is dx summed over each image plane

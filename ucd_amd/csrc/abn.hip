@@ -736,6 +736,45 @@ int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const 
   return check_launch(fn);
 }
 
+// ---- one-call forward / backward (single process): fewer crossings of the Python/ctypes boundary, which is
+// what bounds the step once the per-GPU batch is small (8-GPU regime: ~70 us of host time per layer call)
+int ucd_abn_forward(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r, int dtype, int M, int C,
+                    const float* plane_bias, int HW, const float* weight, const float* bias, float* running_mean,
+                    float* running_var, float momentum, float eps, int training, float* buf, const float* eval_consts,
+                    int act, float slope, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_forward";
+  UCD_REQUIRE(running_mean && running_var, UCD_EINVAL, "%s: running statistics are NULL", fn);
+  if (training) {
+    UCD_REQUIRE(buf, UCD_EINVAL, "%s: buf is NULL", fn);
+    float *sums = buf, *kshift = buf + 2 * C, *mean = buf + 3 * C, *invstd = buf + 4 * C, *scale = buf + 5 * C;
+    UCD_TRY(ucd_abn_stats_finalize(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, weight, running_mean, running_var,
+                                   momentum, eps, mean, invstd, scale, workspace, workspace_bytes, stream));
+    return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, mean, scale, bias, act, slope, stream);
+  }
+  const float* scale = nullptr;
+  if (eval_consts) {
+    scale = eval_consts + C;   // [invstd | scale], computed once for a frozen layer
+  } else {
+    UCD_REQUIRE(buf, UCD_EINVAL, "%s: buf is NULL", fn);
+    UCD_TRY(ucd_abn_eval_params(weight, running_var, eps, C, buf + 4 * C, buf + 5 * C, stream));
+    scale = buf + 5 * C;
+  }
+  return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, running_mean, scale, bias, act, slope,
+                       stream);
+}
+
+int ucd_abn_backward(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, void* dx, int ld_dx,
+                     void* dz_out, int ld_dz, int dtype, int M, int C, const float* plane_bias, int HW, const float* mean,
+                     const float* invstd, const float* scale, const float* bias, const float* weight, float* sums,
+                     float count, int training, int need_sums, int act, float slope, void* workspace,
+                     size_t workspace_bytes, ucd_stream_t stream) {
+  if (training || need_sums)
+    UCD_TRY(ucd_abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale, bias, act, slope,
+                               sums, workspace, workspace_bytes, stream));
+  return ucd_abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz_out, ld_dz, dtype, M, C, plane_bias, HW, mean, invstd,
+                           scale, bias, weight, sums, count, training ? 0 : 1, act, slope, stream);
+}
+
 int ucd_plane_sum(const void* x, int ld_x, int dtype, int B, int HW, int C, float alpha, float* out,
                   ucd_stream_t stream) {
   static const char* fn = "ucd_plane_sum";

@@ -48,6 +48,9 @@ SIGNATURES = {
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
     "ucd_abn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p,
                                _f, _i, _i, _f, _p]),
+    "ucd_abn_forward": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _f, _p, _z, _p]),
+    "ucd_abn_backward": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _i,
+                              _i, _f, _p, _z, _p]),
     "ucd_plane_sum": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "ucd_attmap_workspace_bytes": (_z, [_i, _i]),
     "ucd_attmap": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
@@ -102,31 +105,52 @@ def disable_call_timing():
     _timing = None
 
 
-class _timed:
+class _Timed:
     """with _timed(name, work): <library call>"""
 
     def __init__(self, name, work):
         self.name, self.work = name, work
 
     def __enter__(self):
-        if _timing is not None:
-            self.start = torch.cuda.Event(enable_timing=True)
-            self.end = torch.cuda.Event(enable_timing=True)
-            self.start.record(torch.cuda.current_stream())
+        self.start = torch.cuda.Event(enable_timing=True)
+        self.end = torch.cuda.Event(enable_timing=True)
+        self.start.record(torch.cuda.current_stream())
 
     def __exit__(self, *exc):
-        if _timing is not None:
-            self.end.record(torch.cuda.current_stream())
-            _timing.setdefault(self.name, []).append((self.start, self.end, self.work))
+        self.end.record(torch.cuda.current_stream())
+        _timing.setdefault(self.name, []).append((self.start, self.end, self.work))
         return False
 
 
+class _NoTimer:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+
+
+def _timed(name, work):
+    return _NO_TIMER if _timing is None else _Timed(name, work)
+
+
 def ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device address as a plain int (ctypes converts ints for c_void_p parameters; None is NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """hipStream_t of torch's current stream as an int.  torch.cuda.current_stream() builds a Python Stream
+    object (~10 us); the raw getter is a plain C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
+    return torch.cuda.current_stream().cuda_stream
 
 
 def dtype_code(t):
@@ -158,6 +182,10 @@ def rows_view(x):
     tensor is returned unchanged when its strides already describe rows of C contiguous channels with
     a constant pitch (a channels_last tensor or a channel slice of one); otherwise it is copied."""
     B, Cc, H, W = x.shape
+    st = x.stride()
+    if st[1] == 1 and st[3] == Cc and st[2] == W * Cc and st[0] == H * W * Cc and W > 1 and H > 1 \
+            and not (x.data_ptr() & 15) and not ((Cc * x.element_size()) & 15):
+        return x, B * H * W, Cc, H * W, Cc                 # dense channels-last: the common case
     ok = _rows_ld(x)
     if ok is None:
         x = x.contiguous(memory_format=torch.channels_last)
@@ -224,6 +252,50 @@ def abn_stats_finalize(x, ld, M, Cc, plane_bias, HW, sums, kshift, weight, runni
                                           ptr(weight), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
                                           ptr(mean), ptr(invstd), ptr(scale), ptr(ws), nbytes, stream()),
                "ucd_abn_stats_finalize")
+
+
+def abn_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean, running_var,
+                momentum, eps, training, buf, eval_consts, act, slope):
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    es = x.element_size()
+    if _timing is not None:      # instrumented bench pass: keep the per-kernel attribution
+        if training:
+            abn_stats_finalize(x, ld_x, M, Cc, plane_bias, HW, buf[:2 * Cc], buf[2 * Cc:3 * Cc], weight, running_mean,
+                               running_var, momentum, eps, buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:])
+            abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, buf[3 * Cc:4 * Cc], buf[5 * Cc:], bias, act, slope)
+        else:
+            sc = eval_consts[1] if eval_consts is not None else buf[5 * Cc:]
+            if eval_consts is None:
+                abn_eval_params(weight, running_var, eps, Cc, buf[4 * Cc:5 * Cc], buf[5 * Cc:])
+            abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, running_mean, sc, bias, act, slope)
+        return
+    rc = lib.ucd_abn_forward(x.data_ptr(), ld_x, y.data_ptr(), ld_y, ptr(residual), ld_r, BF16 if es == 2 else F32, M, Cc,
+                             ptr(plane_bias), HW, ptr(weight), ptr(bias), running_mean.data_ptr(), running_var.data_ptr(),
+                             momentum, eps, 1 if training else 0, ptr(buf), ptr(eval_consts), act, slope, ws.data_ptr(),
+                             nbytes, stream())
+    if rc:
+        _check(rc, "ucd_abn_forward")
+
+
+def abn_backward(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane_bias, HW, mean, invstd, scale, bias, weight,
+                 sums, count, training, need_sums, act, slope):
+    lib = load()
+    if _timing is not None:
+        if training or need_sums:
+            abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, bias, act, slope, sums)
+        abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane_bias, HW, mean, invstd, scale, bias,
+                      weight, sums, count, 0 if training else 1, act, slope)
+        return
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    rc = lib.ucd_abn_backward(x.data_ptr(), ld_x, dy.data_ptr(), ld_dy, ptr(y), ld_y, dx.data_ptr(), ld_dx, ptr(dz), ld_dz,
+                              BF16 if x.element_size() == 2 else F32, M, Cc, ptr(plane_bias), HW, mean.data_ptr(),
+                              invstd.data_ptr(), scale.data_ptr(), ptr(bias), ptr(weight), sums.data_ptr(), count,
+                              1 if training else 0, 1 if need_sums else 0, act, slope, ws.data_ptr(), nbytes, stream())
+    if rc:
+        _check(rc, "ucd_abn_backward")
 
 
 def abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale):
