@@ -279,9 +279,20 @@ class ABN(nn.Module):
         act = _act_code(self.activation if activation is None else activation)
         slope = self.activation_param if activation_param is None else activation_param
         inplace = self._inplace_contract and not torch.is_grad_enabled() and out is None
+        if not torch.is_grad_enabled() and not self.training and residual is None and plane_bias is None and out is None:
+            return self._forward_eval_nograd(x, act, slope, inplace)
         return _ABNFunction.apply(x, self.weight, self.bias, residual, plane_bias, self.running_mean,
                                   self.running_var, self.training, self.momentum, self.eps, act, slope,
                                   self._group(), out, inplace, None if self.training else self._eval_constants())
+
+    def _forward_eval_nograd(self, x, act, slope, inplace):
+        """Frozen-statistics forward outside autograd (the teacher): one library call, no Function object."""
+        x, M, Cc, HW, ld_x = hip.rows_view(x)
+        y = x if inplace else hip.empty_like_rows(x)
+        hip.abn_forward(x, ld_x, y, ld_x if inplace else Cc, None, 0, M, Cc, None, HW, self.weight, self.bias,
+                        self.running_mean, self.running_var, self.momentum, self.eps, False, None,
+                        self._eval_constants(), act, slope)
+        return y
 
     def _eval_constants(self):
         """invstd / scale of the running statistics, cached until a parameter or buffer changes (the frozen

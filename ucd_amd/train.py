@@ -66,6 +66,12 @@ class Trainer:
         self.lkd_flag = self.lkd > 0. and model_old is not None
         self.lkd_loss = (UnbiasedKnowledgeDistillationLoss if opts.unkd else KnowledgeDistillationLoss)(alpha=opts.alpha)
         self.regularizer, self.regularizer_flag = None, False
+        # The frozen teacher (eval mode, no gradients, no collectives) is replayed from a hipGraph after two eager
+        # warm-up steps: ~330 kernel launches of host work per step disappear, which matters once the per-GPU batch
+        # is small (8-GPU regime: the step is launch-bound, not GPU-bound).
+        self.graph_teacher = bool(getattr(opts, "graph_teacher", True)) and device.type == "cuda" and model_old is not None
+        self._tg = None
+        self._tg_seen = 0
         self.ret_intermediate = self.lde
         self.unce = bool(opts.unce and self.old_classes != 0)
         # fused up-sampling + CE + KD kernel whenever the loss pair is one it implements:
@@ -81,6 +87,42 @@ class Trainer:
     def _autocast(self):
         return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp and self.device.type == "cuda")
 
+    def _teacher_eager(self, images, up):
+        with torch.no_grad(), self._autocast():
+            return self.model_old(images, x_b_old=None, x_pl_old=None, ret_intermediate=self.ret_intermediate, **up)
+
+    def _teacher_forward(self, images, up):
+        """(outputs_old, features_old); replayed from a captured graph when enabled and the input shape is stable."""
+        if not self.graph_teacher or self.lde_flag:
+            return self._teacher_eager(images, up)
+        tg = self._tg
+        if tg is not None and tg["shape"] == tuple(images.shape) and tg["up"] == bool(up):
+            tg["images"].copy_(images)
+            tg["graph"].replay()
+            return tg["out"]
+        self._tg_seen += 1
+        if self._tg_seen <= 2:                      # eager warm-up: MIOpen solver search, workspaces, constants
+            return self._teacher_eager(images, up)
+        try:
+            from .segmentation_module import Features
+            static = images.clone()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outputs_old, f = self._teacher_eager(static, up)
+                # materialise exactly what the step reads; the lazy attention maps are not part of the graph
+                out = (outputs_old, Features(f.raw("body"), f.raw("pre_logits"), f["sem"]))
+            self._tg = {"graph": graph, "images": static, "out": out, "shape": tuple(images.shape), "up": bool(up)}
+            graph.replay()
+            return out
+        except Exception as e:                      # capture is an optimisation: never lose the step over it
+            self.graph_teacher = False
+            self._tg = None
+            torch.cuda.synchronize()
+            import warnings
+            warnings.warn(f"teacher graph capture disabled: {e!r}")
+            return self._teacher_eager(images, up)
+
     def train_step(self, images, labels, optim, scheduler=None):
         """One iteration; returns device scalars (no host synchronisation)."""
         model, model_old = self.model, self.model_old
@@ -93,9 +135,7 @@ class Trainer:
         fuse = self.fuse_logit_losses
         up = {} if not fuse else {"upsample": False}
         if model_old is not None:
-            with torch.no_grad(), self._autocast():
-                outputs_old, features_old = model_old(images, x_b_old=None, x_pl_old=None,
-                                                      ret_intermediate=self.ret_intermediate, **up)
+            outputs_old, features_old = self._teacher_forward(images, up)
         if hasattr(model, "zero_grad") and hasattr(model, "finish_grad_sync"):
             model.zero_grad()
         else:
