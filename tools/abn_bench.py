@@ -14,7 +14,7 @@ def timeit(f, n=20):
     torch.cuda.synchronize()
     t = sorted(s.elapsed_time(e) for s, e in evs)
     return t[n // 2] * 1e3   # us
-print("%-14s %8s | %18s | %18s | %18s | %18s" % ("C x HW", "MB", "stats us (GB/s)", "apply us (GB/s)", "bwd_reduce", "bwd_apply"))
+if not os.environ.get("ABN_ONLY"): print("%-14s %8s | %18s | %18s | %18s | %18s" % ("C x HW", "MB", "stats us (GB/s)", "apply us (GB/s)", "bwd_reduce", "bwd_apply"))
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 for C, hw in shapes:
     x = torch.randn(B, C, hw, hw, device=dev, dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
@@ -30,9 +30,16 @@ for C, hw in shapes:
     def f_bapp(): hip.abn_bwd_apply(x, C, dy, C, None, 0, dx, C, None, 0, M, C, None, HW, mean, invstd, scale, b, w, sums, M, 0, 1, 0.01)
     f_stats()
     res = []
+    only = os.environ.get("ABN_ONLY")
+    if only:
+        f = {"STATS": f_stats, "APPLY": f_apply, "BRED": f_red, "BAPP": f_bapp}[only]
+        print("%s=%.1f" % (f"{C}x{hw}", timeit(f)), end=" ", flush=True)
+        continue
     for f, nb in ((f_stats, 1), (f_apply, 2), (f_red, 2), (f_bapp, 3)):
         def g():
             f()
         us = timeit(g)
-        res.append("%8.1f (%6.0f)" % (us, nb * mb * 1e6 / us / 1e9 * 1e-0))
+        res.append("%8.1f (%6.0f)" % (us, nb * mb / us * 1e3))
     print("%-14s %8.1f | %18s | %18s | %18s | %18s" % (f"{C}x{hw}^2", mb, *res))
+
+print()
