@@ -24,6 +24,17 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def _view_like(buf, p):
+    """View of the flat slice ``buf`` with the shape AND strides of ``p`` (channels-last 4-D weights keep their
+    format, so fused optimisers see matching layouts and autograd accumulates without re-striding)."""
+    if p.dim() == 4:
+        co, ci, kh, kw = p.shape
+        v = buf.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        if v.stride() == p.stride():
+            return v
+    return buf.view_as(p)
+
+
 class _Bucket:
     __slots__ = ("flat", "params", "pending", "work", "wire", "event")
 
@@ -68,7 +79,7 @@ class GradReducer:
         b.params, b.pending, b.work, b.wire, b.event = plist, len(plist), None, None, None
         off = 0
         for p in plist:
-            p.grad = b.flat[off:off + p.numel()].view_as(p)      # gradients accumulate straight into the bucket
+            p.grad = _view_like(b.flat[off:off + p.numel()], p)  # gradients accumulate straight into the bucket
             off += p.numel()
             self._bucket_of[p] = b
         self.buckets.append(b)
@@ -82,7 +93,7 @@ class GradReducer:
             off = 0                                             # re-attach views dropped by set_to_none
             for p in b.params:
                 if p.grad is None:
-                    p.grad = b.flat[off:off + p.numel()].view_as(p)
+                    p.grad = _view_like(b.flat[off:off + p.numel()], p)
                 off += p.numel()
 
     def _on_grad(self, p):

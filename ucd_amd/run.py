@@ -67,6 +67,12 @@ def build_models(opts, device, classes):
     model_old = make_model(opts, classes=classes[:-1]).to(device) if opts.step > 0 else None
     if opts.fix_bn:
         model.fix_bn()
+    if device.type == "cuda":
+        # activations are channels-last; weights in the same format spare MIOpen one layout copy per 3x3
+        # convolution call and let gradients be adopted without a re-striding copy
+        model = model.to(memory_format=torch.channels_last)
+        if model_old is not None:
+            model_old = model_old.to(memory_format=torch.channels_last)
     return model, model_old
 
 
