@@ -67,7 +67,8 @@ def build(args, device, per_rank_batch, rank):
         {k: v.cpu() for k, v in model_old.state_dict().items()}, 42).items()}
     optimizer = make_optimizer(opts, model)
     scheduler = PolyLR(optimizer, max_iters=30 * 2145 // max(1, args.global_batch), power=opts.lr_power)
-    model = DistributedDataParallel(model, delay_allreduce=True)
+    model = DistributedDataParallel(model, delay_allreduce=True,
+                                    bf16_weights=getattr(opts, "opt_level", "O0") != "O0" and getattr(opts, "bf16_weights", True))
     load_step_checkpoint(opts, model, model_old, state, device)
     opts.pixcon_precision = args.pixcon_precision
     trainer = Trainer(model, model_old, device=device, opts=opts, classes=classes)

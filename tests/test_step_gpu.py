@@ -152,3 +152,48 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
         assert k in ck["model_state"], k
     assert ck["trainer_state"] == {"regularizer": None}
     ddp.load_state_dict(ck["model_state"], strict=True)
+
+
+def test_bf16_working_weights_equal_per_call_casts(tmp_path):
+    """--opt_level O1 with the flat bf16 working copies (ucd_amd/master.py) is the same arithmetic as autocast's
+    per-call weight casts: two steps from the same state give the same losses and the same updated fp32 weights,
+    and the checkpoint keeps the reference's keys and values."""
+    from ucd_amd.ddp import DistributedDataParallel
+    from ucd_amd.run import make_optimizer, save_ckpt
+    from ucd_amd.scheduler import PolyLR
+    from ucd_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    img = synth.images(501, 2, 129)
+    labels = synth.seg_labels(501, 2, 129, 129, range(16, 21))
+    results = []
+    for shadows in (False, True):
+        opts = _opts(["--opt_level", "O1"])
+        opts.bf16_weights = shadows
+        opts.graph_teacher = False
+        model, model_old, classes = _build(opts, dev)
+        optim = make_optimizer(opts, model)
+        ddp = DistributedDataParallel(model, bf16_weights=shadows)
+        assert (ddp.bf16_weights is not None) == shadows
+        trainer = Trainer(ddp, model_old, device=dev, opts=opts, classes=classes)
+        ddp.train()
+        torch.backends.cudnn.deterministic = True
+        r1 = {k: v.item() for k, v in trainer.train_step(img, labels, optim, None).items()}
+        r2 = {k: v.item() for k, v in trainer.train_step(img, labels, optim, None).items()}
+        state = {k: v.detach().float().cpu().clone() for k, v in ddp.state_dict().items()}
+        results.append((r1, r2, state))
+        if shadows:
+            path = str(tmp_path / "ck.pth")
+            save_ckpt(path, ddp, trainer, optim, PolyLR(optim, max_iters=10), 0, 0.0)
+            ck = torch.load(path, map_location="cpu")["model_state"]
+            assert set(ck) == set(state)
+            for k in ("module.body.mod1.conv1.weight", "module.head.map_convs.3.weight"):
+                assert torch.equal(ck[k].float(), state[k]) and ck[k].dtype == torch.float32
+    torch.backends.cudnn.deterministic = False
+    (a1, a2, sa), (b1, b2, sb) = results
+    for k in ("loss", "ce", "lkd", "con"):
+        assert b1[k] == pytest.approx(a1[k], rel=1e-6), k          # identical forward
+        assert b2[k] == pytest.approx(a2[k], rel=2e-2), k          # after one (non bit-reproducible) update
+    for k in ("module.body.mod1.conv1.weight", "module.body.mod4.block3.convs.conv2.weight",
+              "module.head.red_conv.weight", "module.body.mod5.block1.convs.bn3.weight"):
+        d = (sa[k] - sb[k]).norm() / sa[k].norm()
+        assert d < 1e-4, (k, d.item())

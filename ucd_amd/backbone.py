@@ -14,7 +14,7 @@ from functools import partial
 
 import torch.nn as nn
 
-from .blocks import ResidualBlock, try_index
+from .blocks import Conv2d, ResidualBlock, try_index
 
 _STAGE_DILATION = {16: (1, 1, 1, 2), 8: (1, 1, 2, 4)}
 
@@ -37,7 +37,7 @@ class ResNet(nn.Module):
         self.structure, self.bottleneck, self.keep_outputs = structure, bottleneck, keep_outputs
         self.dilation = dilation = list(_STAGE_DILATION[output_stride])
 
-        stem = [("conv1", nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)), ("bn1", norm_act(64))]
+        stem = [("conv1", Conv2d(3, 64, 7, stride=2, padding=3, bias=False)), ("bn1", norm_act(64))]
         if try_index(dilation, 0) == 1:
             stem.append(("pool1", nn.MaxPool2d(3, stride=2, padding=1)))
         self.mod1 = nn.Sequential(OrderedDict(stem))

@@ -40,16 +40,18 @@ def _wgrad_split(M: int) -> int:
 
 
 class _Gemm1x1(torch.autograd.Function):
-    """rows[M, Ci] x w[Co, Ci]^T with the weight gradient computed as a split-K batched GEMM."""
+    """rows[M, Ci] x w[Co, Ci, 1, 1]^T with the weight gradient computed as a split-K batched GEMM and returned in
+    the weight's own 4-D layout (so autograd adopts it without a re-striding copy)."""
 
     @staticmethod
-    def forward(ctx, rows, w):
-        ctx.save_for_backward(rows, w)
-        return rows @ w.t()
+    def forward(ctx, rows, w4):
+        ctx.save_for_backward(rows, w4)
+        return rows @ w4.reshape(w4.shape[0], w4.shape[1]).t()
 
     @staticmethod
     def backward(ctx, dy):
-        rows, w = ctx.saved_tensors
+        rows, w4 = ctx.saved_tensors
+        w = w4.reshape(w4.shape[0], w4.shape[1])
         dy = dy.contiguous()
         dx = dy @ w if ctx.needs_input_grad[0] else None
         dw = None
@@ -60,7 +62,28 @@ class _Gemm1x1(torch.autograd.Function):
                 dw = dy.t() @ rows
             else:
                 dw = torch.bmm(dy.view(S, M // S, Co).transpose(1, 2), rows.view(S, M // S, rows.shape[1])).sum(0)
+            dw = dw.as_strided(w4.shape, w4.stride())     # [Co, Ci, 1, 1] is one memory order in either format
         return dx, dw
+
+
+class Conv2d(nn.Conv2d):
+    """``nn.Conv2d`` that computes with a bf16 working copy of its weight when one is attached and autocast is on
+    (``ucd_amd/master.py``): no per-call cast of the fp32 master weight, no cast node in the backward.  Parameters,
+    ``state_dict`` keys and the fp32 behaviour are those of ``nn.Conv2d``."""
+
+    _w16 = None
+
+    def working_weight(self):
+        w = self._w16
+        if w is not None and torch.is_autocast_enabled():
+            return w
+        return None
+
+    def forward(self, x):
+        w = self.working_weight()
+        if w is None:
+            return super().forward(x)
+        return self._conv_forward(x, w, self.bias)
 
 
 def try_index(scalar_or_list, i):
@@ -71,7 +94,7 @@ def try_index(scalar_or_list, i):
         return scalar_or_list
 
 
-class Conv1x1(nn.Conv2d):
+class Conv1x1(Conv2d):
     """1x1 stride-1 convolution with the reference's parameter shape ([Cout, Cin, 1, 1]).  On the GPU, for
     the wide layers of the network (mod4 / mod5 / ASPP at the stride-16 resolution), it runs as ONE plain
     GEMM on the channels-last row matrix [B*H*W, Cin] x [Cin, Cout] (hipBLASLt) instead of an MIOpen
@@ -93,11 +116,12 @@ class Conv1x1(nn.Conv2d):
         if not rows.is_contiguous():
             rows = rows.contiguous()
         rows = rows.reshape(B * H * W, C)
-        w = self.weight.view(self.out_channels, C)
-        if self.bias is None and torch.is_grad_enabled() and w.requires_grad and rows.dtype != torch.float32:
-            y = _Gemm1x1.apply(rows, w.to(rows.dtype))
+        w16 = self.working_weight()
+        if self.bias is None and rows.dtype != torch.float32 and torch.is_grad_enabled() and self.weight.requires_grad:
+            y = _Gemm1x1.apply(rows, w16 if w16 is not None else self.weight.to(rows.dtype))
         else:
-            y = F.linear(rows, w, self.bias)
+            w = w16 if (w16 is not None and rows.dtype == w16.dtype) else self.weight
+            y = F.linear(rows, w.reshape(self.out_channels, C), self.bias)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 
@@ -134,7 +158,7 @@ class ResidualBlock(nn.Module):
             if k == 1 and s == 1 and g == 1:
                 return Conv1x1(cin, cout)
             pad = dilation if k == 3 else 0
-            return nn.Conv2d(cin, cout, k, stride=s, padding=pad, dilation=dilation if k == 3 else 1,
+            return Conv2d(cin, cout, k, stride=s, padding=pad, dilation=dilation if k == 3 else 1,
                              groups=g, bias=False)
 
         if len(channels) == 3:
@@ -154,7 +178,7 @@ class ResidualBlock(nn.Module):
 
         if stride != 1 or in_channels != channels[-1]:
             self.proj_conv = (Conv1x1(in_channels, channels[-1]) if stride == 1 else
-                              nn.Conv2d(in_channels, channels[-1], 1, stride=stride, padding=0, bias=False))
+                              Conv2d(in_channels, channels[-1], 1, stride=stride, padding=0, bias=False))
             self.proj_bn = norm_act(channels[-1])
             self.proj_bn.activation = "identity"
 
@@ -196,16 +220,16 @@ class DeeplabV3(nn.Module):
         self.hidden_channels = hidden_channels
 
         branches = [Conv1x1(in_channels, hidden_channels)]
-        branches += [nn.Conv2d(in_channels, hidden_channels, 3, bias=False, dilation=d, padding=d)
+        branches += [Conv2d(in_channels, hidden_channels, 3, bias=False, dilation=d, padding=d)
                      for d in dilations]
         self.map_convs = nn.ModuleList(branches)
         self.map_bn = norm_act(hidden_channels * len(branches))
 
-        self.global_pooling_conv = nn.Conv2d(in_channels, hidden_channels, 1, bias=False)
+        self.global_pooling_conv = Conv2d(in_channels, hidden_channels, 1, bias=False)
         self.global_pooling_bn = norm_act(hidden_channels)
 
         self.red_conv = Conv1x1(hidden_channels * len(branches), out_channels)
-        self.pool_red_conv = nn.Conv2d(hidden_channels, out_channels, 1, bias=False)
+        self.pool_red_conv = Conv2d(hidden_channels, out_channels, 1, bias=False)
         self.red_bn = norm_act(out_channels)
 
         self.reset_parameters(self.map_bn.activation, self.map_bn.activation_param)

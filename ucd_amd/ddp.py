@@ -36,11 +36,14 @@ def _view_like(buf, p):
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "pending", "work", "wire", "event")
+    __slots__ = ("flat", "params", "pending", "work", "wire", "event", "fed", "done")
 
 
 class GradReducer:
-    def __init__(self, params, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True):
+    def __init__(self, params, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True, shadow_of=None):
+        # shadow_of: {fp32 parameter: bf16 working copy that autograd differentiates} (ucd_amd/master.py); such a
+        # parameter's slot in the fp32 bucket is filled from the bf16 gradient when the bucket completes
+        self.shadow_of = shadow_of or {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # gradient buckets get a communicator of their own: they are launched from autograd hooks on a side
         # stream while InPlaceABNSync issues its statistics collectives on the compute stream - two independent
@@ -69,7 +72,13 @@ class GradReducer:
             cur_bytes += nb
         if cur:
             self._make_bucket(cur)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self._hooks = []
+        for p in params:
+            holder = self.shadow_of.get(p)
+            if holder is None:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            else:
+                self._hooks.append(holder.register_post_accumulate_grad_hook(lambda t, p=p: self._on_grad(p)))
         self._inflight = []
 
     def _make_bucket(self, plist):
@@ -77,9 +86,12 @@ class GradReducer:
         total = sum(p.numel() for p in plist)
         b.flat = torch.zeros(total, dtype=plist[0].dtype, device=self.device)
         b.params, b.pending, b.work, b.wire, b.event = plist, len(plist), None, None, None
+        b.fed, b.done = [], False
         off = 0
         for p in plist:
             p.grad = _view_like(b.flat[off:off + p.numel()], p)  # gradients accumulate straight into the bucket
+            if p in self.shadow_of:
+                b.fed.append((p.grad, self.shadow_of[p]))
             off += p.numel()
             self._bucket_of[p] = b
         self.buckets.append(b)
@@ -90,6 +102,9 @@ class GradReducer:
         for b in self.buckets:
             b.flat.zero_()
             b.pending = len(b.params)
+            b.done = False
+            for _, holder in b.fed:
+                holder.grad = None                              # autograd then adopts the incoming tensor
             off = 0                                             # re-attach views dropped by set_to_none
             for p in b.params:
                 if p.grad is None:
@@ -99,7 +114,26 @@ class GradReducer:
     def _on_grad(self, p):
         b = self._bucket_of[p]
         b.pending -= 1
-        if b.pending == 0 and self.world > 1:
+        if b.pending == 0:
+            self._complete(b)
+
+    def _complete(self, b):
+        """All gradients of the bucket exist: widen the bf16 ones into their fp32 slots (one multi-tensor copy),
+        then start the all-reduce."""
+        if b.done:
+            return
+        b.done = True
+        if b.fed:
+            dst, src = [], []
+            for view32, holder in b.fed:
+                if holder.grad is not None:
+                    dst.append(view32)
+                    src.append(holder.grad)
+            if src:
+                torch._foreach_copy_(dst, src)
+            for _, holder in b.fed:
+                holder.grad = None
+        if self.world > 1:
             self._launch(b)
 
     def _launch(self, b):
@@ -125,11 +159,11 @@ class GradReducer:
 
     def finish(self):
         """Block the compute stream (not the host) until every bucket of this step is averaged."""
+        for b in self.buckets:                                  # parameters that received no gradient
+            if not b.done:
+                self._complete(b)
         if self.world == 1:
             return
-        for b in self.buckets:                                  # parameters that received no gradient
-            if b.pending != 0 and b not in self._inflight:
-                self._launch(b)
         for b in self._inflight:
             if self.overlap:
                 with torch.cuda.stream(self.stream):
@@ -160,9 +194,11 @@ class DistributedDataParallel(nn.Module):
     Parameters and buffers are broadcast from rank 0 at construction (apex does the same).
     Call ``zero_grad()`` before and ``finish_grad_sync()`` after ``backward()``."""
 
-    def __init__(self, module, delay_allreduce=True, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True):
+    def __init__(self, module, delay_allreduce=True, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True,
+                 bf16_weights=False):
         super().__init__()
         self.module = module
+        self.bf16_weights = None
         self.delay_allreduce = delay_allreduce        # accepted for call compatibility; overlap decides
         self.reducer = None
         if dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -170,10 +206,17 @@ class DistributedDataParallel(nn.Module):
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t, src=0, group=group)
         params = [p for p in module.parameters() if p.requires_grad]
+        shadow_of = None
+        if bf16_weights and params and params[0].is_cuda:
+            from .master import Bf16Weights
+            self.bf16_weights = Bf16Weights(module)
+            shadow_of = self.bf16_weights.shadow_of
         if params:
-            self.reducer = GradReducer(params, bucket_mb, wire_dtype, group, overlap)
+            self.reducer = GradReducer(params, bucket_mb, wire_dtype, group, overlap, shadow_of)
 
     def forward(self, *args, **kwargs):
+        if self.bf16_weights is not None:
+            self.bf16_weights.refresh_if_stale()            # after an optimiser step / checkpoint load
         return self.module(*args, **kwargs)
 
     def zero_grad(self, set_to_none=False):

@@ -1,0 +1,60 @@
+"""bf16 working copies of the convolution weights ("master weights" layout for --opt_level O1).
+
+The reference runs apex AMP O1 (run.py:199-200): every convolution call casts its fp32 weight to the compute type,
+and the backward casts the weight gradient back - two small kernels and two autograd nodes per layer and step,
+~210 launches that matter once the step is launch-bound.  Here the fp32 weights the optimiser updates (and that
+``state_dict`` saves) are re-pointed into ONE flat fp32 buffer, and a flat bf16 buffer of identical layout holds the
+working copies the convolutions read; after an optimiser step the whole set is refreshed by a single cast kernel
+(detected through the buffer's version counter, so any optimiser works).  The bf16 values are exactly the ones the
+per-call cast would have produced (round-to-nearest-even of the fp32 master), so the forward is bit-identical.
+
+The gradients of the working copies arrive in bf16; ``ucd_amd.ddp.GradReducer`` widens a whole bucket of them into
+the fp32 bucket (= ``master.grad``) with one multi-tensor copy when the bucket is complete.
+"""
+from __future__ import annotations
+
+import torch
+
+from .blocks import Conv2d
+from .ddp import _view_like
+
+
+class Bf16Weights:
+    def __init__(self, model, trainable=True):
+        net = model.module if hasattr(model, "module") else model
+        self.convs = [m for m in net.modules() if isinstance(m, Conv2d) and m.weight.is_cuda
+                      and m.weight.dtype == torch.float32 and (m.weight.requires_grad or not trainable)]
+        self.trainable = trainable
+        self.shadow_of = {}
+        if not self.convs:
+            self.flat32 = self.flat16 = None
+            return
+        dev = self.convs[0].weight.device
+        total = sum(m.weight.numel() for m in self.convs)
+        self.flat32 = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat16 = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        off = 0
+        with torch.no_grad():
+            for m in self.convs:
+                w, n = m.weight, m.weight.numel()
+                v32 = _view_like(self.flat32[off:off + n], w)
+                v32.copy_(w)
+                w.data = v32                                  # the Parameter object (optimiser key) is unchanged
+                s = _view_like(self.flat16[off:off + n], w)
+                if trainable:
+                    s.requires_grad_(True)
+                m._w16 = s
+                self.shadow_of[w] = s
+                off += n
+        self._seen = -1
+        self.refresh_if_stale()
+
+    def refresh_if_stale(self):
+        """One cast kernel for all weights, only when some master changed (in-place updates bump the version)."""
+        if self.flat32 is None:
+            return
+        v = self.flat32._version
+        if v != self._seen:
+            with torch.no_grad():
+                self.flat16.copy_(self.flat32)
+            self._seen = v

@@ -123,7 +123,8 @@ def main(opts):
     model, model_old = build_models(opts, device, classes)
     optimizer = make_optimizer(opts, model)
     scheduler = PolyLR(optimizer, max_iters=opts.epochs * len(train_loader), power=opts.lr_power)
-    model = DistributedDataParallel(model, delay_allreduce=True)
+    model = DistributedDataParallel(model, delay_allreduce=True,
+                                    bf16_weights=getattr(opts, "opt_level", "O0") != "O0" and getattr(opts, "bf16_weights", True))
     if opts.step > 0:
         path = opts.step_ckpt or f"checkpoints/step/{task_name}_{opts.name}_{opts.step - 1}.pth"
         if os.path.exists(path):

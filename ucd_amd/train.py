@@ -81,6 +81,11 @@ class Trainer:
         self.amp = getattr(opts, "opt_level", "O0") != "O0"
         # contrastive arithmetic: exact fp32 MFMA with fp32 activations (O0), fp16 operands otherwise
         self.pixcon_precision = getattr(opts, "pixcon_precision", None) or ("f16" if self.amp else "f32")
+        # frozen teacher under autocast: static bf16 copies of its convolution weights (no per-call casts)
+        self._teacher_w16 = None
+        if self.amp and device.type == "cuda" and model_old is not None and getattr(opts, "bf16_weights", True):
+            from .master import Bf16Weights
+            self._teacher_w16 = Bf16Weights(model_old, trainable=False)
         self.last = {}
 
     # ------------------------------------------------------------------------------------------
@@ -93,6 +98,8 @@ class Trainer:
 
     def _teacher_forward(self, images, up):
         """(outputs_old, features_old); replayed from a captured graph when enabled and the input shape is stable."""
+        if self._teacher_w16 is not None:
+            self._teacher_w16.refresh_if_stale()
         if not self.graph_teacher or self.lde_flag:
             return self._teacher_eager(images, up)
         tg = self._tg
