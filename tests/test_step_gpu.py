@@ -166,6 +166,10 @@ def test_bf16_working_weights_equal_per_call_casts(tmp_path):
     img = synth.images(501, 2, 129)
     labels = synth.seg_labels(501, 2, 129, 129, range(16, 21))
     results = []
+    # MIOpen's default pick for some narrow 1x1 convolutions is not run-to-run reproducible (tools/determinism_probe.py)
+    # and this small random network amplifies that to several percent; with deterministic solvers the two modes are
+    # bit-identical, which is the claim
+    torch.backends.cudnn.deterministic = True
     for shadows in (False, True):
         opts = _opts(["--opt_level", "O1"])
         opts.bf16_weights = shadows
@@ -176,7 +180,6 @@ def test_bf16_working_weights_equal_per_call_casts(tmp_path):
         assert (ddp.bf16_weights is not None) == shadows
         trainer = Trainer(ddp, model_old, device=dev, opts=opts, classes=classes)
         ddp.train()
-        torch.backends.cudnn.deterministic = True
         r1 = {k: v.item() for k, v in trainer.train_step(img, labels, optim, None).items()}
         r2 = {k: v.item() for k, v in trainer.train_step(img, labels, optim, None).items()}
         state = {k: v.detach().float().cpu().clone() for k, v in ddp.state_dict().items()}
@@ -192,8 +195,8 @@ def test_bf16_working_weights_equal_per_call_casts(tmp_path):
     (a1, a2, sa), (b1, b2, sb) = results
     for k in ("loss", "ce", "lkd", "con"):
         assert b1[k] == pytest.approx(a1[k], rel=1e-6), k          # identical forward
-        assert b2[k] == pytest.approx(a2[k], rel=2e-2), k          # after one (non bit-reproducible) update
+        assert b2[k] == pytest.approx(a2[k], rel=1e-6), k          # ... and identical update (deterministic convs)
     for k in ("module.body.mod1.conv1.weight", "module.body.mod4.block3.convs.conv2.weight",
               "module.head.red_conv.weight", "module.body.mod5.block1.convs.bn3.weight"):
         d = (sa[k] - sb[k]).norm() / sa[k].norm()
-        assert d < 1e-4, (k, d.item())
+        assert d < 1e-6, (k, d.item())

@@ -10,6 +10,8 @@ dev = torch.device("cuda:0")
 opts = T._opts()
 model, model_old, classes = T._build(opts, dev)
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 65
+if "cl" in sys.argv:
+    model = model.to(memory_format=torch.channels_last)
 img = synth.images(500, 2, size).to(dev)
 model.train()
 rec = []
@@ -26,7 +28,7 @@ for n, m in model.named_modules():
 runs = []
 for r in range(3):
     rec.clear()
-    with torch.no_grad():
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled="bf16" in sys.argv):
         model(img.clone())
     runs.append(list(rec))
 for r in (1, 2):

@@ -46,14 +46,16 @@ class Bf16Weights:
                 m._w16 = s
                 self.shadow_of[w] = s
                 off += n
-        self._seen = -1
+        self._seen = None
         self.refresh_if_stale()
 
     def refresh_if_stale(self):
         """One cast kernel for all weights, only when some master changed (in-place updates bump the version)."""
         if self.flat32 is None:
             return
-        v = self.flat32._version
+        # ``w.data = view`` keeps each Parameter's own version counter, so the flat buffer's counter does not see the
+        # optimiser's in-place updates; every step touches all weights, so the first and last stand for the set
+        v = (self.convs[0].weight._version, self.convs[-1].weight._version)
         if v != self._seen:
             with torch.no_grad():
                 self.flat16.copy_(self.flat32)
