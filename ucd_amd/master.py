@@ -5,7 +5,7 @@ and the backward casts the weight gradient back - two small kernels and two auto
 ~210 launches that matter once the step is launch-bound.  Here the fp32 weights the optimiser updates (and that
 ``state_dict`` saves) are re-pointed into ONE flat fp32 buffer, and a flat bf16 buffer of identical layout holds the
 working copies the convolutions read; after an optimiser step the whole set is refreshed by a single cast kernel
-(detected through the buffer's version counter, so any optimiser works).  The bf16 values are exactly the ones the
+(an optimiser-step hook marks them stale; other in-place writes are seen through the version counters).  The bf16 values are exactly the ones the
 per-call cast would have produced (round-to-nearest-even of the fp32 master), so the forward is bit-identical.
 
 The gradients of the working copies arrive in bf16; ``ucd_amd.ddp.GradReducer`` widens a whole bucket of them into
@@ -13,7 +13,10 @@ the fp32 bucket (= ``master.grad``) with one multi-tensor copy when the bucket i
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from .blocks import Conv2d
 from .ddp import _view_like
@@ -47,7 +50,25 @@ class Bf16Weights:
                 self.shadow_of[w] = s
                 off += n
         self._seen = None
+        self._dirty = True
+        # fused optimisers update the weights without bumping their version counters, so any optimiser step marks
+        # the working copies stale; plain in-place writes (load_state_dict, broadcast) are seen through the versions
+        ref = weakref.ref(self)
+
+        def _after_step(optimizer, args, kwargs):
+            me = ref()
+            if me is not None:
+                me._dirty = True
+        self._hook = register_optimizer_step_post_hook(_after_step)
         self.refresh_if_stale()
+
+    def __del__(self):
+        hook = getattr(self, "_hook", None)
+        if hook is not None:
+            hook.remove()
+
+    def mark_stale(self):
+        self._dirty = True
 
     def refresh_if_stale(self):
         """One cast kernel for all weights, only when some master changed (in-place updates bump the version)."""
@@ -56,7 +77,8 @@ class Bf16Weights:
         # ``w.data = view`` keeps each Parameter's own version counter, so the flat buffer's counter does not see the
         # optimiser's in-place updates; every step touches all weights, so the first and last stand for the set
         v = (self.convs[0].weight._version, self.convs[-1].weight._version)
-        if v != self._seen:
+        if self._dirty or v != self._seen:
             with torch.no_grad():
                 self.flat16.copy_(self.flat32)
             self._seen = v
+            self._dirty = False
