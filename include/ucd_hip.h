@@ -138,6 +138,32 @@ int ucd_abn_backward(const void* x, int ld_x, const void* dy, int ld_dy, const v
                      int training, int need_sums, int act, float slope,
                      void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
+/* SyncBN across one-process-per-GPU ranks (InPlaceABNSync, segmentation_module.py:17; the inplace-abn
+ * extension all-reduces the statistics of every layer in forward and backward).  The collectives stay with the
+ * caller (torch.distributed / RCCL); these are the library calls around them, equal row counts per rank:
+ *
+ *   forward   ucd_abn_sync_stats    pack[0:C] = mean_r, pack[C:2C] = M2_r = sum (x' - mean_r)^2 of this rank
+ *             all_gather(pack)   -> gathered[world][2C]
+ *             ucd_abn_sync_forward  Chan's combination (mean = avg mean_r, M2 = sum M2_r + M sum (mean_r - mean)^2),
+ *                                   finalize with count = world * M into buf = [. . . | mean | invstd | scale]
+ *                                   (same layout as ucd_abn_forward), running statistics update, then apply
+ *   backward  ucd_abn_sync_bwd_reduce  sums = local_sums = [sum dz | sum dz xhat] of this rank
+ *             all_reduce(sums)
+ *             ucd_abn_bwd_apply with count = world * M    (local_sums are the rank's d bias / d weight) */
+int ucd_abn_sync_stats(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW,
+                       float* sums /* [2*C] scratch */, float* kshift /* [C] scratch */, float* pack /* [2*C] */,
+                       void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+int ucd_abn_sync_forward(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r,
+                         int dtype, int M, int C, const float* plane_bias, int HW,
+                         const float* gathered /* [world][2*C] */, int world,
+                         const float* weight, const float* bias, float* running_mean, float* running_var,
+                         float momentum, float eps, float* buf /* [6*C] */, int act, float slope, ucd_stream_t stream);
+int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
+                            int dtype, int M, int C, const float* plane_bias, int HW,
+                            const float* mean, const float* invstd, const float* scale, const float* shift,
+                            int act, float slope, float* sums /* [2*C] */, float* local_sums /* [2*C] */,
+                            void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
 /* Per-(image, channel) reduction over the HW rows of each image: out[b, c] = alpha * sum_hw x.
  * Global average pooling of the ASPP image-level branch (modules/deeplab.py:72-76) with alpha = 1/HW,
  * and the gradient of a plane_bias (sum of dz over the plane) with alpha = 1. */

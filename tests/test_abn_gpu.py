@@ -1,6 +1,7 @@
 """GPU: the HIP ABN kernels (through the C ABI) against torch's batch_norm + leaky_relu on CPU fp32
 (the documented semantics of inplace_abn.ABN - SURVEY.md section 8-c; tolerance 1e-5 abs/rel in
 fp32, bf16 I/O checked against the same fp32 reference at bf16 resolution)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -180,3 +181,70 @@ def test_plane_mean_and_attmap():
     a = (x ** 2).sum(1)
     a = a / a.flatten(1).norm(dim=1)[:, None, None]
     torch.testing.assert_close(y.cpu(), a.unsqueeze(1) * x, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sync_forward_backward_kernels_match_global_batch(dtype):
+    """The library calls around the SyncBN collectives (ucd_abn_sync_stats / _sync_forward / _sync_bwd_reduce), driven
+    here for three 'ranks' held in one process, against batch norm over the concatenated batch (fp32 torch) and the
+    oracle's combination formula."""
+    from oracle.syncbn import combine_rank_moments
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    world, B, C, H, W = 3, 2, 64, 9, 7
+    M, HW = B * H * W, H * W
+    xs = [(torch.randn(B, C, H, W, device=dev) * 2 + 5).to(dtype).contiguous(memory_format=torch.channels_last)
+          for _ in range(world)]
+    weight = torch.rand(C, device=dev) + 0.5
+    bias = torch.randn(C, device=dev)
+    packs, bufs = [], []
+    for x in xs:
+        buf = torch.zeros(8 * C, device=dev)
+        hip.abn_sync_stats(x, C, M, C, None, HW, buf[:2 * C], buf[2 * C:3 * C], buf[6 * C:])
+        packs.append(buf[6 * C:].clone()); bufs.append(buf)
+    gathered = torch.stack(packs).contiguous()                       # [world][2C] = what all_gather returns
+    full = torch.cat([x.float() for x in xs])                        # the global batch
+    ref_mean = full.mean(dim=(0, 2, 3)); ref_var = full.var(dim=(0, 2, 3), unbiased=False)
+    om, ov, _ = combine_rank_moments(gathered.view(world, 2, C).cpu().numpy(), M)
+    np.testing.assert_allclose(om, ref_mean.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ov, ref_var.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    ys = []
+    for x, buf in zip(xs, bufs):
+        y = torch.empty_like(x)
+        rm_r, rv_r = rm.clone(), rv.clone()
+        hip.abn_sync_forward(x, C, y, C, None, 0, M, C, None, HW, gathered, world, weight, bias, rm_r, rv_r, 0.1, 1e-5, buf,
+                             hip.ACT_CODES["leaky_relu"], 0.01)
+        ys.append(y)
+        np.testing.assert_allclose(buf[3 * C:4 * C].cpu().numpy(), om, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(buf[4 * C:5 * C].cpu().numpy(), 1 / np.sqrt(ov + 1e-5), rtol=1e-4)
+    n = world * M
+    np.testing.assert_allclose(rm_r.cpu().numpy(), 0.1 * om, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rv_r.cpu().numpy(), 0.9 + 0.1 * ov * n / (n - 1), rtol=1e-4)
+    fr = full.clone().requires_grad_(True)
+    wr, br = weight.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(torch.nn.functional.batch_norm(fr, None, None, wr, br, True, 0.1, 1e-5), 0.01)
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(torch.cat([y.float() for y in ys]).cpu().numpy(), yr.detach().cpu().numpy(), **tol)
+    # backward: per-rank sums -> "all_reduce" -> bwd_apply with the global count
+    dys = [torch.randn(B, C, H, W, device=dev).to(dtype).contiguous(memory_format=torch.channels_last) for _ in range(world)]
+    yr.backward(torch.cat([d.float() for d in dys]))
+    sums_r, local_r = [], []
+    for x, dy, buf in zip(xs, dys, bufs):
+        s4 = torch.zeros(4 * C, device=dev)
+        hip.abn_sync_bwd_reduce(x, C, dy, C, None, 0, M, C, None, HW, buf[3 * C:4 * C], buf[4 * C:5 * C], buf[5 * C:6 * C], bias,
+                                hip.ACT_CODES["leaky_relu"], 0.01, s4[:2 * C], s4[2 * C:])
+        assert torch.equal(s4[:2 * C], s4[2 * C:])
+        sums_r.append(s4[:2 * C]); local_r.append(s4[2 * C:])
+    total = torch.stack(sums_r).sum(0)
+    gtol = dict(rtol=1e-3, atol=1e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-1)
+    np.testing.assert_allclose(total[:C].cpu().numpy(), br.grad.cpu().numpy(), **gtol)
+    np.testing.assert_allclose(total[C:].cpu().numpy(), wr.grad.cpu().numpy(), **gtol)
+    dxs = []
+    for x, dy, buf in zip(xs, dys, bufs):
+        dx = torch.empty_like(x)
+        hip.abn_bwd_apply(x, C, dy, C, None, 0, dx, C, None, 0, M, C, None, HW, buf[3 * C:4 * C], buf[4 * C:5 * C],
+                          buf[5 * C:6 * C], bias, weight, total, float(n), 0, hip.ACT_CODES["leaky_relu"], 0.01)
+        dxs.append(dx.float())
+    got, ref = torch.cat(dxs), fr.grad
+    assert ((got - ref).norm() / ref.norm()).item() < (1e-4 if dtype == torch.float32 else 1e-2)

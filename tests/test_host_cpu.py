@@ -135,32 +135,33 @@ def test_bucketed_gradient_averaging_gloo_world2(tmp_path):
 
 
 _SYNCBN_WORKER = r"""
-import sys, torch, torch.distributed as dist
+import sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
-from ucd_amd.abn import _combine_stats_across_ranks
+from ucd_amd.abn import _all_gather_stats
+from oracle.syncbn import rank_moments, combine_rank_moments
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 torch.manual_seed(5)
 C, M = 8, 37
 full = torch.randn(world * M, C) * 3 + 100.0           # |mean| >> std: the case the shifted sums exist for
 x = full[rank * M:(rank + 1) * M]
-k = x[0].clone()                                         # per-rank shift = first row, like ucd_abn_stats
-sums = torch.cat(((x - k).sum(0), ((x - k) ** 2).sum(0)))
-_combine_stats_across_ranks(sums, k, M, C, world, None)
-N = world * M
-mean = k + sums[:C] / N                                  # what ucd_abn_finalize computes from (sums, kshift, count)
-var = (sums[C:] - sums[:C] * (sums[:C] / N)) / N
-ref_mean, ref_var = full.double().mean(0), full.double().var(0, unbiased=False)
-assert torch.allclose(mean.double(), ref_mean, rtol=1e-6, atol=1e-6), (mean, ref_mean)
-assert torch.allclose(var.double(), ref_var, rtol=1e-4, atol=1e-6), (var, ref_var)
+mean_r, m2_r = rank_moments(x.numpy())                   # what ucd_abn_sync_stats packs on the device
+pack = torch.from_numpy(np.concatenate([mean_r, m2_r])).float()
+gathered = _all_gather_stats(pack, world, None).view(world, 2, C)      # the layer's forward collective
+assert torch.equal(gathered[rank].reshape(-1), pack)
+mean, var, _ = combine_rank_moments(gathered.numpy(), M)               # what ucd_abn_sync_forward computes from it
+ref_mean, ref_var = full.double().mean(0).numpy(), full.double().var(0, unbiased=False).numpy()
+assert np.allclose(mean, ref_mean, rtol=1e-6, atol=1e-6), (mean, ref_mean)
+assert np.allclose(var, ref_var, rtol=1e-4, atol=1e-6), (var, ref_var)
 print("SYNC_OK", rank)
 dist.destroy_process_group()
 """
 
 
 def test_syncbn_statistics_combination_gloo_world2(tmp_path):
-    """InPlaceABNSync's cross-rank combination (Chan's formula over all-gathered per-rank mean / M2) equals
-    the statistics of the concatenated batch."""
+    """InPlaceABNSync's forward collective (all-gather of per-rank mean / M2) and the combination formula the HIP
+    kernel implements (oracle/syncbn.py; checked against the kernel in tests/test_abn_gpu.py) give the statistics of
+    the concatenated batch."""
     script = tmp_path / "sync_worker.py"
     script.write_text(_SYNCBN_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")

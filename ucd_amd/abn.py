@@ -42,20 +42,11 @@ def _group_size(group):
     return dist.get_world_size(group if group is not None else None)
 
 
-def _combine_stats_across_ranks(sums, kshift, M, Cc, world, group):
-    """Chan's parallel combination of per-rank (count, mean, M2) - equal counts per rank (DistributedSampler
-    with drop_last, run.py:147-149) - written back in the form ucd_abn_finalize takes:
-    kshift = global mean, sums = [0, global M2]."""
-    d = sums[:Cc] / M
-    pack = torch.cat((kshift + d, sums[Cc:] - sums[:Cc] * d))          # [mean_r | M2_r]
-    flat = torch.empty(world * 2 * Cc, dtype=torch.float32, device=sums.device)
+def _all_gather_stats(pack, world, group):
+    """[world, 2C] table of every rank's (mean_r | M2_r) - the one forward collective of a SyncBN layer."""
+    flat = torch.empty(world * pack.numel(), dtype=torch.float32, device=pack.device)
     dist.all_gather_into_tensor(flat, pack, group=group if group is not None else None)
-    gathered = flat.view(world, 2 * Cc)
-    mean_g = gathered[:, :Cc].mean(dim=0)
-    m2 = gathered[:, Cc:].sum(dim=0) + M * ((gathered[:, :Cc] - mean_g) ** 2).sum(dim=0)
-    kshift.copy_(mean_g)
-    sums[:Cc].zero_()
-    sums[Cc:].copy_(m2)
+    return flat
 
 
 class _ABNFunction(torch.autograd.Function):
@@ -86,17 +77,18 @@ class _ABNFunction(torch.autograd.Function):
             ld_y = Cc
         # [sums(2C) | kshift | mean | invstd | scale]
         use_cache = not training and eval_cache is not None
-        buf = None if use_cache else torch.empty(6 * Cc, dtype=torch.float32, device=dev)
+        buf = None if use_cache else torch.empty((8 if world > 1 else 6) * Cc, dtype=torch.float32, device=dev)
         if world == 1:
             # one library call: statistics + finalize + apply (training) or running-statistics apply (eval)
             hip.abn_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean,
                             running_var, momentum, eps, training, buf, eval_cache if use_cache else None, act, slope)
         else:
-            sums, kshift, mean, invstd, scale = buf[:2 * Cc], buf[2 * Cc:3 * Cc], buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:]
-            hip.abn_stats(x, ld_x, M, Cc, plane_bias, HW, sums, kshift)
-            _combine_stats_across_ranks(sums, kshift, M, Cc, world, group)
-            hip.abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale)
-            hip.abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, scale, bias, act, slope)
+            # statistics of this rank -> all_gather -> combination + finalize + apply: two library calls, one collective
+            pack = buf[6 * Cc:]
+            hip.abn_sync_stats(x, ld_x, M, Cc, plane_bias, HW, buf[:2 * Cc], buf[2 * Cc:3 * Cc], pack)
+            gathered = _all_gather_stats(pack, world, group)
+            hip.abn_sync_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, gathered, world, weight, bias,
+                                 running_mean, running_var, momentum, eps, buf, act, slope)
         if use_cache:   # the backward (if any) reads invstd / scale from the same [.. | invstd | scale] layout
             buf = torch.cat((torch.empty(4 * Cc, dtype=torch.float32, device=dev), eval_cache.reshape(-1))) \
                 if ctx.needs_input_grad[0] else eval_cache
@@ -116,23 +108,25 @@ class _ABNFunction(torch.autograd.Function):
         dy, _, _, _, ld_dy = hip.rows_view(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         mean = buf[3 * Cc:4 * Cc] if training else mean_eval
         invstd, scale = buf[4 * Cc:5 * Cc], buf[5 * Cc:]
-        sums = torch.empty(2 * Cc, dtype=torch.float32, device=x.device)
+        sync = training and world > 1
+        sums = torch.empty((4 if sync else 2) * Cc, dtype=torch.float32, device=x.device)
         need_param_grad = weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dx = hip.empty_like_rows(x)
         dz = hip.empty_like_rows(x) if has_res else None
         ld_yy = ld_y if y is not None else 0
-        if not (training and world > 1):
+        if not sync:
             hip.abn_backward(x, ld_x, dy, ld_dy, y, ld_yy, dx, Cc, dz, Cc if has_res else 0, M, Cc, plane_bias, HW, mean,
                              invstd, scale, shift, weight, sums, count, training, need_param_grad, act, slope)
             dbias = dweight = None
             if need_param_grad:
                 dbias, dweight = sums[:Cc], sums[Cc:]
         else:
-            hip.abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_yy, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope,
-                               sums)
+            local, sums = sums[2 * Cc:], sums[:2 * Cc]           # this rank's sums = its d bias / d weight
+            hip.abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_yy, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act,
+                                    slope, sums, local)
             dbias = dweight = None
             if need_param_grad:
-                dbias, dweight = sums[:Cc].clone(), sums[Cc:].clone()
+                dbias, dweight = local[:Cc], local[Cc:]
             dist.all_reduce(sums, group=group if group is not None else None)
             hip.abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_yy, dx, Cc, dz, Cc if has_res else 0, M, Cc, plane_bias, HW, mean,
                               invstd, scale, shift, weight, sums, count, 0, act, slope)
@@ -162,6 +156,9 @@ class _ABNBranchesFunction(torch.autograd.Function):
         buf = torch.empty(6 * Ct, dtype=torch.float32, device=dev)
         mean, invstd, scale = buf[3 * Ct:4 * Ct], buf[4 * Ct:5 * Ct], buf[5 * Ct:]
         world = _group_size(group) if training else 1
+        if world > 1:
+            return _ABNBranchesFunction._forward_sync(ctx, weight, bias, running_mean, running_var, momentum, eps, act,
+                                                      slope, group, views, out, buf, world)
         count = float(M * world)
         offs, o = [], 0
         for c in chans:
@@ -173,8 +170,6 @@ class _ABNBranchesFunction(torch.autograd.Function):
             w, b = (weight[sl], bias[sl]) if weight is not None else (None, None)
             if training:
                 hip.abn_stats(x, ld, M, c, None, HW, sums, kshift)
-                if world > 1:
-                    _combine_stats_across_ranks(sums, kshift, M, c, world, group)
                 hip.abn_finalize(sums, kshift, count, c, w, running_mean[sl], running_var[sl], momentum, eps, mean[sl],
                                  invstd[sl], scale[sl])
                 mu = mean[sl]
@@ -186,6 +181,38 @@ class _ABNBranchesFunction(torch.autograd.Function):
             mean.copy_(running_mean)
         ctx.save_for_backward(weight, bias, buf, *[v[0] for v in views])
         ctx.cfg = (M, HW, chans, offs, [v[4] for v in views], training, act, slope, group, count, world)
+        return out
+
+    @staticmethod
+    def _forward_sync(ctx, weight, bias, running_mean, running_var, momentum, eps, act, slope, group, views, out, buf, world):
+        """Training forward across ranks: every branch's (mean_r | M2_r) goes into ONE gather; the combination then runs
+        per branch on its slice of the gathered table."""
+        x0, M, _, HW, _ = views[0]
+        chans = [v[2] for v in views]
+        Ct = sum(chans)
+        offs, o = [], 0
+        for c in chans:
+            offs.append(o)
+            o += c
+        # pack layout [mean(Ct) | M2(Ct)] so that a channel slice of the table is again [world][mean | M2] with stride 2Ct
+        pack = torch.empty(2 * Ct, dtype=torch.float32, device=x0.device)
+        tmp = torch.empty(2 * max(chans), dtype=torch.float32, device=x0.device)
+        for (x, _, c, _, ld), o in zip(views, offs):
+            hip.abn_sync_stats(x, ld, M, c, None, HW, buf[3 * o:3 * o + 2 * c], buf[3 * o + 2 * c:3 * (o + c)], tmp)
+            pack[o:o + c].copy_(tmp[:c])
+            pack[Ct + o:Ct + o + c].copy_(tmp[c:2 * c])
+        gathered = _all_gather_stats(pack, world, group).view(world, 2, Ct)
+        bbuf = torch.empty(6 * max(chans), dtype=torch.float32, device=x0.device)
+        mean, invstd, scale = buf[3 * Ct:4 * Ct], buf[4 * Ct:5 * Ct], buf[5 * Ct:]
+        for (x, _, c, _, ld), o in zip(views, offs):
+            sl = slice(o, o + c)
+            g = gathered[:, :, sl].contiguous()                  # [world][2][c] = [world][mean_r | M2_r]
+            w, b = (weight[sl], bias[sl]) if weight is not None else (None, None)
+            hip.abn_sync_forward(x, ld, out[:, sl], Ct, None, 0, M, c, None, HW, g, world, w, b, running_mean[sl],
+                                 running_var[sl], momentum, eps, bbuf, act, slope)
+            mean[sl].copy_(bbuf[3 * c:4 * c]); invstd[sl].copy_(bbuf[4 * c:5 * c]); scale[sl].copy_(bbuf[5 * c:6 * c])
+        ctx.save_for_backward(weight, bias, buf, *[v[0] for v in views])
+        ctx.cfg = (M, HW, chans, offs, [v[4] for v in views], True, act, slope, group, float(M * world), world)
         return out
 
     @staticmethod

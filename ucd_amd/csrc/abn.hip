@@ -173,7 +173,21 @@ struct FinalizeArgs {
   float* invstd;
   float* scale;
   float count, momentum, eps;
+  float* pack;   // PACK mode: [mean_r | M2_r] of this rank for the cross-rank combination
 };
+
+__device__ __forceinline__ void finalize_moments(int c, float mean, float m2, const FinalizeArgs& f) {
+  const float var = fmaxf(m2 / f.count, 0.f);
+  const float invstd = 1.f / sqrtf(var + f.eps);
+  if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
+  if (f.running_var) {
+    const float unbiased = f.count > 1.f ? var * (f.count / (f.count - 1.f)) : var;
+    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+  }
+  f.mean[c] = mean;
+  f.invstd[c] = invstd;
+  f.scale[c] = (f.weight ? f.weight[c] : 1.f) * invstd;
+}
 
 __device__ __forceinline__ void finalize_channel(int c, float s, float ss, const FinalizeArgs& f) {
   const float inv_n = 1.f / f.count;
@@ -191,9 +205,11 @@ __device__ __forceinline__ void finalize_channel(int c, float s, float ss, const
   f.scale[c] = (f.weight ? f.weight[c] : 1.f) * invstd;
 }
 
-template <bool FINALIZE>
+// MODE 0: sums only (and an optional second copy), 1: + finalize, 2: + pack [mean_r | M2_r] for the SyncBN gather
+template <int MODE>
 __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int C,
-                                                              float* __restrict__ sums, FinalizeArgs fin) {
+                                                              float* __restrict__ sums, FinalizeArgs fin,
+                                                              float* __restrict__ sums2 = nullptr) {
   __shared__ float lds[16][17];
   const int kl = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int c = blockIdx.x * 8 + (kl & 7);
@@ -217,12 +233,40 @@ __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += lds[i][kl];
     sums[k] = t;
+    if (sums2) sums2[k] = t;
     lds[0][kl] = t;
   }
-  if (FINALIZE) {
+  if (MODE == 1) {
     __syncthreads();
     if (lane == 0 && kl < 8 && c < C) finalize_channel(c, lds[0][kl], lds[0][kl + 8], fin);
   }
+  if (MODE == 2) {
+    __syncthreads();
+    if (lane == 0 && kl < 8 && c < C) {
+      const float s1 = lds[0][kl], s2 = lds[0][kl + 8];
+      const float d = s1 / fin.count;
+      fin.pack[c] = fin.kshift[c] + d;
+      fin.pack[C + c] = s2 - s1 * d;
+    }
+  }
+}
+
+// SyncBN: Chan's combination of the per-rank (mean, M2) pairs (equal counts per rank) + the usual finalize.
+// gathered: [world][2C] = [mean_r | M2_r]; fin.count = world * m_local.
+__global__ void abn_combine_finalize_kernel(const float* __restrict__ gathered, int world, int C, float m_local,
+                                            FinalizeArgs fin) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean = 0.f;
+  for (int r = 0; r < world; ++r) mean += gathered[(size_t)r * 2 * C + c];
+  mean /= (float)world;
+  float m2 = 0.f, dev2 = 0.f;
+  for (int r = 0; r < world; ++r) {
+    const float d = gathered[(size_t)r * 2 * C + c] - mean;
+    m2 += gathered[(size_t)r * 2 * C + C + c];
+    dev2 += d * d;
+  }
+  finalize_moments(c, mean, m2 + m_local * dev2, fin);
 }
 
 __global__ void abn_finalize_kernel(const float* __restrict__ sums, int C, FinalizeArgs fin) {
@@ -609,10 +653,12 @@ static int abn_stats_impl(const void* x, int ld_x, int dtype, int M, int C, cons
         (const float*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial, kshift);
   }
   UCD_TRY(check_launch(fn));
-  if (fin)
-    reduce_bands_kernel<true><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, *fin);
+  if (fin && fin->pack)
+    reduce_bands_kernel<2><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, *fin);
+  else if (fin)
+    reduce_bands_kernel<1><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, *fin);
   else
-    reduce_bands_kernel<false><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{});
+    reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{});
   return check_launch(fn);
 }
 
@@ -626,7 +672,7 @@ int ucd_abn_stats_finalize(const void* x, int ld_x, int dtype, int M, int C, con
                            float momentum, float eps, float* mean, float* invstd, float* scale, void* workspace,
                            size_t workspace_bytes, ucd_stream_t stream) {
   UCD_REQUIRE(mean && invstd && scale && kshift, UCD_EINVAL, "ucd_abn_stats_finalize: NULL output");
-  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, (float)M, momentum, eps};
+  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, (float)M, momentum, eps, nullptr};
   return abn_stats_impl(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, workspace, workspace_bytes, stream, &fin);
 }
 
@@ -635,7 +681,7 @@ int ucd_abn_finalize(const float* sums, const float* kshift, float count, int C,
                      float* scale, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_finalize";
   UCD_REQUIRE(sums && mean && invstd && scale && C > 0 && count > 0.f, UCD_EINVAL, "%s: bad arguments", fn);
-  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, count, momentum, eps};
+  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, count, momentum, eps, nullptr};
   abn_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, C, fin);
   return check_launch(fn);
 }
@@ -678,11 +724,10 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
   return check_launch(fn);
 }
 
-int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,
-                       int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
-                       const float* scale, const float* shift, int act, float slope, float* sums, void* workspace,
-                       size_t workspace_bytes, ucd_stream_t stream) {
-  static const char* fn = "ucd_abn_bwd_reduce";
+static int bwd_reduce_impl(const char* fn, const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
+                           int dtype, int M, int C, const float* plane_bias, int HW, const float* mean,
+                           const float* invstd, const float* scale, const float* shift, int act, float slope,
+                           float* sums, float* sums_copy, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   UCD_TRY(check_common(fn, dtype, M, C, act));
   UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
   UCD_TRY(check_act_tensor(fn, "dy", dy, ld_dy, dtype, C, false));
@@ -709,8 +754,48 @@ int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const
   }
 #undef LAUNCH_RED
   UCD_TRY(check_launch(fn));
-  reduce_bands_kernel<false><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{});
+  reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{}, sums_copy);
   return check_launch(fn);
+}
+
+int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,
+                       int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
+                       const float* scale, const float* shift, int act, float slope, float* sums, void* workspace,
+                       size_t workspace_bytes, ucd_stream_t stream) {
+  return bwd_reduce_impl("ucd_abn_bwd_reduce", x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale,
+                         shift, act, slope, sums, nullptr, workspace, workspace_bytes, stream);
+}
+
+// ---- SyncBN (one process per GPU): the three library calls around the two collectives of a layer ----
+// forward:  ucd_abn_sync_stats -> all_gather(pack) -> ucd_abn_sync_forward
+// backward: ucd_abn_sync_bwd_reduce -> all_reduce(sums) -> ucd_abn_bwd_apply
+int ucd_abn_sync_stats(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW, float* sums,
+                       float* kshift, float* pack, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  UCD_REQUIRE(sums && kshift && pack, UCD_EINVAL, "ucd_abn_sync_stats: NULL output");
+  FinalizeArgs fin{kshift, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (float)M, 0.f, 0.f, pack};
+  return abn_stats_impl(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, workspace, workspace_bytes, stream, &fin);
+}
+
+int ucd_abn_sync_forward(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r, int dtype, int M, int C,
+                         const float* plane_bias, int HW, const float* gathered, int world, const float* weight,
+                         const float* bias, float* running_mean, float* running_var, float momentum, float eps, float* buf,
+                         int act, float slope, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_sync_forward";
+  UCD_REQUIRE(gathered && buf && world >= 1 && C > 0 && M > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  float *mean = buf + 3 * C, *invstd = buf + 4 * C, *scale = buf + 5 * C;
+  FinalizeArgs fin{nullptr, weight, running_mean, running_var, mean, invstd, scale, (float)M * (float)world, momentum, eps,
+                   nullptr};
+  abn_combine_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(gathered, world, C, (float)M, fin);
+  UCD_TRY(check_launch(fn));
+  return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, mean, scale, bias, act, slope, stream);
+}
+
+int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,
+                            int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
+                            const float* scale, const float* shift, int act, float slope, float* sums, float* local_sums,
+                            void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  return bwd_reduce_impl("ucd_abn_sync_bwd_reduce", x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd,
+                         scale, shift, act, slope, sums, local_sums, workspace, workspace_bytes, stream);
 }
 
 int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, void* dx, int ld_dx,

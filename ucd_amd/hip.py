@@ -46,6 +46,9 @@ SIGNATURES = {
     "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _p]),
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_abn_sync_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _z, _p]),
+    "ucd_abn_sync_forward": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _f, _p]),
+    "ucd_abn_sync_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "ucd_abn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p,
                                _f, _i, _i, _f, _p]),
     "ucd_abn_forward": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _f, _p, _z, _p]),
@@ -296,6 +299,36 @@ def abn_backward(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane
                               1 if training else 0, 1 if need_sums else 0, act, slope, ws.data_ptr(), nbytes, stream())
     if rc:
         _check(rc, "ucd_abn_backward")
+
+
+def abn_sync_stats(x, ld, M, Cc, plane_bias, HW, sums, kshift, pack):
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    with _timed("ucd_abn_stats", M * Cc * x.element_size()):
+        _check(lib.ucd_abn_sync_stats(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(kshift),
+                                      ptr(pack), ptr(ws), nbytes, stream()), "ucd_abn_sync_stats")
+
+
+def abn_sync_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, gathered, world, weight, bias, running_mean,
+                     running_var, momentum, eps, buf, act, slope):
+    with _timed("ucd_abn_apply", M * Cc * x.element_size() * (2 + (residual is not None))):
+        _check(load().ucd_abn_sync_forward(ptr(x), ld_x, ptr(y), ld_y, ptr(residual), ld_r, dtype_code(x), M, Cc,
+                                           ptr(plane_bias), HW, ptr(gathered), world, ptr(weight), ptr(bias),
+                                           ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(buf),
+                                           act, float(slope), stream()), "ucd_abn_sync_forward")
+
+
+def abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope, sums,
+                        local_sums):
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    with _timed("ucd_abn_bwd_reduce", M * Cc * x.element_size() * (2 + (y is not None))):
+        _check(lib.ucd_abn_sync_bwd_reduce(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, dtype_code(x), M, Cc,
+                                           ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), act,
+                                           float(slope), ptr(sums), ptr(local_sums), ptr(ws), nbytes, stream()),
+               "ucd_abn_sync_bwd_reduce")
 
 
 def abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale):
