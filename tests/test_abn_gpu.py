@@ -189,6 +189,7 @@ def test_sync_forward_backward_kernels_match_global_batch(dtype):
     here for three 'ranks' held in one process, against batch norm over the concatenated batch (fp32 torch) and the
     oracle's combination formula."""
     from oracle.syncbn import combine_rank_moments
+    from ucd_amd import hip
     dev = torch.device("cuda:0")
     torch.manual_seed(11)
     world, B, C, H, W = 3, 2, 64, 9, 7
