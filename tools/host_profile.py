@@ -2,6 +2,10 @@
 import cProfile, pstats, sys, os, io, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("UCD_ABN_FORCE_SYNC") == "1":      # the multi-rank code path (collectives over a 1-rank RCCL group)
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+    dist.init_process_group("nccl", rank=0, world_size=1)
 import bench
 sys.argv = ["bench.py", "--global_batch", "3"]
 args = bench.parse()

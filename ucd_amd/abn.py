@@ -22,6 +22,8 @@ files - SURVEY.md section 8-a5).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -34,6 +36,9 @@ def _act_code(name):
         return hip.ACT_CODES[name]
     except KeyError:
         raise RuntimeError(f"activation {name!r} is not supported by the HIP ABN (leaky_relu, identity)") from None
+
+
+_FORCE_SYNC = os.environ.get("UCD_ABN_FORCE_SYNC") == "1"   # profiling aid: take the multi-rank code path at world 1
 
 
 def _group_size(group):
@@ -77,8 +82,9 @@ class _ABNFunction(torch.autograd.Function):
             ld_y = Cc
         # [sums(2C) | kshift | mean | invstd | scale]
         use_cache = not training and eval_cache is not None
-        buf = None if use_cache else torch.empty((8 if world > 1 else 6) * Cc, dtype=torch.float32, device=dev)
-        if world == 1:
+        sync = training and (world > 1 or (_FORCE_SYNC and dist.is_initialized()))
+        buf = None if use_cache else torch.empty((8 if sync else 6) * Cc, dtype=torch.float32, device=dev)
+        if not sync:
             # one library call: statistics + finalize + apply (training) or running-statistics apply (eval)
             hip.abn_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean,
                             running_var, momentum, eps, training, buf, eval_cache if use_cache else None, act, slope)
@@ -95,7 +101,7 @@ class _ABNFunction(torch.autograd.Function):
         mean = running_mean if not training else None
         needs_y = residual is not None and act != hip.ACT_IDENTITY
         ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, bias, buf, mean)
-        ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, residual is not None,
+        ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, sync, residual is not None,
                    plane_bias is not None, x.shape[0])
         if y is x_in:
             ctx.mark_dirty(x_in)
@@ -104,11 +110,10 @@ class _ABNFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, y, plane_bias, weight, shift, buf, mean_eval = ctx.saved_tensors
-        M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, world, has_res, has_pb, B = ctx.cfg
+        M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, sync, has_res, has_pb, B = ctx.cfg
         dy, _, _, _, ld_dy = hip.rows_view(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         mean = buf[3 * Cc:4 * Cc] if training else mean_eval
         invstd, scale = buf[4 * Cc:5 * Cc], buf[5 * Cc:]
-        sync = training and world > 1
         sums = torch.empty((4 if sync else 2) * Cc, dtype=torch.float32, device=x.device)
         need_param_grad = weight is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dx = hip.empty_like_rows(x)
