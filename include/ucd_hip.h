@@ -32,6 +32,7 @@ extern "C" {
 #define UCD_VERSION 100 /* 0.1.0 */
 
 typedef void* ucd_stream_t; /* hipStream_t */
+typedef void* ucd_comm_t;   /* RCCL communicator owned by this library (ucd_comm_init) */
 
 enum ucd_dtype { UCD_F32 = 0, UCD_BF16 = 1 };
 enum ucd_act { UCD_ACT_IDENTITY = 0, UCD_ACT_LEAKY_RELU = 1 };
@@ -42,6 +43,7 @@ enum ucd_error {
   UCD_EALIGN = -2,      /* pointer / leading dimension / channel count not 16-byte friendly */
   UCD_EWORKSPACE = -3,  /* workspace too small */
   UCD_EUNSUPPORTED = -4 /* shape outside what the kernels are built for */
+#define UCD_ERCCL_BASE 100000 /* RCCL failures are returned as UCD_ERCCL_BASE + ncclResult_t */
 };
 
 int ucd_version(void);
@@ -163,6 +165,35 @@ int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, 
                             const float* mean, const float* invstd, const float* scale, const float* shift,
                             int act, float slope, float* sums /* [2*C] */, float* local_sums /* [2*C] */,
                             void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* ---- library-owned RCCL communicator (one process per GPU) ------------------------------------------
+ * Replaces the per-layer torch.distributed collectives of InPlaceABNSync (the reference reaches NCCL through the
+ * inplace-abn extension, segmentation_module.py:17): the exchange runs on the caller's stream inside the layer call.
+ *   ucd_comm_load(path)      bind RCCL from the shared object the process already uses (NULL/"" = default search)
+ *   rank 0: ucd_comm_unique_id(id, 128); every rank receives the 128 bytes (e.g. one torch.distributed broadcast)
+ *   every rank: ucd_comm_init(id, 128, nranks, rank, &comm)         (collective; current HIP device = the rank's GPU) */
+int ucd_comm_load(const char* rccl_path);
+int ucd_comm_unique_id(void* id_out, size_t bytes);
+int ucd_comm_init(const void* id, size_t bytes, int nranks, int rank, ucd_comm_t* comm_out);
+int ucd_comm_destroy(ucd_comm_t comm);
+int ucd_comm_all_gather(ucd_comm_t comm, const float* send, float* recv /* [nranks*count] */, size_t count,
+                        ucd_stream_t stream);
+int ucd_comm_all_reduce_sum(ucd_comm_t comm, float* buf, size_t count, ucd_stream_t stream);
+
+/* Whole SyncBN layer in one call each way, collectives included (comm from ucd_comm_init, world = its size):
+ *   forward   ucd_abn_sync_stats -> all-gather -> ucd_abn_sync_forward; buf = [6*C | pack 2*C | gathered world*2*C]
+ *   backward  ucd_abn_sync_bwd_reduce -> all-reduce -> ucd_abn_bwd_apply(count = world*M);
+ *             sums4 = [sums 2*C (global on return) | this rank's d bias, d weight 2*C] */
+int ucd_abn_sync_forward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, void* y, int ld_y,
+                              const void* residual, int ld_r, int dtype, int M, int C, const float* plane_bias, int HW,
+                              const float* weight, const float* bias, float* running_mean, float* running_var,
+                              float momentum, float eps, float* buf, int act, float slope,
+                              void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+int ucd_abn_sync_backward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, const void* dy, int ld_dy,
+                               const void* y, int ld_y, void* dx, int ld_dx, void* dz_out, int ld_dz, int dtype, int M,
+                               int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
+                               const float* scale, const float* bias, const float* weight, float* sums4, int act,
+                               float slope, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
 /* Per-(image, channel) reduction over the HW rows of each image: out[b, c] = alpha * sum_hw x.
  * Global average pooling of the ASPP image-level branch (modules/deeplab.py:72-76) with alpha = 1/HW,

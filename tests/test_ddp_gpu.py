@@ -89,3 +89,47 @@ def test_two_ranks_equal_single_process(tmp_path):
 
 def test_two_ranks_with_rank_local_contrastive(tmp_path):
     _run(tmp_path, 0.01, 29722)
+
+
+_DIRECT_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ["UCD_ABN_FORCE_SYNC"] = "1"          # take the multi-rank code path with a 1-rank RCCL communicator
+from ucd_amd import abn, comm, synth
+dist.init_process_group("nccl", rank=0, world_size=1)
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+c = comm.direct_comm(None)
+assert c is not None and c.world == 1, "library-owned RCCL communicator was not created"
+for dtype in (torch.float32, torch.bfloat16):
+    x0 = synth.t_normal(3, (4, 64, 9, 11), stream=1).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    r0 = synth.t_normal(4, (4, 64, 9, 11), stream=1).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(5, (4, 64, 9, 11), stream=1).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for sync in (True, False):
+        abn._FORCE_SYNC = sync
+        m = abn.InPlaceABNSync(64).to(dev)
+        with torch.no_grad():
+            m.weight.copy_(torch.linspace(0.5, 1.5, 64)); m.bias.copy_(torch.linspace(-1, 1, 64))
+        x = x0.clone().requires_grad_(True); r = r0.clone().requires_grad_(True)
+        y = m(x * 1.0, residual=r * 1.0, activation="leaky_relu", activation_param=0.01)
+        y.backward(dy)
+        outs.append((y.detach().float(), x.grad.float(), r.grad.float(), m.weight.grad.clone(), m.bias.grad.clone(),
+                     m.running_mean.clone(), m.running_var.clone()))
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for a, b in zip(*outs):
+        assert (a - b).norm().item() <= tol * max(b.norm().item(), 1e-6), (dtype, (a - b).abs().max().item())
+print("DIRECT_RCCL_OK")
+dist.destroy_process_group()
+"""
+
+
+def test_library_owned_rccl_communicator_world1(tmp_path):
+    """ucd_comm_* + ucd_abn_sync_{forward,backward}_comm over a real (1-rank) RCCL communicator on the compute stream
+    give the single-process batch norm; exercises the RCCL binding, unique-id plumbing and the fused layer calls that a
+    multi-GPU node uses (more than one rank per GPU is refused by RCCL, so this is the most a 1-GPU box can run)."""
+    script = tmp_path / "direct_worker.py"
+    script.write_text(_DIRECT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29723", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DIRECT_RCCL_OK" in r.stdout

@@ -29,6 +29,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import hip
+from .comm import direct_comm
 
 
 def _act_code(name):
@@ -83,14 +84,19 @@ class _ABNFunction(torch.autograd.Function):
         # [sums(2C) | kshift | mean | invstd | scale]
         use_cache = not training and eval_cache is not None
         sync = training and (world > 1 or (_FORCE_SYNC and dist.is_initialized()))
-        buf = None if use_cache else torch.empty((8 if sync else 6) * Cc, dtype=torch.float32, device=dev)
-        if not sync:
+        comm = direct_comm(group if group is not None else None) if sync else None
+        buf = None if use_cache else torch.empty(((8 + 2 * world) if sync else 6) * Cc, dtype=torch.float32, device=dev)
+        if comm is not None:
+            # the whole layer, statistics exchange included, in one library call on this stream
+            hip.abn_sync_forward_comm(comm.handle, world, x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight,
+                                      bias, running_mean, running_var, momentum, eps, buf, act, slope)
+        elif not sync:
             # one library call: statistics + finalize + apply (training) or running-statistics apply (eval)
             hip.abn_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean,
                             running_var, momentum, eps, training, buf, eval_cache if use_cache else None, act, slope)
         else:
             # statistics of this rank -> all_gather -> combination + finalize + apply: two library calls, one collective
-            pack = buf[6 * Cc:]
+            pack = buf[6 * Cc:8 * Cc]
             hip.abn_sync_stats(x, ld_x, M, Cc, plane_bias, HW, buf[:2 * Cc], buf[2 * Cc:3 * Cc], pack)
             gathered = _all_gather_stats(pack, world, group)
             hip.abn_sync_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, gathered, world, weight, bias,
@@ -103,6 +109,7 @@ class _ABNFunction(torch.autograd.Function):
         ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, bias, buf, mean)
         ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, sync, residual is not None,
                    plane_bias is not None, x.shape[0])
+        ctx.comm = comm
         if y is x_in:
             ctx.mark_dirty(x_in)
         return y
@@ -119,7 +126,14 @@ class _ABNFunction(torch.autograd.Function):
         dx = hip.empty_like_rows(x)
         dz = hip.empty_like_rows(x) if has_res else None
         ld_yy = ld_y if y is not None else 0
-        if not sync:
+        if sync and ctx.comm is not None:
+            hip.abn_sync_backward_comm(ctx.comm.handle, ctx.comm.world, x, ld_x, dy, ld_dy, y, ld_yy, dx, Cc, dz,
+                                       Cc if has_res else 0, M, Cc, plane_bias, HW, mean, invstd, scale, shift, weight, sums,
+                                       act, slope)
+            dbias = dweight = None
+            if need_param_grad:
+                dbias, dweight = sums[2 * Cc:3 * Cc], sums[3 * Cc:]
+        elif not sync:
             hip.abn_backward(x, ld_x, dy, ld_dy, y, ld_yy, dx, Cc, dz, Cc if has_res else 0, M, Cc, plane_bias, HW, mean,
                              invstd, scale, shift, weight, sums, count, training, need_param_grad, act, slope)
             dbias = dweight = None

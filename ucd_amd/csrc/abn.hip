@@ -790,6 +790,32 @@ int ucd_abn_sync_forward(const void* x, int ld_x, void* y, int ld_y, const void*
   return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, mean, scale, bias, act, slope, stream);
 }
 
+int ucd_abn_sync_forward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, void* y, int ld_y, const void* residual,
+                              int ld_r, int dtype, int M, int C, const float* plane_bias, int HW, const float* weight,
+                              const float* bias, float* running_mean, float* running_var, float momentum, float eps,
+                              float* buf, int act, float slope, void* workspace, size_t workspace_bytes,
+                              ucd_stream_t stream) {
+  UCD_REQUIRE(comm && buf && world >= 1, UCD_EINVAL, "ucd_abn_sync_forward_comm: bad arguments");
+  float *pack = buf + 6 * C, *gathered = buf + 8 * C;
+  UCD_TRY(ucd_abn_sync_stats(x, ld_x, dtype, M, C, plane_bias, HW, buf, buf + 2 * C, pack, workspace, workspace_bytes, stream));
+  UCD_TRY(comm_all_gather_f32(comm, pack, gathered, (size_t)2 * C, (hipStream_t)stream));
+  return ucd_abn_sync_forward(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, gathered, world, weight, bias,
+                              running_mean, running_var, momentum, eps, buf, act, slope, stream);
+}
+
+int ucd_abn_sync_backward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, const void* dy, int ld_dy, const void* y,
+                               int ld_y, void* dx, int ld_dx, void* dz_out, int ld_dz, int dtype, int M, int C,
+                               const float* plane_bias, int HW, const float* mean, const float* invstd, const float* scale,
+                               const float* bias, const float* weight, float* sums4, int act, float slope, void* workspace,
+                               size_t workspace_bytes, ucd_stream_t stream) {
+  UCD_REQUIRE(comm && sums4 && world >= 1, UCD_EINVAL, "ucd_abn_sync_backward_comm: bad arguments");
+  UCD_TRY(ucd_abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale, bias, act,
+                                  slope, sums4, sums4 + 2 * C, workspace, workspace_bytes, stream));
+  UCD_TRY(comm_all_reduce_sum_f32(comm, sums4, (size_t)2 * C, (hipStream_t)stream));
+  return ucd_abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz_out, ld_dz, dtype, M, C, plane_bias, HW, mean, invstd,
+                           scale, bias, weight, sums4, (float)M * (float)world, 0, act, slope, stream);
+}
+
 int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,
                             int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
                             const float* scale, const float* shift, int act, float slope, float* sums, float* local_sums,

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <string.h>
 
 #include "../../include/ucd_hip.h"
 
@@ -23,6 +24,10 @@ int check_launch(const char* what);  // hipGetLastError -> 0 or positive hipErro
       return (code);                      \
     }                                     \
   } while (0)
+
+// RCCL on the caller's stream (comm.hip)
+int comm_all_gather_f32(void* comm, const float* send, float* recv, size_t count, hipStream_t s);
+int comm_all_reduce_sum_f32(void* comm, float* buf, size_t count, hipStream_t s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

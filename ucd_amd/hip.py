@@ -46,6 +46,16 @@ SIGNATURES = {
     "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _p]),
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_comm_load": (_i, [C.c_char_p]),
+    "ucd_comm_unique_id": (_i, [_p, _z]),
+    "ucd_comm_init": (_i, [_p, _z, _i, _i, C.POINTER(C.c_void_p)]),
+    "ucd_comm_destroy": (_i, [_p]),
+    "ucd_comm_all_gather": (_i, [_p, _p, _p, _z, _p]),
+    "ucd_comm_all_reduce_sum": (_i, [_p, _p, _z, _p]),
+    "ucd_abn_sync_forward_comm": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _f,
+                                       _p, _z, _p]),
+    "ucd_abn_sync_backward_comm": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p,
+                                        _p, _i, _f, _p, _z, _p]),
     "ucd_abn_sync_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _z, _p]),
     "ucd_abn_sync_forward": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _f, _p]),
     "ucd_abn_sync_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
@@ -299,6 +309,29 @@ def abn_backward(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane
                               1 if training else 0, 1 if need_sums else 0, act, slope, ws.data_ptr(), nbytes, stream())
     if rc:
         _check(rc, "ucd_abn_backward")
+
+
+def abn_sync_forward_comm(comm, world, x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean,
+                          running_var, momentum, eps, buf, act, slope):
+    """Whole SyncBN forward of a layer (statistics, all-gather on the current stream, combination, apply)."""
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    _check(lib.ucd_abn_sync_forward_comm(comm, world, ptr(x), ld_x, ptr(y), ld_y, ptr(residual), ld_r, dtype_code(x), M, Cc,
+                                         ptr(plane_bias), HW, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+                                         float(momentum), float(eps), ptr(buf), act, float(slope), ptr(ws), nbytes, stream()),
+           "ucd_abn_sync_forward_comm")
+
+
+def abn_sync_backward_comm(comm, world, x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane_bias, HW, mean, invstd,
+                           scale, bias, weight, sums4, act, slope):
+    lib = load()
+    nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
+    ws = workspace(nbytes, x.device)
+    _check(lib.ucd_abn_sync_backward_comm(comm, world, ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, ptr(dx), ld_dx, ptr(dz),
+                                          ld_dz, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale),
+                                          ptr(bias), ptr(weight), ptr(sums4), act, float(slope), ptr(ws), nbytes, stream()),
+           "ucd_abn_sync_backward_comm")
 
 
 def abn_sync_stats(x, ld, M, Cc, plane_bias, HW, sums, kshift, pack):
