@@ -44,6 +44,7 @@ enum ucd_error {
   UCD_EWORKSPACE = -3,  /* workspace too small */
   UCD_EUNSUPPORTED = -4 /* shape outside what the kernels are built for */
 #define UCD_ERCCL_BASE 100000 /* RCCL failures are returned as UCD_ERCCL_BASE + ncclResult_t */
+#define UCD_EBLAS_BASE 200000 /* hipBLASLt failures are returned as UCD_EBLAS_BASE + hipblasStatus_t */
 };
 
 int ucd_version(void);
@@ -165,6 +166,20 @@ int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, 
                             const float* mean, const float* invstd, const float* scale, const float* shift,
                             int act, float slope, float* sums /* [2*C] */, float* local_sums /* [2*C] */,
                             void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* ---- row-major bf16 GEMMs of the wide 1x1 convolutions (modules/residual.py:57-63 builds them as nn.Conv2d(k=1);
+ * on the channels-last row matrix [B*H*W, C] they are plain GEMMs), fp32 accumulation, bf16 output, through hipBLASLt
+ * with the algorithm picked once per shape by timing the library's candidates (tune != 0) and cached:
+ *   mode 0:  C[M,N] = A[M,K] . B[N,K]^T     forward          rows x weight^T
+ *   mode 1:  C[M,N] = A[M,K] . B[K,N]       input gradient   dY x weight
+ *   mode 2:  C[M,N] = A[K,M]^T . B[K,N]     weight gradient  dY^T x rows   (K = B*H*W)
+ * lda/ldb/ldc = row pitch in elements.  ucd_gemm_load binds hipBLASLt from the shared object the process already uses. */
+int ucd_gemm_load(const char* hipblaslt_path);
+size_t ucd_gemm_workspace_bytes(void);
+int ucd_gemm_bf16(int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                  void* workspace, size_t workspace_bytes, int tune, ucd_stream_t stream);
+float ucd_gemm_last_tuned_us(void);
+int ucd_gemm_last_candidates(void);
 
 /* ---- library-owned RCCL communicator (one process per GPU) ------------------------------------------
  * Replaces the per-layer torch.distributed collectives of InPlaceABNSync (the reference reaches NCCL through the

@@ -46,6 +46,11 @@ SIGNATURES = {
     "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _p]),
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_gemm_load": (_i, [C.c_char_p]),
+    "ucd_gemm_workspace_bytes": (_z, []),
+    "ucd_gemm_bf16": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _z, _i, _p]),
+    "ucd_gemm_last_tuned_us": (_f, []),
+    "ucd_gemm_last_candidates": (_i, []),
     "ucd_comm_load": (_i, [C.c_char_p]),
     "ucd_comm_unique_id": (_i, [_p, _z]),
     "ucd_comm_init": (_i, [_p, _z, _i, _i, C.POINTER(C.c_void_p)]),
@@ -309,6 +314,45 @@ def abn_backward(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane
                               1 if training else 0, 1 if need_sums else 0, act, slope, ws.data_ptr(), nbytes, stream())
     if rc:
         _check(rc, "ucd_abn_backward")
+
+
+_gemm_ready = None
+
+
+def _loaded_library_path(fragment):
+    """Path of a shared object this process already has mapped (PyTorch-ROCm ships its own hipBLASLt / RCCL; a second
+    instance of either must not be mixed in)."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if fragment in line:
+                    return line.split()[-1]
+    except OSError:
+        pass
+    return ""
+
+
+def gemm_available():
+    global _gemm_ready
+    if _gemm_ready is None:
+        try:
+            _check(load().ucd_gemm_load(_loaded_library_path("libhipblaslt").encode()), "ucd_gemm_load")
+            _gemm_ready = True
+        except (RuntimeError, ImportError, OSError):
+            _gemm_ready = False
+    return _gemm_ready
+
+
+def gemm_bf16(mode, a, b, out, tune=True):
+    """Row-major bf16 GEMM into ``out`` (see ucd_gemm_bf16): mode 0 a[M,K] b[N,K]^T, 1 a[M,K] b[K,N], 2 a[K,M]^T b[K,N]."""
+    lib = load()
+    M, N = out.shape
+    K = a.shape[0] if mode == 2 else a.shape[1]
+    nbytes = lib.ucd_gemm_workspace_bytes()
+    ws = workspace(nbytes, out.device, "gemm")
+    _check(lib.ucd_gemm_bf16(mode, M, N, K, ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(out), out.stride(0), ptr(ws), nbytes,
+                             1 if tune else 0, stream()), "ucd_gemm_bf16")
+    return out
 
 
 def abn_sync_forward_comm(comm, world, x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean,
