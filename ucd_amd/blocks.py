@@ -39,6 +39,21 @@ def _wgrad_split(M: int) -> int:
     return 1
 
 
+def _lib_gemm():
+    """``ucd_amd.hip`` when its hipBLASLt entry point (tuned once per shape, ~12 us of host time per call instead of
+    ~19 through the framework) can be used, else None (then the same products go through torch)."""
+    from . import hip
+    return hip if hip.gemm_available() else None
+
+
+def _mm_nt(rows, w):
+    """rows[M, K] @ w[N, K]^T (bf16)."""
+    lib = _lib_gemm() if rows.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 else None
+    if lib is None:
+        return rows @ w.t()
+    return lib.gemm_bf16(0, rows, w, torch.empty(rows.shape[0], w.shape[0], dtype=rows.dtype, device=rows.device))
+
+
 class _Gemm1x1(torch.autograd.Function):
     """rows[M, Ci] x w[Co, Ci, 1, 1]^T with the weight gradient computed as a split-K batched GEMM and returned in
     the weight's own 4-D layout (so autograd adopts it without a re-striding copy)."""
@@ -46,22 +61,27 @@ class _Gemm1x1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rows, w4):
         ctx.save_for_backward(rows, w4)
-        return rows @ w4.reshape(w4.shape[0], w4.shape[1]).t()
+        return _mm_nt(rows, w4.reshape(w4.shape[0], w4.shape[1]))
 
     @staticmethod
     def backward(ctx, dy):
         rows, w4 = ctx.saved_tensors
         w = w4.reshape(w4.shape[0], w4.shape[1])
         dy = dy.contiguous()
-        dx = dy @ w if ctx.needs_input_grad[0] else None
+        lib = _lib_gemm() if dy.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dy @ w if lib is None else lib.gemm_bf16(1, dy, w, torch.empty_like(rows))
         dw = None
         if ctx.needs_input_grad[1]:
             M, Co = dy.shape
             S = _wgrad_split(M)
-            if S == 1:
+            if S > 1:        # K = B*H*W is long: 8 batched chunks + a sum beat every single-kernel candidate (41 vs 96 us)
+                dw = torch.bmm(dy.view(S, M // S, Co).transpose(1, 2), rows.view(S, M // S, rows.shape[1])).sum(0)
+            elif lib is None:
                 dw = dy.t() @ rows
             else:
-                dw = torch.bmm(dy.view(S, M // S, Co).transpose(1, 2), rows.view(S, M // S, rows.shape[1])).sum(0)
+                dw = lib.gemm_bf16(2, dy, rows, torch.empty(Co, rows.shape[1], dtype=dy.dtype, device=dy.device))
             dw = dw.as_strided(w4.shape, w4.stride())     # [Co, Ci, 1, 1] is one memory order in either format
         return dx, dw
 
@@ -121,7 +141,11 @@ class Conv1x1(Conv2d):
             y = _Gemm1x1.apply(rows, w16 if w16 is not None else self.weight.to(rows.dtype))
         else:
             w = w16 if (w16 is not None and rows.dtype == w16.dtype) else self.weight
-            y = F.linear(rows, w.reshape(self.out_channels, C), self.bias)
+            w = w.reshape(self.out_channels, C)
+            if self.bias is None and not torch.is_grad_enabled() and w.dtype == rows.dtype == torch.bfloat16:
+                y = _mm_nt(rows, w)                          # the frozen teacher
+            else:
+                y = F.linear(rows, w, self.bias)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 
