@@ -183,8 +183,9 @@ _workspaces = {}
 
 
 def workspace(nbytes, device, tag="abn"):
-    """Grow-only scratch buffer per (device, tag); calls on one stream are ordered, so it is shared."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    """Grow-only scratch buffer per (device, tag, stream): calls on one stream are ordered, so they share it; work on
+    another stream (the teacher running beside the student) gets its own."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag, stream())
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -72,6 +72,10 @@ class Trainer:
         self.graph_teacher = bool(getattr(opts, "graph_teacher", True)) and device.type == "cuda" and model_old is not None
         self._tg = None
         self._tg_seen = 0
+        # the teacher has no dependence on the student before the losses: it runs on a side stream next to the student's
+        # forward, filling the gaps that the small 33x33 layers of either network leave on the GPU
+        self.overlap_teacher = bool(getattr(opts, "overlap_teacher", True)) and device.type == "cuda" and model_old is not None
+        self._side = torch.cuda.Stream(device) if self.overlap_teacher else None
         self.ret_intermediate = self.lde
         self.unce = bool(opts.unce and self.old_classes != 0)
         # fused up-sampling + CE + KD kernel whenever the loss pair is one it implements:
@@ -142,7 +146,13 @@ class Trainer:
         fuse = self.fuse_logit_losses
         up = {} if not fuse else {"upsample": False}
         if model_old is not None:
-            outputs_old, features_old = self._teacher_forward(images, up)
+            if self._side is not None:
+                main = torch.cuda.current_stream(self.device)
+                self._side.wait_stream(main)                      # the batch is ready; last step's readers are done
+                with torch.cuda.stream(self._side):
+                    outputs_old, features_old = self._teacher_forward(images, up)
+            else:
+                outputs_old, features_old = self._teacher_forward(images, up)
         if hasattr(model, "zero_grad") and hasattr(model, "finish_grad_sync"):
             model.zero_grad()
         else:
@@ -154,6 +164,8 @@ class Trainer:
                 outputs, features = model(images, x_b_old=_raw(features_old, "body"),
                                           x_pl_old=_raw(features_old, "pre_logits"),
                                           ret_intermediate=self.ret_intermediate, **up)
+        if model_old is not None and self._side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side)     # teacher outputs are needed from here on
         if fuse:
             # one pass over the label map: bilinear up-sampling + CE (+ KD) + gradient w.r.t. the low-res logits
             total, ce, kd = fused_seg_losses(features["sem"], features_old["sem"] if self.lkd_flag else None, labels,
