@@ -142,8 +142,8 @@ class Conv1x1(Conv2d):
         else:
             w = w16 if (w16 is not None and rows.dtype == w16.dtype) else self.weight
             w = w.reshape(self.out_channels, C)
-            if self.bias is None and not torch.is_grad_enabled() and w.dtype == rows.dtype == torch.bfloat16:
-                y = _mm_nt(rows, w)                          # the frozen teacher
+            if self.bias is None and not torch.is_grad_enabled() and rows.dtype == torch.bfloat16:
+                y = _mm_nt(rows, w if w.dtype == rows.dtype else w.to(rows.dtype))      # the frozen teacher
             else:
                 y = F.linear(rows, w, self.bias)
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
