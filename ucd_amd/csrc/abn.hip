@@ -26,21 +26,14 @@ struct Geom {
   int TX, TY, gx, gy, rows_per_band;
 };
 
-static int tune(const char* name, int dflt) {   // TEMP: exploration knob
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
+// Launch geometry.  Measured on MI355X over every layer shape of the network (B = 24, 513^2; tools/abn_bench.py):
+// two 256-thread blocks per CU (512 blocks in all) stream fastest - more resident waves make the 13-107 MB layers
+// up to 2x SLOWER (DRAM page / TLB thrash of too many concurrent row streams), fewer leave HBM idle - and a band must
+// be a whole number of 4-row batches so that no lane falls into the one-row-at-a-time tail loop.
 template <int VEC>
-Geom make_geom(int M, int C, int target_blocks, int min_iters, int max_bands = 4096, const char* who = nullptr) {
+Geom make_geom(int M, int C, int target_blocks, int min_iters, int max_bands = 4096) {
   Geom g;
-  int round_rows = 4;
-  if (who) {
-    char key[64];
-    snprintf(key, sizeof key, "UCD_TB_%s", who); target_blocks = tune(key, target_blocks);
-    snprintf(key, sizeof key, "UCD_MI_%s", who); min_iters = tune(key, min_iters);
-    snprintf(key, sizeof key, "UCD_RR_%s", who); round_rows = tune(key, 4);
-  }
+  const int round_rows = 4;
   int CG = C / VEC;
   g.TX = CG < 64 ? CG : 64;
   g.TY = kBlock / g.TX;
@@ -51,7 +44,7 @@ Geom make_geom(int M, int C, int target_blocks, int min_iters, int max_bands = 4
   if (gy > max_bands) gy = max_bands;
   if (gy < 1) gy = 1;
   g.rows_per_band = ceil_div(M, gy);
-  if (round_rows) g.rows_per_band = ceil_div(g.rows_per_band, round_rows * g.TY) * round_rows * g.TY;
+  g.rows_per_band = ceil_div(g.rows_per_band, round_rows * g.TY) * round_rows * g.TY;
   g.gy = ceil_div(M, g.rows_per_band);
   return g;
 }
@@ -642,7 +635,7 @@ static int abn_stats_impl(const void* x, int ld_x, int dtype, int M, int C, cons
   float* partial = (float*)workspace;
   Geom g;
   if (dtype == UCD_BF16) {
-    g = make_geom<8>(M, C, 512, 8, kMaxBands, "STATS");
+    g = make_geom<8>(M, C, 512, 8, kMaxBands);
     UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
     abn_stats_kernel<__hip_bfloat16><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>(
         (const __hip_bfloat16*)x, ld_x, M, C, plane_bias, HW, g.TX, g.TY, g.rows_per_band, partial, kshift);
@@ -707,7 +700,7 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_APPLY(T, VECN, ACT)                                                                             \
   {                                                                                                            \
-    Geom g = make_geom<VECN>(M, C, 512, 4, 4096, "APPLY") ;                                                    \
+    Geom g = make_geom<VECN>(M, C, 512, 4);                                                                 \
     abn_apply_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, 0, s>>>((const T*)x, ld_x, (T*)y, ld_y,               \
                                                                  (const T*)residual, ld_r, M, C, plane_bias,   \
                                                                  HW, mean, scale, shift, slope, g.TX, g.TY,    \
@@ -739,7 +732,7 @@ static int bwd_reduce_impl(const char* fn, const void* x, int ld_x, const void* 
   Geom g;
 #define LAUNCH_RED(T, VECN, ACT)                                                                                   \
   {                                                                                                                \
-    g = make_geom<VECN>(M, C, 512, 8, kMaxBands, "BRED") ;                                                         \
+    g = make_geom<VECN>(M, C, 512, 8, kMaxBands);                                                                \
     UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);       \
     abn_bwd_reduce_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, kBlock * 2 * VECN * 4, s>>>(                         \
         (const T*)x, ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, M, C, plane_bias, HW, mean, invstd, scale,     \
@@ -843,7 +836,7 @@ int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const 
   const float inv_count = frozen ? 0.f : 1.f / count;
 #define LAUNCH_BWD(T, VECN, ACT)                                                                                   \
   {                                                                                                                \
-    Geom g = make_geom<VECN>(M, C, 512, 4, 4096, "BAPP") ;                                                        \
+    Geom g = make_geom<VECN>(M, C, 512, 4);                                                                    \
     abn_bwd_apply_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, 0, s>>>(                                              \
         (const T*)x, ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, (T*)dx, ld_dx, (T*)dz_out, ld_dz, M, C,        \
         plane_bias, HW, mean, invstd, scale, shift, weight, sums, inv_count, frozen, slope, g.TX, g.TY,           \
