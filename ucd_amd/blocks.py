@@ -275,20 +275,21 @@ class DeeplabV3(nn.Module):
 
     # -- image-level pooling -----------------------------------------------------------------
     def _global_pooling(self, x):
+        """(pooled map, replicate-padding still to apply or None).  Training: the plain global average [B, C, 1, 1].
+        Evaluation: sliding average of (at most) pooling_size, stride 1, replicate-padded back to the input size
+        (reference deeplab.py:77-88).  The reference pads first and runs the branch's two 1x1 convolutions and its
+        norm on the full-size map; they are pointwise, so they commute with the replication and run here on the
+        small pooled map (2x2 at 513^2 with the default --pooling 32) - same values, 270x fewer pixels."""
         if self.training or self.pooling_size is None:
-            # training: plain global average -> [B, C, 1, 1]
             if _is_fused_abn(self.red_bn):
                 from . import abn as _abn
-                return _abn.global_avg_pool(x)
-            return x.flatten(2).mean(dim=-1)[:, :, None, None]
-        # evaluation: sliding average of (at most) pooling_size, stride 1, then replicate-pad
-        # back to the input size (reference deeplab.py:77-88)
+                return _abn.global_avg_pool(x), None
+            return x.flatten(2).mean(dim=-1)[:, :, None, None], None
         ph = min(try_index(self.pooling_size, 0), x.shape[2])
         pw = min(try_index(self.pooling_size, 1), x.shape[3])
         pad = ((pw - 1) // 2, (pw - 1) // 2 + (1 - pw % 2),
                (ph - 1) // 2, (ph - 1) // 2 + (1 - ph % 2))
-        pool = F.avg_pool2d(x, (ph, pw), stride=1)
-        return F.pad(pool, pad=pad, mode="replicate")
+        return F.avg_pool2d(x, (ph, pw), stride=1), pad
 
     def forward(self, x):
         fused = _is_fused_abn(self.map_bn) and _is_fused_abn(self.red_bn)
@@ -300,8 +301,10 @@ class DeeplabV3(nn.Module):
             out = self.map_bn(torch.cat([m(x) for m in self.map_convs], dim=1))
         out = self.red_conv(out)
 
-        pool = self._global_pooling(x)
+        pool, pad = self._global_pooling(x)
         pool = self.pool_red_conv(self.global_pooling_bn(self.global_pooling_conv(pool)))
+        if pad is not None and pool.shape[-2:] != (1, 1):
+            pool = F.pad(pool, pad=pad, mode="replicate")
         if fused and pool.shape[-2:] == (1, 1):
             # per-(image, channel) bias folded into red_bn's statistics and apply passes
             return self.red_bn(out, plane_bias=pool)
