@@ -249,3 +249,35 @@ def test_sync_forward_backward_kernels_match_global_batch(dtype):
         dxs.append(dx.float())
     got, ref = torch.cat(dxs), fr.grad
     assert ((got - ref).norm() / ref.norm()).item() < (1e-4 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_cpp_autograd_node_equals_python_function(dtype, with_res):
+    """ucd_amd/csrc/abn_node.cpp (the host path of the student's training-mode layers) against the Python autograd
+    Function it shadows: same library calls, so outputs, gradients and running statistics are bit-identical."""
+    from ucd_amd import abn
+    node = abn._abn_node()
+    assert node is not None, "the C++ autograd node is not built (python ucd_amd/csrc/build_node.py)"
+    dev = torch.device("cuda:0")
+    shape = (3, 64, 13, 11)
+    x0 = synth.t_normal(21, shape, stream=1).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    r0 = synth.t_normal(22, shape, stream=1).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(23, shape, stream=1).to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for use_node in (True, False):
+        abn._node_mod = node if use_node else None
+        try:
+            m = abn.InPlaceABN(64).to(dev).train()
+            with torch.no_grad():
+                m.weight.copy_(torch.linspace(0.5, 1.5, 64)); m.bias.copy_(torch.linspace(-1, 1, 64))
+            x = x0.clone().requires_grad_(True)
+            r = r0.clone().requires_grad_(True) if with_res else None
+            y = m(x * 1.0, residual=None if r is None else r * 1.0, activation="leaky_relu", activation_param=0.01)
+            y.backward(dy)
+            outs.append([y.detach(), x.grad, m.weight.grad, m.bias.grad, m.running_mean.clone(), m.running_var.clone()]
+                        + ([r.grad] if with_res else []))
+        finally:
+            abn._node_mod = node
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

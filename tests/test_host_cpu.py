@@ -170,3 +170,15 @@ def test_syncbn_statistics_combination_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("SYNC_OK") == 2
+
+
+def test_cpp_autograd_node_builds_and_imports():
+    """The host-side C++ node links against libucd_hip.so and PyTorch and exposes its entry points (no GPU call)."""
+    import subprocess, sys
+    subprocess.run([sys.executable, os.path.join(ROOT, "ucd_amd", "csrc", "build_node.py")], check=True)
+    from ucd_amd import abn
+    node = abn._abn_node()
+    assert node is not None and hasattr(node, "abn_train") and hasattr(node, "dense_channels_last")
+    import torch
+    assert node.dense_channels_last(torch.zeros(2, 8, 3, 3).contiguous(memory_format=torch.channels_last))
+    assert not node.dense_channels_last(torch.zeros(2, 8, 3, 3))

@@ -48,6 +48,26 @@ def _group_size(group):
     return dist.get_world_size(group if group is not None else None)
 
 
+_node_mod = False
+
+
+def _abn_node():
+    """The C++ autograd node (ucd_amd/csrc/abn_node.cpp) or None when it has not been built; the Python Function below
+    is the complete implementation, the node a faster host path for the training-mode layers."""
+    global _node_mod
+    if _node_mod is False:
+        if os.environ.get("UCD_ABN_NODE", "1") == "0":
+            _node_mod = None
+        else:
+            try:
+                hip.load()                                   # libucd_hip.so first: the node links against it
+                from . import _abn_node as mod
+                _node_mod = mod
+            except ImportError:
+                _node_mod = None
+    return _node_mod
+
+
 def _all_gather_stats(pack, world, group):
     """[world, 2C] table of every rank's (mean_r | M2_r) - the one forward collective of a SyncBN layer."""
     flat = torch.empty(world * pack.numel(), dtype=torch.float32, device=pack.device)
@@ -83,8 +103,8 @@ class _ABNFunction(torch.autograd.Function):
             ld_y = Cc
         # [sums(2C) | kshift | mean | invstd | scale]
         use_cache = not training and eval_cache is not None
-        sync = training and (world > 1 or (_FORCE_SYNC and dist.is_initialized()))
-        comm = direct_comm(group if group is not None else None) if sync else None
+        sync = training and group is not False and (world > 1 or (_FORCE_SYNC and dist.is_initialized()))
+        comm = direct_comm(group) if sync else None
         buf = None if use_cache else torch.empty(((8 + 2 * world) if sync else 6) * Cc, dtype=torch.float32, device=dev)
         if comm is not None:
             # the whole layer, statistics exchange included, in one library call on this stream
@@ -327,6 +347,17 @@ class ABN(nn.Module):
         inplace = self._inplace_contract and not torch.is_grad_enabled() and out is None
         if not torch.is_grad_enabled() and not self.training and residual is None and plane_bias is None and out is None:
             return self._forward_eval_nograd(x, act, slope, inplace)
+        if self.training and plane_bias is None and out is None and self.weight is not None and torch.is_grad_enabled():
+            node = _abn_node()
+            if node is not None and node.dense_channels_last(x) and (residual is None or node.dense_channels_last(residual)):
+                group = self._group()
+                world = _group_size(group)
+                sync = group is not False and (world > 1 or (_FORCE_SYNC and dist.is_initialized()))
+                comm = direct_comm(group) if sync else None
+                if comm is not None or not sync:
+                    return node.abn_train(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
+                                          self.momentum, self.eps, act, slope, comm.handle if comm is not None else 0,
+                                          world, hip.stream())
         return _ABNFunction.apply(x, self.weight, self.bias, residual, plane_bias, self.running_mean,
                                   self.running_var, self.training, self.momentum, self.eps, act, slope,
                                   self._group(), out, inplace, None if self.training else self._eval_constants())

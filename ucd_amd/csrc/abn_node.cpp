@@ -1,0 +1,159 @@
+// Autograd node of the training-mode ABN layer in C++ (PyTorch extension, host code only).
+//
+// The kernels live behind the C ABI (include/ucd_hip.h); what this file replaces is the Python wrapper around them on
+// the student's 106 training-mode layers: a Python autograd.Function costs ~38 us forward and ~33 us backward of host
+// time per layer (tools/host_profile2.py), which is what bounds the step once a GPU holds 3-6 images (4-8 GPU runs).
+// Here the forward is one pybind call (~8 us) and the backward never enters Python.  It mirrors
+// ucd_amd/abn.py::_ABNFunction for the case it is used for - batch statistics, dense channels-last input, optional
+// fused residual, optional SyncBN through the library-owned RCCL communicator - and the Python class stays the
+// reference implementation for everything else (eval mode, plane bias, slice outputs, torch.distributed fallback).
+//
+// The reference reaches the same work through inplace_abn's autograd Functions (segmentation_module.py:15-20).
+#include <torch/extension.h>
+
+#include <map>
+#include <mutex>
+
+#include "../../include/ucd_hip.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void check(int rc, const char* what) {
+  TORCH_CHECK(rc == 0, what, " failed (code ", rc, "): ", ucd_last_error());
+}
+
+// grow-only scratch per (device, stream); calls on one stream are ordered
+std::mutex g_mu;
+std::map<std::pair<int, int64_t>, at::Tensor> g_ws;
+
+void* workspace(const at::Tensor& like, size_t bytes, int64_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto key = std::make_pair((int)like.get_device(), stream);
+  auto it = g_ws.find(key);
+  if (it == g_ws.end() || (size_t)it->second.numel() < bytes) {
+    size_t n = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+    g_ws[key] = at::empty({(int64_t)n}, like.options().dtype(at::kByte));
+    it = g_ws.find(key);
+  }
+  return it->second.data_ptr();
+}
+
+bool dense_channels_last(const at::Tensor& x) {
+  if (x.dim() != 4) return false;
+  const auto B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
+  (void)B;
+  return H > 1 && W > 1 && x.stride(1) == 1 && x.stride(3) == C && x.stride(2) == W * C && x.stride(0) == H * W * C &&
+         (reinterpret_cast<uintptr_t>(x.data_ptr()) & 15) == 0 && ((C * x.element_size()) & 15) == 0;
+}
+
+int dtype_code(const at::Tensor& x) {
+  if (x.scalar_type() == at::kBFloat16) return UCD_BF16;
+  TORCH_CHECK(x.scalar_type() == at::kFloat, "ucd abn node: bf16 or fp32 activations only");
+  return UCD_F32;
+}
+
+const float* fptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+
+class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
+ public:
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor weight, at::Tensor bias,
+                            c10::optional<at::Tensor> residual_, at::Tensor running_mean, at::Tensor running_var,
+                            double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
+                            int64_t stream) {
+    TORCH_CHECK(dense_channels_last(x), "ucd abn node: input must be a dense channels-last tensor");
+    at::Tensor residual = residual_.has_value() ? *residual_ : at::Tensor();
+    const bool has_res = residual.defined();
+    if (has_res) TORCH_CHECK(dense_channels_last(residual) && residual.sizes() == x.sizes() && residual.scalar_type() == x.scalar_type(),
+                             "ucd abn node: residual must match the input");
+    const int64_t C = x.size(1), HW = x.size(2) * x.size(3), M = x.size(0) * HW;
+    const bool sync = comm != 0;
+    at::Tensor y = at::empty_like(x);   // preserves channels-last
+    at::Tensor buf = at::empty({(sync ? 8 + 2 * world : 6) * C}, x.options().dtype(at::kFloat));
+    const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)C);
+    void* ws = workspace(x, ws_bytes, stream);
+    const int dt = dtype_code(x);
+    if (sync) {
+      check(ucd_abn_sync_forward_comm((ucd_comm_t)comm, (int)world, x.data_ptr(), (int)C, y.data_ptr(), (int)C,
+                                      has_res ? residual.data_ptr() : nullptr, has_res ? (int)C : 0, dt, (int)M, (int)C, nullptr,
+                                      (int)HW, fptr(weight), fptr(bias), running_mean.data_ptr<float>(),
+                                      running_var.data_ptr<float>(), (float)momentum, (float)eps, buf.data_ptr<float>(), (int)act,
+                                      (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+            "ucd_abn_sync_forward_comm");
+    } else {
+      check(ucd_abn_forward(x.data_ptr(), (int)C, y.data_ptr(), (int)C, has_res ? residual.data_ptr() : nullptr,
+                            has_res ? (int)C : 0, dt, (int)M, (int)C, nullptr, (int)HW, fptr(weight), fptr(bias),
+                            running_mean.data_ptr<float>(), running_var.data_ptr<float>(), (float)momentum, (float)eps, 1,
+                            buf.data_ptr<float>(), nullptr, (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+            "ucd_abn_forward");
+    }
+    const bool needs_y = has_res && act != UCD_ACT_IDENTITY;   // the sign of z is not recoverable from x alone
+    ctx->save_for_backward({x, needs_y ? y : at::Tensor(), weight, bias, buf});
+    ctx->saved_data["act"] = act;
+    ctx->saved_data["slope"] = slope;
+    ctx->saved_data["comm"] = comm;
+    ctx->saved_data["world"] = world;
+    ctx->saved_data["stream"] = stream;
+    ctx->saved_data["has_res"] = has_res;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    at::Tensor x = saved[0], y = saved[1], weight = saved[2], bias = saved[3], buf = saved[4];
+    const int64_t act = ctx->saved_data["act"].toInt(), comm = ctx->saved_data["comm"].toInt();
+    const int64_t world = ctx->saved_data["world"].toInt(), stream = ctx->saved_data["stream"].toInt();
+    const double slope = ctx->saved_data["slope"].toDouble();
+    const bool has_res = ctx->saved_data["has_res"].toBool();
+    const int64_t C = x.size(1), HW = x.size(2) * x.size(3), M = x.size(0) * HW;
+    at::Tensor dy = grads[0];
+    if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
+    if (!dense_channels_last(dy)) dy = dy.contiguous(at::MemoryFormat::ChannelsLast);
+    at::Tensor dx = at::empty_like(x);
+    at::Tensor dz = has_res ? at::empty_like(x) : at::Tensor();
+    const bool sync = comm != 0;
+    at::Tensor sums = at::empty({(sync ? 4 : 2) * C}, x.options().dtype(at::kFloat));
+    float* b = buf.data_ptr<float>();
+    const float *mean = b + 3 * C, *invstd = b + 4 * C, *scale = b + 5 * C;
+    const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)C);
+    void* ws = workspace(x, ws_bytes, stream);
+    const int dt = dtype_code(x);
+    const void* yp = y.defined() ? y.data_ptr() : nullptr;
+    at::Tensor dbias, dweight;
+    if (sync) {
+      check(ucd_abn_sync_backward_comm((ucd_comm_t)comm, (int)world, x.data_ptr(), (int)C, dy.data_ptr(), (int)C, yp, yp ? (int)C : 0,
+                                       dx.data_ptr(), (int)C, has_res ? dz.data_ptr() : nullptr, has_res ? (int)C : 0, dt, (int)M,
+                                       (int)C, nullptr, (int)HW, mean, invstd, scale, fptr(bias), fptr(weight), sums.data_ptr<float>(),
+                                       (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+            "ucd_abn_sync_backward_comm");
+      dbias = sums.narrow(0, 2 * C, C);
+      dweight = sums.narrow(0, 3 * C, C);
+    } else {
+      check(ucd_abn_backward(x.data_ptr(), (int)C, dy.data_ptr(), (int)C, yp, yp ? (int)C : 0, dx.data_ptr(), (int)C,
+                             has_res ? dz.data_ptr() : nullptr, has_res ? (int)C : 0, dt, (int)M, (int)C, nullptr, (int)HW, mean,
+                             invstd, scale, fptr(bias), fptr(weight), sums.data_ptr<float>(), (float)M, 1, 1, (int)act,
+                             (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+            "ucd_abn_backward");
+      dbias = sums.narrow(0, 0, C);
+      dweight = sums.narrow(0, C, C);
+    }
+    at::Tensor none;
+    return {dx, dweight, dbias, has_res ? dz : none, none, none, none, none, none, none, none, none, none};
+  }
+};
+
+at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,
+                     at::Tensor running_mean, at::Tensor running_var, double momentum, double eps, int64_t act, double slope,
+                     int64_t comm, int64_t world, int64_t stream) {
+  return ABNTrainNode::apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world, stream);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "C++ autograd node of the training-mode ABN layer over libucd_hip.so";
+  m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
+  m.def("dense_channels_last", &dense_channels_last);
+}
