@@ -119,7 +119,8 @@ class Trainer:
             static = images.clone()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: RCCL / watchdog threads of a multi-GPU run keep making HIP calls while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 outputs_old, f = self._teacher_eager(static, up)
                 # materialise exactly what the step reads; the lazy attention maps are not part of the graph
                 out = (outputs_old, Features(f.raw("body"), f.raw("pre_logits"), f["sem"]))
