@@ -81,12 +81,20 @@ def build(args, device, per_rank_batch, rank):
 def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
     """Second, instrumented pass (not part of `value`): HIP events around every libucd_hip call on the
     stream it is launched on, plus the algorithmic bytes / flops of each call."""
-    from ucd_amd import hip
+    from ucd_amd import abn, hip
+    # attribution mode: every library call visible and alone on the stream - no C++ node, no teacher graph, no
+    # teacher/student overlap (the timed region above ran with all three)
+    saved = (abn._node_mod, trainer.graph_teacher, trainer._side)
+    abn._abn_node()
+    abn._node_mod, trainer.graph_teacher, trainer._side = None, False, None
     rec = hip.enable_call_timing()
-    for _ in range(steps):
-        trainer.train_step(images, labels, optimizer, scheduler)
-    torch.cuda.synchronize()
-    hip.disable_call_timing()
+    try:
+        for _ in range(steps):
+            trainer.train_step(images, labels, optimizer, scheduler)
+        torch.cuda.synchronize()
+    finally:
+        hip.disable_call_timing()
+        abn._node_mod, trainer.graph_teacher, trainer._side = saved
     out = {}
     for name, calls in rec.items():
         ms = sum(s.elapsed_time(e) for s, e, _ in calls)
@@ -177,6 +185,17 @@ def main():
                     "frac": ach / PEAK_HBM_GBS, "traffic": None}
         roof["avg_launch_us"] = k["avg_us"]
         roof["launches_per_step"] = k["launches"] / min(args.steps, 3)
+        # HBM traffic of that kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+        # --pmc WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_to_json.py); null if absent
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(name.split("[")[0])
+                if rec and rec.get("global_batch") == args.global_batch and world == 1:
+                    roof["traffic"] = rec["bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/r01_pmc_bench.json"
+            except (OSError, ValueError):
+                pass
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
