@@ -187,10 +187,13 @@ def test_fp16_performance_mode_vs_oracle(B, N, h, K, H, new_ids, max_label):
     assert (fn_d.grad.cpu() - ref_in.grad).abs().max().item() / scale < 2e-3
 
 
-def test_fp16_rescale_branch_is_exercised():
-    """Force the online-maximum rescale: anchors whose first contrast tiles are far (cos ~ -1) and whose
-    later tiles are near (cos ~ +1) raise the running negative maximum by ~2/0.07*log2(e) = 41 log2 units,
-    far past the 2^8 threshold, at a chosen tile."""
+@pytest.mark.parametrize("T", [0.07, 0.05])
+def test_fp16_extreme_logit_range(T):
+    """The widest logit range the fp16 sweep can meet: anchors whose first contrast tiles are far (cos ~ -1) and whose
+    later tiles are near (cos ~ +1), i.e. 2/T*log2(e) = 41 (T = 0.07) / 58 (T = 0.05) log2 units between them.
+    T = 0.07 takes the constant-shift form of sweep 1 (far terms underflow, as they may: they are < 2^-28 of the near
+    ones); T = 0.05 is past its limit and takes the online-maximum form, whose rescale (threshold 2^8) fires at a
+    chosen tile."""
     from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare
     B, N, h, K, H = 2, 64, 16, 16, 256
     f_n, f_o, l_po, labels = synth.contrastive_case(4242, B, N, h, h, K, H, H, list(range(16, 21)))
@@ -201,11 +204,11 @@ def test_fp16_rescale_branch_is_exercised():
     f_n[1] -= d[None, :, None, None].expand(1, N, h, h)[0]
     ref_in = f_n.clone().requires_grad_(True)
     prep = OC.pre_contrastive_pixel(ref_in, labels, l_po, f_o)
-    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
-    _, da, neg, G, num = OC.pixcon_loss_backward(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], T)
+    _, da, neg, G, num = OC.pixcon_loss_backward(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], T)
     fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
     pb = pixcon_prepare(fn_d.contiguous(memory_format=torch.channels_last), lab_d, lpo_d, fo_d, sort_by_label=False, fp16=True)
-    loss_out, grad_a, stats = pixcon_loss_raw(pb, 0.07, True, True, need_grad=True, row_stats=True, precision="f16")
+    loss_out, grad_a, stats = pixcon_loss_raw(pb, T, True, True, need_grad=True, row_stats=True, precision="f16")
     m = pb.meta_host()
     assert abs(loss_out[0].item() - ref.item()) / abs(ref.item()) < 1e-3
     torch.testing.assert_close(stats[0, :m.A].cpu().double(), neg, rtol=3e-3, atol=0)

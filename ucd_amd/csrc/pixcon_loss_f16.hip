@@ -37,6 +37,7 @@ constexpr int kN = 256;
 constexpr int kPitchH = kN + 24;   // halfs; 560 B = 140 dwords = 12 (mod 64): ds_read_b128 rows conflict-free
 constexpr int kMaxSplit = 16;
 constexpr float kRescaleTh = 8.f;  // log2 units
+constexpr float kFixedShiftMaxK2 = 24.f;   // log2(e)/T <= 24  <=>  T >= 0.0601: the constant-shift form of sweep 1
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
@@ -73,6 +74,9 @@ __device__ __forceinline__ void tile_fetch(Stage& st, const _Float16* __restrict
   st.b = *reinterpret_cast<const uint4*>(p + 8 * kN);
   st.c = *reinterpret_cast<const uint4*>(p + 16 * kN);
   st.d = *reinterpret_cast<const uint4*>(p + 24 * kN);
+  // the values are not needed before the commit at the end of the iteration, so the scheduler sinks the four loads
+  // down to it (load ; wait ; write) unless memory operations are fenced here
+  asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ void tile_commit(const Stage& st, _Float16* __restrict__ cs) {
   const int row = threadIdx.x >> 5, c = threadIdx.x & 31;
@@ -83,14 +87,19 @@ __device__ __forceinline__ void tile_commit(const Stage& st, _Float16* __restric
   *reinterpret_cast<uint4*>(p + 24 * kPitchH) = st.d;
 }
 
+// The compiler's default schedule for these two GEMMs is `ds_read ; s_waitcnt ; v_mfma` sixteen times over - every LDS
+// round trip (~180 cycles) exposed in front of a 32-cycle MFMA, one wave per SIMD and nobody to hide it.  Both
+// functions therefore issue ALL their LDS reads first and fence the scheduler (sched_barrier) so they stay there;
+// the waitcnt pass then counts the reads down one MFMA at a time.
 __device__ __forceinline__ f32x16 gemm_scores(const _Float16* __restrict__ cs, const f16x8 (&a16)[16], int lane) {
   f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const _Float16* rowp = cs + (lane & 31) * kPitchH + 8 * (lane >> 5);
+  f16x8 c[16];
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
-    const f16x8 c = *reinterpret_cast<const f16x8*>(rowp + 16 * ks);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c, a16[ks], acc, 0, 0, 0);
-  }
+  for (int ks = 0; ks < 16; ++ks) c[ks] = *reinterpret_cast<const f16x8*>(rowp + 16 * ks);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[ks], a16[ks], acc, 0, 0, 0);
   return acc;
 }
 
@@ -104,16 +113,24 @@ __device__ __forceinline__ void gemm_values(f32x16 (&acc)[8], const _Float16* __
     for (int jj = 0; jj < 8; ++jj) bfrag[s][jj] = (_Float16)w[8 * s + jj];
   // this lane supplies the address of row (R0 + q), columns 4p..4p+3 of its 16-lane group's 4x16 block
   const _Float16* base = cs + (4 * half + q) * kPitchH + 16 * g + 4 * p;
+  h4 lo[8][2], hi[8][2];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const _Float16* a0 = base + (16 * s) * kPitchH + 32 * nt;
-      const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)a0);
-      const h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(a0 + 8 * kPitchH));
+      lo[nt][s] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)a0);
+      hi[nt][s] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(a0 + 8 * kPitchH));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
       f16x8 a;
-      a[0] = (_Float16)lo[0]; a[1] = (_Float16)lo[1]; a[2] = (_Float16)lo[2]; a[3] = (_Float16)lo[3];
-      a[4] = (_Float16)hi[0]; a[5] = (_Float16)hi[1]; a[6] = (_Float16)hi[2]; a[7] = (_Float16)hi[3];
+      a[0] = (_Float16)lo[nt][s][0]; a[1] = (_Float16)lo[nt][s][1]; a[2] = (_Float16)lo[nt][s][2]; a[3] = (_Float16)lo[nt][s][3];
+      a[4] = (_Float16)hi[nt][s][0]; a[5] = (_Float16)hi[nt][s][1]; a[6] = (_Float16)hi[nt][s][2]; a[7] = (_Float16)hi[nt][s][3];
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag[s], acc[nt], 0, 0, 0);
     }
   }
@@ -162,6 +179,13 @@ __device__ __forceinline__ void epilogue_a(f32x16& x, const int* __restrict__ la
   }
 }
 
+// FIXED: the rows are L2-normalised, so s2 = cos * log2(e)/T is bounded by k2 and a constant shift m = k2 - 14.5 keeps
+// E = exp2(s2 - m) below 2^15 (fp16 range) for EVERY pair, with full fp16 precision down to cos = 1 - 28.5/k2 (-0.38
+// at T = 0.07; smaller terms are below 2^-28 of the row's self term).  No running maximum, no conditional rescale -
+// and therefore no VALU instruction that touches the 128 accumulator registers inside the loop: with the rescale
+// branch present the register allocator moves all of them AGPR -> VGPR -> AGPR every iteration (~400 v_accvgpr_*
+// per tile).  Used when k2 <= kFixedShiftMaxK2 (T >= 0.06); the running-maximum form stays for sharper temperatures.
+template <bool FIXED>
 __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float16* __restrict__ ch16,
                                                                   const uint8_t* __restrict__ row_label,
                                                                   const ucd_pixcon_meta* __restrict__ meta, float k2,
@@ -199,7 +223,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
   for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) U[nt][r] = 0.f;
-  float neg = 0.f, m_run = -1e30f, mx_all = -INFINITY;
+  float neg = 0.f, m_run = FIXED ? k2 - 14.5f : -1e30f, mx_all = -INFINITY;
 
   auto commit_labels = [&](int buf, int tile) {
     if (threadIdx.x < 64) {   // wave 0: 32 labels + their min / max over the valid rows
@@ -247,16 +271,18 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
       const bool pure = labs[kTJ + 1] < 256 && (labs[kTJ] > w_hi || labs[kTJ + 1] < w_lo);
       if (pure) epilogue_a<true>(x_cur, labs, la, half, k2, tmax, mx_all);
       else epilogue_a<false>(x_cur, labs, la, half, k2, tmax, mx_all);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = tmax > m_run + kRescaleTh ? tmax : m_run;
-      if (__any(m_new != m_run)) {   // rare: lanes that keep their maximum scale by 1
-        const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
-        neg *= sc;
+      if (!FIXED) {
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = tmax > m_run + kRescaleTh ? tmax : m_run;
+        if (__any(m_new != m_run)) {   // rare: lanes that keep their maximum scale by 1
+          const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+          neg *= sc;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt)
+          for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) U[nt][r] *= sc;
-        m_run = m_new;
+            for (int r = 0; r < 16; ++r) U[nt][r] *= sc;
+          m_run = m_new;
+        }
       }
       // ---- block B
 #pragma unroll
@@ -268,6 +294,10 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
       gemm_values(U, cs, x_cur, lane);
       if (has_next) x_cur = x_next;
     }
+    // keep the loop-carried accumulators in the AGPR half of the register file (the allocator otherwise parks other
+    // values there and moves the accumulators in and out around them)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) asm volatile("" : "+a"(U[nt]));
     tile_commit(stage, cs0 + b_new * kTJ * kPitchH);
     commit_labels(b_new, t_new);
     __syncthreads();
@@ -532,13 +562,17 @@ int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float
   const int maxA = BHW;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pixcon16_neg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pixcon16_neg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)pixcon16_neg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)pixcon16_pos_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipGetLastError();
     attr_set = true;
   }
   const size_t lds1n = (size_t)3 * kTJ * kPitchH * 2 + 3 * (kTJ + 4) * 4;
-  pixcon16_neg_kernel<<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
+  if (k2 <= kFixedShiftMaxK2)
+    pixcon16_neg_kernel<true><<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
+  else
+    pixcon16_neg_kernel<false><<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);
   int rc = check_launch(fn);
   if (rc) return rc;
   const size_t lds2 = (size_t)3 * kTJ * kPitchH * 2 + 3 * kTJ * 4 + (size_t)3 * kTJ * (2 * KP16 + 8) * 2;
