@@ -64,27 +64,36 @@ __device__ __forceinline__ void load_anchor_frags(f16x8 (&a16)[16], const _Float
 
 // 32 x 256 fp16 contrast tile = 1024 x 16 B: four 16-byte pieces per thread, kept in four named registers
 // (an indexed array ends up in scratch memory)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct Stage {
-  uint4 a, b, c, d;
+  u32x4 a, b, c, d;
 };
+// The four loads are inline asm on purpose: the values are not needed before the commit at the end of the iteration,
+// and the scheduler sinks ordinary loads down to their first use (load ; wait ; write - the whole HBM/L2 round trip
+// exposed once per tile).  Issued here, they travel under the MFMA work of the iteration; tile_wait() is the matching
+// s_waitcnt and carries the registers as operands so that no use can move above it.
 __device__ __forceinline__ void tile_fetch(Stage& st, const _Float16* __restrict__ ch16, int j0) {
   const int row = threadIdx.x >> 5, c = threadIdx.x & 31;   // piece q covers rows 8q + row
-  const _Float16* p = ch16 + (size_t)(j0 + row) * kN + c * 8;
-  st.a = *reinterpret_cast<const uint4*>(p);
-  st.b = *reinterpret_cast<const uint4*>(p + 8 * kN);
-  st.c = *reinterpret_cast<const uint4*>(p + 16 * kN);
-  st.d = *reinterpret_cast<const uint4*>(p + 24 * kN);
-  // the values are not needed before the commit at the end of the iteration, so the scheduler sinks the four loads
-  // down to it (load ; wait ; write) unless memory operations are fenced here
-  asm volatile("" ::: "memory");
+  const _Float16* p0 = ch16 + (size_t)(j0 + row) * kN + c * 8;
+  const _Float16* p1 = p0 + 8 * kN;
+  const _Float16* p2 = p0 + 16 * kN;
+  const _Float16* p3 = p0 + 24 * kN;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.a) : "v"(p0));
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.b) : "v"(p1));
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.c) : "v"(p2));
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.d) : "v"(p3));
 }
-__device__ __forceinline__ void tile_commit(const Stage& st, _Float16* __restrict__ cs) {
+__device__ __forceinline__ void tile_wait(Stage& st) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.a), "+v"(st.b), "+v"(st.c), "+v"(st.d)::"memory");
+}
+__device__ __forceinline__ void tile_commit(Stage& st, _Float16* __restrict__ cs) {
+  tile_wait(st);
   const int row = threadIdx.x >> 5, c = threadIdx.x & 31;
   _Float16* p = cs + row * kPitchH + c * 8;
-  *reinterpret_cast<uint4*>(p) = st.a;
-  *reinterpret_cast<uint4*>(p + 8 * kPitchH) = st.b;
-  *reinterpret_cast<uint4*>(p + 16 * kPitchH) = st.c;
-  *reinterpret_cast<uint4*>(p + 24 * kPitchH) = st.d;
+  *reinterpret_cast<u32x4*>(p) = st.a;
+  *reinterpret_cast<u32x4*>(p + 8 * kPitchH) = st.b;
+  *reinterpret_cast<u32x4*>(p + 16 * kPitchH) = st.c;
+  *reinterpret_cast<u32x4*>(p + 24 * kPitchH) = st.d;
 }
 
 // The compiler's default schedule for these two GEMMs is `ds_read ; s_waitcnt ; v_mfma` sixteen times over - every LDS
