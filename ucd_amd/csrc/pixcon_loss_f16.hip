@@ -67,27 +67,29 @@ __device__ __forceinline__ void load_anchor_frags(f16x8 (&a16)[16], const _Float
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct Stage {
   u32x4 a, b, c, d;
+  u32x4 side;          // sweep 2: this thread's 16-byte chunk of the tile's teacher-probability rows
+  unsigned lab;        // label byte of contrast row (threadIdx.x & 31) of the tile
 };
-// The four loads are inline asm on purpose: the values are not needed before the commit at the end of the iteration,
-// and the scheduler sinks ordinary loads down to their first use (load ; wait ; write - the whole HBM/L2 round trip
-// exposed once per tile).  Issued here, they travel under the MFMA work of the iteration; tile_wait() is the matching
-// s_waitcnt and carries the registers as operands so that no use can move above it.
-__device__ __forceinline__ void tile_fetch(Stage& st, const _Float16* __restrict__ ch16, int j0) {
+// The values fetched here are not needed before the commit at the end of the iteration, and the compiler sinks loads
+// down to their first use (load ; wait ; write - the whole HBM/L2 round trip exposed once per tile).  A memory-clobbering
+// asm statement right after them pins them here, PROVIDED the pointers are not noalias: the kernels therefore take
+// ch16 / row_label / p16 without __restrict__.  (Inline-asm loads would hide the pending register writes from the
+// compiler - any copy the register allocator inserts before a hand-written s_waitcnt reads stale data; volatile
+// loads become system-scope FLAT loads that bypass the L2.)
+__device__ __forceinline__ void tile_fetch(Stage& st, const _Float16* ch16, const uint8_t* row_label, int j0) {
+  st.lab = row_label[j0 + (threadIdx.x & 31)];
   const int row = threadIdx.x >> 5, c = threadIdx.x & 31;   // piece q covers rows 8q + row
   const _Float16* p0 = ch16 + (size_t)(j0 + row) * kN + c * 8;
-  const _Float16* p1 = p0 + 8 * kN;
-  const _Float16* p2 = p0 + 16 * kN;
-  const _Float16* p3 = p0 + 24 * kN;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.a) : "v"(p0));
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.b) : "v"(p1));
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.c) : "v"(p2));
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st.d) : "v"(p3));
+  st.a = *reinterpret_cast<const u32x4*>(p0);
+  st.b = *reinterpret_cast<const u32x4*>(p0 + 8 * kN);
+  st.c = *reinterpret_cast<const u32x4*>(p0 + 16 * kN);
+  st.d = *reinterpret_cast<const u32x4*>(p0 + 24 * kN);
 }
-__device__ __forceinline__ void tile_wait(Stage& st) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(st.a), "+v"(st.b), "+v"(st.c), "+v"(st.d)::"memory");
+__device__ __forceinline__ void side_fetch(Stage& st, const _Float16* src) {
+  st.side = *reinterpret_cast<const u32x4*>(src);
 }
-__device__ __forceinline__ void tile_commit(Stage& st, _Float16* __restrict__ cs) {
-  tile_wait(st);
+__device__ __forceinline__ void fetch_fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void tile_commit(const Stage& st, _Float16* __restrict__ cs) {
   const int row = threadIdx.x >> 5, c = threadIdx.x & 31;
   _Float16* p = cs + row * kPitchH + c * 8;
   *reinterpret_cast<u32x4*>(p) = st.a;
@@ -195,8 +197,7 @@ __device__ __forceinline__ void epilogue_a(f32x16& x, const int* __restrict__ la
 // branch present the register allocator moves all of them AGPR -> VGPR -> AGPR every iteration (~400 v_accvgpr_*
 // per tile).  Used when k2 <= kFixedShiftMaxK2 (T >= 0.06); the running-maximum form stays for sharper temperatures.
 template <bool FIXED>
-__global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float16* __restrict__ ch16,
-                                                                  const uint8_t* __restrict__ row_label,
+__global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float16* ch16, const uint8_t* row_label,
                                                                   const ucd_pixcon_meta* __restrict__ meta, float k2,
                                                                   int nsplit, int maxA, float* __restrict__ negp,
                                                                   float* __restrict__ mrunp, float* __restrict__ maxp,
@@ -234,9 +235,9 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
     for (int r = 0; r < 16; ++r) U[nt][r] = 0.f;
   float neg = 0.f, m_run = FIXED ? k2 - 14.5f : -1e30f, mx_all = -INFINITY;
 
-  auto commit_labels = [&](int buf, int tile) {
+  auto commit_labels = [&](int buf, unsigned lab_byte) {
     if (threadIdx.x < 64) {   // wave 0: 32 labels + their min / max over the valid rows
-      const int lc = threadIdx.x < kTJ ? (int)row_label[tile * kTJ + threadIdx.x] : kPadLabel;
+      const int lc = threadIdx.x < kTJ ? (int)lab_byte : kPadLabel;
       int lo = lc == kPadLabel ? 256 : lc, hi = lc == kPadLabel ? 256 : lc;   // a padding row forces the slow path
 #pragma unroll
       for (int off = 16; off > 0; off >>= 1) {
@@ -250,14 +251,14 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
 
   Stage stage;
   if (nt_loc > 0) {
-    tile_fetch(stage, ch16, v_begin * kTJ);
+    tile_fetch(stage, ch16, row_label, v_begin * kTJ);
     tile_commit(stage, cs0);
-    commit_labels(0, v_begin);
+    commit_labels(0, stage.lab);
   }
   if (nt_loc > 1) {
-    tile_fetch(stage, ch16, (v_begin + 1) * kTJ);
+    tile_fetch(stage, ch16, row_label, (v_begin + 1) * kTJ);
     tile_commit(stage, cs0 + kTJ * kPitchH);
-    commit_labels(1, v_begin + 1);
+    commit_labels(1, stage.lab);
   }
   __syncthreads();
   f32x16 x_cur;
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
     // unconditional (clamped) prefetch two tiles ahead: no branch inside the pipelined body; past the end it
     // re-fetches the last tile into a slot nobody reads again
     const int t_new = min(v_begin + t + 2, v_end - 1);
-    tile_fetch(stage, ch16, t_new * kTJ);
+    tile_fetch(stage, ch16, row_label, t_new * kTJ);
+    fetch_fence();
     const _Float16* cs = cs0 + b_cur * kTJ * kPitchH;
     const int* labs = labs0 + b_cur * kLabStride;
     if (wave_ok) {
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) asm volatile("" : "+a"(U[nt]));
     tile_commit(stage, cs0 + b_new * kTJ * kPitchH);
-    commit_labels(b_new, t_new);
+    commit_labels(b_new, stage.lab);
     __syncthreads();
   }
   neg += __shfl_xor(neg, 32, 64);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
 // ---- sweep 2 --------------------------------------------------------------------------------------------
 // p16: [Cpad][2][KP16] halfs (hi then lo) ; KP16 = K rounded up to 16
 __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
-    const _Float16* __restrict__ ch16, const uint8_t* __restrict__ row_label, const _Float16* __restrict__ p16, int KP16,
+    const _Float16* ch16, const uint8_t* row_label, const _Float16* p16, int KP16,
     const ucd_pixcon_meta* __restrict__ meta, float k2, int shift_pos, int use_prob, int nsplit1, int nsplit2, int maxA,
     const float* __restrict__ negp, const float* __restrict__ mrunp, const float* __restrict__ maxp,
     float* __restrict__ lossp, float* __restrict__ qsump, float* __restrict__ Vp) {
@@ -383,10 +385,25 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
   float lossacc = 0.f, qsum = 0.f;
   const int nk = KP16 / 16;
 
-  auto commit_side = [&](int buf, int j0) {
-    if (threadIdx.x < kTJ) labs0[buf * kTJ + threadIdx.x] = row_label[j0 + threadIdx.x];
-    if (use_prob) {
-      const int chunks = (2 * KP16) / 8;                    // 16-byte chunks per row
+  // teacher-probability rows of a tile: 2*KP16 halfs per row = `chunks` 16-byte pieces; when the tile has at most one
+  // piece per thread (K <= 32 classes) the piece travels with the tile prefetch, else it is copied at commit time
+  const int chunks = use_prob ? (2 * KP16) / 8 : 0;
+  const bool side_fast = use_prob && chunks * kTJ <= kThreads;
+  const int s_idx = min((int)threadIdx.x, max(kTJ * chunks - 1, 0));
+  const int s_row = chunks ? s_idx / chunks : 0, s_c = chunks ? s_idx - s_row * chunks : 0;
+  Stage stage;
+  auto fetch = [&](int j0) {
+    tile_fetch(stage, ch16, row_label, j0);
+    if (side_fast) side_fetch(stage, p16 + (size_t)(j0 + s_row) * 2 * KP16 + s_c * 8);
+    fetch_fence();
+  };
+  auto commit = [&](int buf, int j0) {
+    tile_commit(stage, cs0 + buf * kTJ * kPitchH);
+    if (threadIdx.x < kTJ) labs0[buf * kTJ + threadIdx.x] = (int)stage.lab;
+    if (side_fast) {
+      if ((int)threadIdx.x < kTJ * chunks)
+        *reinterpret_cast<u32x4*>(ps0 + (buf * kTJ + s_row) * ppitch + s_c * 8) = stage.side;
+    } else if (use_prob) {
       for (int idx = threadIdx.x; idx < kTJ * chunks; idx += kThreads) {
         const int row = idx / chunks, c = idx - row * chunks;
         *reinterpret_cast<uint4*>(ps0 + (buf * kTJ + row) * ppitch + c * 8) =
@@ -395,10 +412,39 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
     }
   };
 
+  // the anchors' own probability fragments do not change over the sweep: loaded once (two 16-class steps cover K <= 32)
+  f16x8 pah[2], pal[2];
+  {
+    const _Float16* pa = p16 + (size_t)(row_ok ? i_row : 0) * 2 * KP16 + 8 * half;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (use_prob && kk < nk) {
+        pah[kk] = *reinterpret_cast<const f16x8*>(pa + 16 * kk);
+        pal[kk] = *reinterpret_cast<const f16x8*>(pa + KP16 + 16 * kk);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { pah[kk][e] = (_Float16)0.f; pal[kk][e] = (_Float16)0.f; }
+      }
+    }
+  }
+
   // P^T tile of contrast tile `buf`: pm[j][i] = sum_k pc[j][k] pa[i][k]  (hi/lo split: 3 MFMAs per 16 classes)
   auto prob_tile = [&](int buf) {
     f32x16 pm = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const _Float16* pc = ps0 + (buf * kTJ + (lane & 31)) * ppitch + 8 * half;
+    if (nk <= 2) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        if (kk < nk) {
+          const f16x8 ch = *reinterpret_cast<const f16x8*>(pc + 16 * kk);
+          const f16x8 cl = *reinterpret_cast<const f16x8*>(pc + KP16 + 16 * kk);
+          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, pah[kk], pm, 0, 0, 0);
+          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(ch, pal[kk], pm, 0, 0, 0);
+          pm = __builtin_amdgcn_mfma_f32_32x32x16_f16(cl, pah[kk], pm, 0, 0, 0);
+        }
+      }
+      return pm;
+    }
     const _Float16* pa = p16 + (size_t)(row_ok ? i_row : 0) * 2 * KP16 + 8 * half;
     for (int kk = 0; kk < nk; ++kk) {
       const f16x8 ch = *reinterpret_cast<const f16x8*>(pc + 16 * kk);
@@ -413,20 +459,17 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
   };
 
   // three-buffer software pipeline (same schedule as sweep 1): scores / probabilities of tile t+1 are issued
-  // beside the epilogue of tile t; tile t+2 travels global -> registers -> LDS meanwhile
+  // beside the epilogue of tile t; tile t+2 (rows, labels, probability rows) travels global -> registers -> LDS meanwhile
   const int nt_loc = v_end - v_begin;
-  Stage stage;
   if (nt_loc > 0) {
     const int j0 = tl.at(v_begin) * kTJ;
-    tile_fetch(stage, ch16, j0);
-    tile_commit(stage, cs0);
-    commit_side(0, j0);
+    fetch(j0);
+    commit(0, j0);
   }
   if (nt_loc > 1) {
     const int j0 = tl.at(v_begin + 1) * kTJ;
-    tile_fetch(stage, ch16, j0);
-    tile_commit(stage, cs0 + kTJ * kPitchH);
-    commit_side(1, j0);
+    fetch(j0);
+    commit(1, j0);
   }
   __syncthreads();
   f32x16 x_cur, pm_cur;
@@ -439,36 +482,40 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
     const bool has_next = t + 1 < nt_loc;
     const int j0 = tl.at(v_begin + t) * kTJ;
     const int j0n = tl.at(min(v_begin + t + 2, v_end - 1)) * kTJ;
-    tile_fetch(stage, ch16, j0n);
+    fetch(j0n);
     const _Float16* cs = cs0 + b_cur * kTJ * kPitchH;
     const int* labs = labs0 + b_cur * kTJ;
     {
       const int bn = has_next ? b_nxt : b_cur;
+      int lcs[16];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) lcs[reg] = labs[tile_row(reg, half)];   // one batch of LDS reads, not 16 round trips
       f32x16 x_next = gemm_scores(cs0 + bn * kTJ * kPitchH, a16, lane);
       f32x16 pm_next;
       if (use_prob) pm_next = prob_tile(bn);
+      // branch-free: every element is evaluated, non-positives contribute zero
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int jl = tile_row(reg, half);
-        const int lc = labs[jl];
+        const int lc = lcs[reg];
         const bool pos = row_ok && lc == la && (j0 + jl) != i_row;
-        float q = 0.f;
-        if (pos) {
-          const float pw = (use_prob && !(gt_i && lc >= min_new)) ? pm_cur[reg] : 1.f;
-          const float sp2 = x_cur[reg] * k2 - m2;
-          const float d = __builtin_amdgcn_exp2f(sp2) + neg_true;
-          lossacc += pw * (sp2 * kLn2 - __logf(d));
-          q = pw * (neg_true / d);
-          qsum += q;
-        }
+        const float pw = (use_prob && !(gt_i && lc >= min_new)) ? pm_cur[reg] : 1.f;
+        const float sp2 = x_cur[reg] * k2 - m2;
+        const float d = __builtin_amdgcn_exp2f(sp2) + neg_true;
+        const float dd = pos ? d : 1.f;                       // keeps log / rcp finite on the unused lanes
+        const float term = pw * (sp2 * kLn2 - __logf(dd));
+        const float q = pos ? pw * (neg_true * __builtin_amdgcn_rcpf(dd)) : 0.f;
+        lossacc += pos ? term : 0.f;
+        qsum += q;
         x_cur[reg] = q;
       }
       gemm_values(V, cs, x_cur, lane);
       x_cur = x_next;
       if (use_prob) pm_cur = pm_next;
     }
-    tile_commit(stage, cs0 + b_new * kTJ * kPitchH);
-    commit_side(b_new, j0n);
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) asm volatile("" : "+a"(V[nt]));   // accumulators stay in the AGPR half (see sweep 1)
+    commit(b_new, j0n);
     __syncthreads();
   }
   lossacc += __shfl_xor(lossacc, 32, 64);
