@@ -98,53 +98,78 @@ __device__ __forceinline__ void tile_commit(const Stage& st, _Float16* __restric
   *reinterpret_cast<u32x4*>(p + 24 * kPitchH) = st.d;
 }
 
-// The compiler's default schedule for these two GEMMs is `ds_read ; s_waitcnt ; v_mfma` sixteen times over - every LDS
-// round trip (~180 cycles) exposed in front of a 32-cycle MFMA, one wave per SIMD and nobody to hide it.  Both
-// functions therefore issue ALL their LDS reads first and fence the scheduler (sched_barrier) so they stay there;
-// the waitcnt pass then counts the reads down one MFMA at a time.
-__device__ __forceinline__ f32x16 gemm_scores(const _Float16* __restrict__ cs, const f16x8 (&a16)[16], int lane) {
-  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const _Float16* rowp = cs + (lane & 31) * kPitchH + 8 * (lane >> 5);
+// The compiler's default schedule for the two GEMMs of a tile is `ds_read ; s_waitcnt ; v_mfma` sixteen times over -
+// every LDS round trip (~180 cycles) exposed in front of a 32-cycle MFMA, one wave per SIMD and nobody to hide it.
+// They are therefore split in a load phase and an MFMA phase: a tile step issues ALL its LDS reads first (the score
+// fragments of tile t+1 and the value fragments of tile t, 48 instructions, fenced with sched_barrier so they stay
+// there); the LDS pipe then streams them while the score MFMAs and the VALU epilogue of tile t run, and the waitcnt
+// pass counts the reads down one MFMA at a time.
+struct ScoreFrags {
   f16x8 c[16];
+};
+struct ValueFrags {
+  h4 lo[8][2], hi[8][2];
+};
+
+__device__ __forceinline__ void load_score_frags(ScoreFrags& f, const _Float16* __restrict__ cs, int lane) {
+  const _Float16* rowp = cs + (lane & 31) * kPitchH + 8 * (lane >> 5);
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) c[ks] = *reinterpret_cast<const f16x8*>(rowp + 16 * ks);
-  __builtin_amdgcn_sched_barrier(0);
+  for (int ks = 0; ks < 16; ++ks) f.c[ks] = *reinterpret_cast<const f16x8*>(rowp + 16 * ks);
+}
+
+__device__ __forceinline__ f32x16 mfma_scores(const ScoreFrags& f, const f16x8 (&a16)[16]) {
+  f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[ks], a16[ks], acc, 0, 0, 0);
+  for (int ks = 0; ks < 16; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.c[ks], a16[ks], acc, 0, 0, 0);
   return acc;
 }
 
-// Y[n][i] += sum_j C[j][n] w[j][i]; w (fp32 accumulator layout, values in fp16 range) is the B operand
-__device__ __forceinline__ void gemm_values(f32x16 (&acc)[8], const _Float16* __restrict__ cs, const f32x16& w, int lane) {
+__device__ __forceinline__ void load_value_frags(ValueFrags& f, const _Float16* __restrict__ cs, int lane) {
   const int half = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-  f16x8 bfrag[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int jj = 0; jj < 8; ++jj) bfrag[s][jj] = (_Float16)w[8 * s + jj];
   // this lane supplies the address of row (R0 + q), columns 4p..4p+3 of its 16-lane group's 4x16 block
   const _Float16* base = cs + (4 * half + q) * kPitchH + 16 * g + 4 * p;
-  h4 lo[8][2], hi[8][2];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const _Float16* a0 = base + (16 * s) * kPitchH + 32 * nt;
-      lo[nt][s] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)a0);
-      hi[nt][s] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(a0 + 8 * kPitchH));
+      f.lo[nt][s] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)a0);
+      f.hi[nt][s] = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(a0 + 8 * kPitchH));
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Y[n][i] += sum_j C[j][n] w[j][i]; w (fp32 accumulator layout, values in fp16 range) is the B operand
+__device__ __forceinline__ void mfma_values(f32x16 (&acc)[8], const ValueFrags& f, const f32x16& w) {
+  f16x8 bfrag[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) bfrag[s][jj] = (_Float16)w[8 * s + jj];
 #pragma unroll
   for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       f16x8 a;
-      a[0] = (_Float16)lo[nt][s][0]; a[1] = (_Float16)lo[nt][s][1]; a[2] = (_Float16)lo[nt][s][2]; a[3] = (_Float16)lo[nt][s][3];
-      a[4] = (_Float16)hi[nt][s][0]; a[5] = (_Float16)hi[nt][s][1]; a[6] = (_Float16)hi[nt][s][2]; a[7] = (_Float16)hi[nt][s][3];
+      a[0] = (_Float16)f.lo[nt][s][0]; a[1] = (_Float16)f.lo[nt][s][1]; a[2] = (_Float16)f.lo[nt][s][2]; a[3] = (_Float16)f.lo[nt][s][3];
+      a[4] = (_Float16)f.hi[nt][s][0]; a[5] = (_Float16)f.hi[nt][s][1]; a[6] = (_Float16)f.hi[nt][s][2]; a[7] = (_Float16)f.hi[nt][s][3];
       acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bfrag[s], acc[nt], 0, 0, 0);
     }
   }
+}
+
+__device__ __forceinline__ f32x16 gemm_scores(const _Float16* __restrict__ cs, const f16x8 (&a16)[16], int lane) {
+  ScoreFrags f;
+  load_score_frags(f, cs, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  return mfma_scores(f, a16);
+}
+
+__device__ __forceinline__ void gemm_values(f32x16 (&acc)[8], const _Float16* __restrict__ cs, const f32x16& w, int lane) {
+  ValueFrags f;
+  load_value_frags(f, cs, lane);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_values(acc, f, w);
 }
 
 __device__ __forceinline__ void store_values(const f32x16 (&acc)[8], float* __restrict__ dst, int half) {
@@ -274,9 +299,13 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
     const _Float16* cs = cs0 + b_cur * kTJ * kPitchH;
     const int* labs = labs0 + b_cur * kLabStride;
     if (wave_ok) {
-      // ---- block A
-      f32x16 x_next;
-      if (has_next) x_next = gemm_scores(cs0 + b_nxt * kTJ * kPitchH, a16, lane);
+      // ---- all LDS reads of the step, then block A
+      ScoreFrags sf;
+      ValueFrags vf;
+      load_score_frags(sf, cs0 + (has_next ? b_nxt : b_cur) * kTJ * kPitchH, lane);
+      if (FIXED) load_value_frags(vf, cs, lane);   // the running-maximum form has no registers to spare for them yet
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 x_next = mfma_scores(sf, a16);
       float tmax = -INFINITY;
       // wave-uniform (LDS broadcast values); hi == 256 marks a tile with padding rows
       const bool pure = labs[kTJ + 1] < 256 && (labs[kTJ] > w_hi || labs[kTJ + 1] < w_lo);
@@ -302,8 +331,9 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
         neg += e;
         x_cur[reg] = e;
       }
-      gemm_values(U, cs, x_cur, lane);
-      if (has_next) x_cur = x_next;
+      if (FIXED) mfma_values(U, vf, x_cur);
+      else gemm_values(U, cs, x_cur, lane);
+      x_cur = x_next;
     }
     // keep the loop-carried accumulators in the AGPR half of the register file (the allocator otherwise parks other
     // values there and moves the accumulators in and out around them)
