@@ -520,7 +520,12 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
       int lcs[16];
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) lcs[reg] = labs[tile_row(reg, half)];   // one batch of LDS reads, not 16 round trips
-      f32x16 x_next = gemm_scores(cs0 + bn * kTJ * kPitchH, a16, lane);
+      ScoreFrags sf;
+      ValueFrags vf;
+      load_score_frags(sf, cs0 + bn * kTJ * kPitchH, lane);
+      load_value_frags(vf, cs, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16 x_next = mfma_scores(sf, a16);
       f32x16 pm_next;
       if (use_prob) pm_next = prob_tile(bn);
       // branch-free: every element is evaluated, non-positives contribute zero
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_pos_kernel(
         qsum += q;
         x_cur[reg] = q;
       }
-      gemm_values(V, cs, x_cur, lane);
+      mfma_values(V, vf, x_cur);
       x_cur = x_next;
       if (use_prob) pm_cur = pm_next;
     }
