@@ -18,6 +18,8 @@
 //   fetched with ds_read_b64_tr_b16 from the row-major LDS tile (hardware transpose, 4 rows x 16 columns
 //   per 16-lane group).
 //   Teacher joint probabilities P = p_i . p_j use a hi/lo fp16 split (3 MFMAs per 16 classes, ~2^-21).
+#include <type_traits>
+
 #include "common.h"
 #include "pixcon.h"
 
@@ -288,9 +290,10 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
   __syncthreads();
   f32x16 x_cur;
   if (nt_loc > 0 && wave_ok) x_cur = gemm_scores(cs0, a16, lane);
-  for (int t = 0; t < nt_loc; ++t) {
-    const int b_cur = t % 3, b_nxt = (t + 1) % 3, b_new = (t + 2) % 3;
-    const bool has_next = t + 1 < nt_loc;
+  // unrolled by the three LDS buffers: buffer indices are compile-time constants, so every LDS address of a step is a
+  // per-lane base plus an immediate offset (a rotating index costs ~100 address VALU instructions per tile)
+  auto step = [&](auto bc_tag, int t) {
+    constexpr int b_cur = decltype(bc_tag)::value, b_nxt = (b_cur + 1) % 3, b_new = (b_cur + 2) % 3;
     // unconditional (clamped) prefetch two tiles ahead: no branch inside the pipelined body; past the end it
     // re-fetches the last tile into a slot nobody reads again
     const int t_new = min(v_begin + t + 2, v_end - 1);
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
       // ---- all LDS reads of the step, then block A
       ScoreFrags sf;
       ValueFrags vf;
-      load_score_frags(sf, cs0 + (has_next ? b_nxt : b_cur) * kTJ * kPitchH, lane);
+      load_score_frags(sf, cs0 + b_nxt * kTJ * kPitchH, lane);   // past the last tile: stale rows, result unused
       if (FIXED) load_value_frags(vf, cs, lane);   // the running-maximum form has no registers to spare for them yet
       __builtin_amdgcn_sched_barrier(0);
       f32x16 x_next = mfma_scores(sf, a16);
@@ -342,6 +345,11 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16_neg_kernel(const _Float1
     tile_commit(stage, cs0 + b_new * kTJ * kPitchH);
     commit_labels(b_new, stage.lab);
     __syncthreads();
+  };
+  for (int t = 0; t < nt_loc; t += 3) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nt_loc) step(std::integral_constant<int, 1>{}, t + 1);
+    if (t + 2 < nt_loc) step(std::integral_constant<int, 2>{}, t + 2);
   }
   neg += __shfl_xor(neg, 32, 64);
   mx_all = fmaxf(mx_all, __shfl_xor(mx_all, 32, 64));
