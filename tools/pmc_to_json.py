@@ -28,6 +28,12 @@ if calls:
     n = max(1, min(kern[k]["dispatches_seen"] for k in calls if "neg" in k or "pos" in k))
     out["ucd_pixcon_loss"] = {"global_batch": int(sys.argv[4]), "bytes_per_launch": sum(kern[k]["bytes"] * kern[k]["dispatches_seen"] / n for k in calls),
                               "kernels": calls}
+# HBM-stream calls: one dominant kernel each (the stage-2 reduce_bands launches move a few KB)
+for call, k in (("ucd_abn_apply", "abn_apply_kernel"), ("ucd_abn_stats", "abn_stats_kernel"),
+                ("ucd_abn_bwd_reduce", "abn_bwd_reduce_kernel"), ("ucd_abn_bwd_apply", "abn_bwd_apply_kernel"),
+                ("ucd_seg_losses", "seg_losses_kernel")):
+    if k in kern:
+        out[call] = {"global_batch": int(sys.argv[4]), "bytes_per_launch": kern[k]["bytes"], "kernels": [k]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "kernels"})[:600])
 for k, v in kern.items():
