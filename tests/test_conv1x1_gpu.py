@@ -33,3 +33,32 @@ def test_conv1x1_gemm_path_matches_conv2d(B, hw, ci, co):
     assert conv.weight.grad.dtype == torch.float32
     assert rel(conv.weight.grad, wr.grad) < 1e-2
     assert _wgrad_split(24 * 33 * 33) == 8 and _wgrad_split(3 * 33 * 33) == 1
+
+
+def test_cpp_gemm_node_equals_python_function():
+    """The C++ autograd node of the 1x1-conv GEMM (ucd_amd/csrc/abn_node.cpp: Gemm1x1Node) issues the same library calls as
+    the Python Function it shadows: outputs and gradients are bit-identical."""
+    from ucd_amd import blocks
+    dev = torch.device("cuda:0")
+    node = blocks._gemm_node()
+    assert node is not None, "C++ node not built (python ucd_amd/csrc/build_node.py)"
+    torch.manual_seed(3)
+    outs = []
+    for use_node in (True, False):
+        blocks._node_cache[0] = node if use_node else None
+        try:
+            conv = Conv1x1(1024, 256).to(dev)
+            with torch.no_grad():
+                conv.weight.copy_(torch.linspace(-1, 1, conv.weight.numel()).view_as(conv.weight) * 0.05)
+            x = torch.randn(3, 1024, 33, 33, device=dev, generator=torch.Generator(dev).manual_seed(5)).to(torch.bfloat16) \
+                .contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            dy = torch.randn(3, 256, 33, 33, device=dev, generator=torch.Generator(dev).manual_seed(6)).to(torch.bfloat16) \
+                .contiguous(memory_format=torch.channels_last)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = conv(x)
+            y.backward(dy)
+            outs.append((y.detach().clone(), x.grad.clone(), conv.weight.grad.clone()))
+        finally:
+            blocks._node_cache[0] = node
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)

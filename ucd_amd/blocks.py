@@ -46,6 +46,23 @@ def _lib_gemm():
     return hip if hip.gemm_available() else None
 
 
+_node_cache = [False]
+
+
+def _gemm_node():
+    """ucd_amd._abn_node (C++ autograd nodes) when built and the tuned-GEMM entry point is usable, else None."""
+    if _node_cache[0] is False:
+        from . import abn
+        mod = abn._abn_node()
+        _node_cache[0] = mod if (mod is not None and hasattr(mod, "gemm1x1") and _lib_gemm() is not None) else None
+    return _node_cache[0]
+
+
+def _hip_stream():
+    from . import hip
+    return hip.stream()
+
+
 def _mm_nt(rows, w):
     """rows[M, K] @ w[N, K]^T (bf16)."""
     lib = _lib_gemm() if rows.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 else None
@@ -138,7 +155,12 @@ class Conv1x1(Conv2d):
         rows = rows.reshape(B * H * W, C)
         w16 = self.working_weight()
         if self.bias is None and rows.dtype != torch.float32 and torch.is_grad_enabled() and self.weight.requires_grad:
-            y = _Gemm1x1.apply(rows, w16 if w16 is not None else self.weight.to(rows.dtype))
+            w4 = w16 if w16 is not None else self.weight.to(rows.dtype)
+            node = _gemm_node() if rows.dtype == torch.bfloat16 else None
+            if node is not None:          # same library calls, autograd node in C++ (host time per layer 71 -> ~25 us)
+                y = node.gemm1x1(rows, w4, _hip_stream())
+            else:
+                y = _Gemm1x1.apply(rows, w4)
         else:
             w = w16 if (w16 is not None and rows.dtype == w16.dtype) else self.weight
             w = w.reshape(self.out_channels, C)

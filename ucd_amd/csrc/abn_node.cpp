@@ -29,9 +29,9 @@ void check(int rc, const char* what) {
 std::mutex g_mu;
 std::map<std::pair<int, int64_t>, at::Tensor> g_ws;
 
-void* workspace(const at::Tensor& like, size_t bytes, int64_t stream) {
+void* workspace(const at::Tensor& like, size_t bytes, int64_t stream, int tag = 0) {
   std::lock_guard<std::mutex> lock(g_mu);
-  auto key = std::make_pair((int)like.get_device(), stream);
+  auto key = std::make_pair((int)like.get_device() * 4 + tag, stream);
   auto it = g_ws.find(key);
   if (it == g_ws.end() || (size_t)it->second.numel() < bytes) {
     size_t n = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
@@ -144,6 +144,67 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
   }
 };
 
+// ---- wide 1x1 convolution as a row-matrix GEMM (ucd_amd/blocks.py::_Gemm1x1 is the Python twin) ------------------
+// y[M, Co] = rows[M, Ci] . w[Co, Ci]^T through ucd_gemm_bf16 (hipBLASLt, tuned once per shape); the weight gradient of a
+// long M is eight batched K-chunks + a sum (41 us against 96 for the best single-kernel candidate at M = 26136).
+int64_t wgrad_split(int64_t M) {
+  if (M >= 8192)
+    for (int64_t S : {8, 4, 12, 6, 3, 2})
+      if (M % S == 0) return S;
+  return 1;
+}
+
+class Gemm1x1Node : public torch::autograd::Function<Gemm1x1Node> {
+ public:
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor rows, at::Tensor w4, int64_t stream) {
+    TORCH_CHECK(rows.dim() == 2 && rows.is_contiguous() && rows.scalar_type() == at::kBFloat16 && w4.dim() == 4 &&
+                    w4.scalar_type() == at::kBFloat16 && w4.size(1) == rows.size(1) && w4.size(2) == 1 && w4.size(3) == 1,
+                "ucd gemm1x1 node: rows [M, Ci] bf16 contiguous and weight [Co, Ci, 1, 1] bf16 expected");
+    const int64_t M = rows.size(0), Ci = rows.size(1), Co = w4.size(0);
+    at::Tensor y = at::empty({M, Co}, rows.options());
+    const size_t wsb = ucd_gemm_workspace_bytes();
+    check(ucd_gemm_bf16(0, (int)M, (int)Co, (int)Ci, rows.data_ptr(), (int)Ci, w4.data_ptr(), (int)Ci, y.data_ptr(), (int)Co,
+                        workspace(rows, wsb, stream, 1), wsb, 1, (ucd_stream_t)stream),
+          "ucd_gemm_bf16");
+    ctx->save_for_backward({rows, w4});
+    ctx->saved_data["stream"] = stream;
+    return y;
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    at::Tensor rows = saved[0], w4 = saved[1];
+    const int64_t stream = ctx->saved_data["stream"].toInt();
+    const int64_t M = rows.size(0), Ci = rows.size(1), Co = w4.size(0);
+    at::Tensor dy = grads[0].contiguous();
+    if (dy.scalar_type() != at::kBFloat16) dy = dy.to(at::kBFloat16);
+    const size_t wsb = ucd_gemm_workspace_bytes();
+    void* ws = workspace(rows, wsb, stream, 1);
+    at::Tensor dx, dw;
+    if (ctx->needs_input_grad(0)) {
+      dx = at::empty_like(rows);
+      check(ucd_gemm_bf16(1, (int)M, (int)Ci, (int)Co, dy.data_ptr(), (int)Co, w4.data_ptr(), (int)Ci, dx.data_ptr(), (int)Ci, ws,
+                          wsb, 1, (ucd_stream_t)stream),
+            "ucd_gemm_bf16");
+    }
+    if (ctx->needs_input_grad(1)) {
+      const int64_t S = wgrad_split(M);
+      if (S > 1) {
+        dw = at::bmm(dy.view({S, M / S, Co}).transpose(1, 2), rows.view({S, M / S, Ci})).sum(0);
+      } else {
+        dw = at::empty({Co, Ci}, rows.options());
+        check(ucd_gemm_bf16(2, (int)Co, (int)Ci, (int)M, dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, dw.data_ptr(), (int)Ci,
+                            ws, wsb, 1, (ucd_stream_t)stream),
+              "ucd_gemm_bf16");
+      }
+      dw = dw.as_strided(w4.sizes(), w4.strides());   // [Co, Ci, 1, 1] is one memory order in either format
+    }
+    return {dx, dw, at::Tensor()};
+  }
+};
+
+at::Tensor gemm1x1(at::Tensor rows, at::Tensor w4, int64_t stream) { return Gemm1x1Node::apply(rows, w4, stream); }
+
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,
                      at::Tensor running_mean, at::Tensor running_var, double momentum, double eps, int64_t act, double slope,
                      int64_t comm, int64_t world, int64_t stream) {
@@ -156,4 +217,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node of the training-mode ABN layer over libucd_hip.so";
   m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
   m.def("dense_channels_last", &dense_channels_last);
+  m.def("gemm1x1", &gemm1x1, "rows[M, Ci] x w[Co, Ci, 1, 1]^T with autograd in C++ (call ucd_gemm_load first)");
 }
