@@ -198,7 +198,8 @@ int ucd_comm_all_reduce_sum(ucd_comm_t comm, float* buf, size_t count, ucd_strea
 /* Whole SyncBN layer in one call each way, collectives included (comm from ucd_comm_init, world = its size):
  *   forward   ucd_abn_sync_stats -> all-gather -> ucd_abn_sync_forward; buf = [6*C | pack 2*C | gathered world*2*C]
  *   backward  ucd_abn_sync_bwd_reduce -> all-reduce -> ucd_abn_bwd_apply(count = world*M);
- *             sums4 = [sums 2*C (global on return) | this rank's d bias, d weight 2*C] */
+ *             sums [2*C] = the global sums on return, local_sums [2*C] = this rank's [d bias | d weight]
+ *             (may point straight at the parameters' gradient storage) */
 int ucd_abn_sync_forward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, void* y, int ld_y,
                               const void* residual, int ld_r, int dtype, int M, int C, const float* plane_bias, int HW,
                               const float* weight, const float* bias, float* running_mean, float* running_var,
@@ -207,8 +208,9 @@ int ucd_abn_sync_forward_comm(ucd_comm_t comm, int world, const void* x, int ld_
 int ucd_abn_sync_backward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, const void* dy, int ld_dy,
                                const void* y, int ld_y, void* dx, int ld_dx, void* dz_out, int ld_dz, int dtype, int M,
                                int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
-                               const float* scale, const float* bias, const float* weight, float* sums4, int act,
-                               float slope, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+                               const float* scale, const float* bias, const float* weight, float* sums,
+                               float* local_sums, int act, float slope, void* workspace, size_t workspace_bytes,
+                               ucd_stream_t stream);
 
 /* Per-(image, channel) reduction over the HW rows of each image: out[b, c] = alpha * sum_hw x.
  * Global average pooling of the ASPP image-level branch (modules/deeplab.py:72-76) with alpha = 1/HW,

@@ -281,3 +281,36 @@ def test_cpp_autograd_node_equals_python_function(dtype, with_res):
             abn._node_mod = node
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_direct_parameter_gradients_under_the_reducer():
+    """Under ucd_amd.ddp the ABN parameters' .grad views of a layer are laid out [d bias | d weight] and the backward
+    kernels write them in place (no gradient tensors, no accumulate adds): same values as the plain autograd path."""
+    from ucd_amd import abn
+    from ucd_amd.ddp import DistributedDataParallel
+    dev = torch.device("cuda:0")
+
+    def net():
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Conv2d(8, 64, 3, padding=1, bias=False), abn.InPlaceABN(64),
+                                torch.nn.Conv2d(64, 32, 1, bias=False), abn.InPlaceABN(32, activation="identity")).to(dev)
+        m = m.to(memory_format=torch.channels_last)
+        with torch.no_grad():
+            m[1].weight.copy_(torch.linspace(0.5, 1.5, 64)); m[1].bias.copy_(torch.linspace(-1, 1, 64))
+        return m.train()
+
+    x = synth.t_normal(31, (4, 8, 12, 10), stream=1).to(dev).contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(32, (4, 32, 12, 10), stream=1).to(dev).contiguous(memory_format=torch.channels_last)
+    plain = net()
+    plain(x).backward(dy)
+    wrapped = DistributedDataParallel(net())
+    assert wrapped.reducer.direct_flat is not None and wrapped.module[1]._direct_grad_ptr() != 0
+    for step in range(2):                      # twice: the second step must not accumulate on top of the first
+        wrapped.zero_grad()
+        wrapped(x).backward(dy)
+        wrapped.finish_grad_sync()
+        for (n, p), (_, q) in zip(plain.named_parameters(), wrapped.module.named_parameters()):
+            assert q.grad is not None, n
+            torch.testing.assert_close(q.grad, p.grad, rtol=1e-5, atol=1e-6, msg=n)
+    flat = wrapped.reducer.direct_flat
+    assert torch.equal(flat[:64], wrapped.module[1].bias.grad) and torch.equal(flat[64:128], wrapped.module[1].weight.grad)

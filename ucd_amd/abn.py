@@ -357,10 +357,25 @@ class ABN(nn.Module):
                 if comm is not None or not sync:
                     return node.abn_train(x, self.weight, self.bias, residual, self.running_mean, self.running_var,
                                           self.momentum, self.eps, act, slope, comm.handle if comm is not None else 0,
-                                          world, hip.stream())
+                                          world, hip.stream(), self._direct_grad_ptr())
         return _ABNFunction.apply(x, self.weight, self.bias, residual, plane_bias, self.running_mean,
                                   self.running_var, self.training, self.momentum, self.eps, act, slope,
                                   self._group(), out, inplace, None if self.training else self._eval_constants())
+
+    _direct_grads = None        # set by ucd_amd.ddp: (flat [d bias | d weight] view, its address) the kernels write into
+
+    def _direct_grad_ptr(self):
+        """Address of this layer's [d bias | d weight] gradient storage when the reducer owns it (the backward kernels
+        then write the parameter gradients in place), else 0.  Valid only while both .grad views are the ones handed out."""
+        d = self._direct_grads
+        if d is None or not (self.weight.requires_grad and self.bias.requires_grad):
+            return 0
+        flat, addr = d
+        C = self.num_features
+        gb, gw = self.bias.grad, self.weight.grad
+        if gb is None or gw is None or gb.data_ptr() != addr or gw.data_ptr() != addr + 4 * C:
+            return 0
+        return addr
 
     def _forward_eval_nograd(self, x, act, slope, inplace):
         """Frozen-statistics forward outside autograd (the teacher): one library call, no Function object."""

@@ -799,14 +799,14 @@ int ucd_abn_sync_forward_comm(ucd_comm_t comm, int world, const void* x, int ld_
 int ucd_abn_sync_backward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, const void* dy, int ld_dy, const void* y,
                                int ld_y, void* dx, int ld_dx, void* dz_out, int ld_dz, int dtype, int M, int C,
                                const float* plane_bias, int HW, const float* mean, const float* invstd, const float* scale,
-                               const float* bias, const float* weight, float* sums4, int act, float slope, void* workspace,
-                               size_t workspace_bytes, ucd_stream_t stream) {
-  UCD_REQUIRE(comm && sums4 && world >= 1, UCD_EINVAL, "ucd_abn_sync_backward_comm: bad arguments");
+                               const float* bias, const float* weight, float* sums, float* local_sums, int act, float slope,
+                               void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  UCD_REQUIRE(comm && sums && local_sums && world >= 1, UCD_EINVAL, "ucd_abn_sync_backward_comm: bad arguments");
   UCD_TRY(ucd_abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale, bias, act,
-                                  slope, sums4, sums4 + 2 * C, workspace, workspace_bytes, stream));
-  UCD_TRY(comm_all_reduce_sum_f32(comm, sums4, (size_t)2 * C, (hipStream_t)stream));
+                                  slope, sums, local_sums, workspace, workspace_bytes, stream));
+  UCD_TRY(comm_all_reduce_sum_f32(comm, sums, (size_t)2 * C, (hipStream_t)stream));
   return ucd_abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz_out, ld_dz, dtype, M, C, plane_bias, HW, mean, invstd,
-                           scale, bias, weight, sums4, (float)M * (float)world, 0, act, slope, stream);
+                           scale, bias, weight, sums, (float)M * (float)world, 0, act, slope, stream);
 }
 
 int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,

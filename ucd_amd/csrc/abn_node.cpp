@@ -62,7 +62,10 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
   static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor weight, at::Tensor bias,
                             c10::optional<at::Tensor> residual_, at::Tensor running_mean, at::Tensor running_var,
                             double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
-                            int64_t stream) {
+                            int64_t stream, int64_t param_grad) {
+    // param_grad != 0: address of this layer's [d bias | d weight] storage (2*C floats, the parameters' .grad views laid
+    // out back to back by ucd_amd.ddp); the backward kernels then write the parameter gradients there themselves and the
+    // node reports none - no gradient tensors, no AccumulateGrad adds (212 tiny launches per step)
     TORCH_CHECK(dense_channels_last(x), "ucd abn node: input must be a dense channels-last tensor");
     at::Tensor residual = residual_.has_value() ? *residual_ : at::Tensor();
     const bool has_res = residual.defined();
@@ -97,6 +100,7 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
     ctx->saved_data["world"] = world;
     ctx->saved_data["stream"] = stream;
     ctx->saved_data["has_res"] = has_res;
+    ctx->saved_data["param_grad"] = param_grad;
     return y;
   }
 
@@ -107,6 +111,7 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
     const int64_t world = ctx->saved_data["world"].toInt(), stream = ctx->saved_data["stream"].toInt();
     const double slope = ctx->saved_data["slope"].toDouble();
     const bool has_res = ctx->saved_data["has_res"].toBool();
+    float* param_grad = reinterpret_cast<float*>(ctx->saved_data["param_grad"].toInt());
     const int64_t C = x.size(1), HW = x.size(2) * x.size(3), M = x.size(0) * HW;
     at::Tensor dy = grads[0];
     if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
@@ -114,7 +119,8 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
     at::Tensor dx = at::empty_like(x);
     at::Tensor dz = has_res ? at::empty_like(x) : at::Tensor();
     const bool sync = comm != 0;
-    at::Tensor sums = at::empty({(sync ? 4 : 2) * C}, x.options().dtype(at::kFloat));
+    at::Tensor sums;
+    if (sync || !param_grad) sums = at::empty({(sync && !param_grad ? 4 : 2) * C}, x.options().dtype(at::kFloat));
     float* b = buf.data_ptr<float>();
     const float *mean = b + 3 * C, *invstd = b + 4 * C, *scale = b + 5 * C;
     const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)C);
@@ -126,21 +132,26 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
       check(ucd_abn_sync_backward_comm((ucd_comm_t)comm, (int)world, x.data_ptr(), (int)C, dy.data_ptr(), (int)C, yp, yp ? (int)C : 0,
                                        dx.data_ptr(), (int)C, has_res ? dz.data_ptr() : nullptr, has_res ? (int)C : 0, dt, (int)M,
                                        (int)C, nullptr, (int)HW, mean, invstd, scale, fptr(bias), fptr(weight), sums.data_ptr<float>(),
-                                       (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+                                       param_grad ? param_grad : sums.data_ptr<float>() + 2 * C, (int)act, (float)slope, ws,
+                                       ws_bytes, (ucd_stream_t)stream),
             "ucd_abn_sync_backward_comm");
-      dbias = sums.narrow(0, 2 * C, C);
-      dweight = sums.narrow(0, 3 * C, C);
+      if (!param_grad) {
+        dbias = sums.narrow(0, 2 * C, C);
+        dweight = sums.narrow(0, 3 * C, C);
+      }
     } else {
       check(ucd_abn_backward(x.data_ptr(), (int)C, dy.data_ptr(), (int)C, yp, yp ? (int)C : 0, dx.data_ptr(), (int)C,
                              has_res ? dz.data_ptr() : nullptr, has_res ? (int)C : 0, dt, (int)M, (int)C, nullptr, (int)HW, mean,
-                             invstd, scale, fptr(bias), fptr(weight), sums.data_ptr<float>(), (float)M, 1, 1, (int)act,
-                             (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+                             invstd, scale, fptr(bias), fptr(weight), param_grad ? param_grad : sums.data_ptr<float>(), (float)M,
+                             1, 1, (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
             "ucd_abn_backward");
-      dbias = sums.narrow(0, 0, C);
-      dweight = sums.narrow(0, C, C);
+      if (!param_grad) {
+        dbias = sums.narrow(0, 0, C);
+        dweight = sums.narrow(0, C, C);
+      }
     }
     at::Tensor none;
-    return {dx, dweight, dbias, has_res ? dz : none, none, none, none, none, none, none, none, none, none};
+    return {dx, dweight, dbias, has_res ? dz : none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -207,8 +218,9 @@ at::Tensor gemm1x1(at::Tensor rows, at::Tensor w4, int64_t stream) { return Gemm
 
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,
                      at::Tensor running_mean, at::Tensor running_var, double momentum, double eps, int64_t act, double slope,
-                     int64_t comm, int64_t world, int64_t stream) {
-  return ABNTrainNode::apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world, stream);
+                     int64_t comm, int64_t world, int64_t stream, int64_t param_grad) {
+  return ABNTrainNode::apply(x, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world, stream,
+                             param_grad);
 }
 
 }  // namespace

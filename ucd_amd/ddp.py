@@ -40,7 +40,7 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, params, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True, shadow_of=None):
+    def __init__(self, params, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True, shadow_of=None, direct_modules=()):
         # shadow_of: {fp32 parameter: bf16 working copy that autograd differentiates} (ucd_amd/master.py); such a
         # parameter's slot in the fp32 bucket is filled from the bf16 gradient when the bucket completes
         self.shadow_of = shadow_of or {}
@@ -54,6 +54,25 @@ class GradReducer:
         self.use_avg = self.world > 1 and dist.get_backend(group) == "nccl"   # RCCL reduces with AVG; gloo sums
         self.wire_dtype = wire_dtype
         params = [p for p in params if p.requires_grad]
+        # ABN layers whose backward kernels write [d bias | d weight] straight into gradient storage (ucd_amd/abn.py,
+        # csrc/abn_node.cpp): their parameters get ONE flat bucket of their own, laid out bias-then-weight per layer, that
+        # no autograd hook feeds - it is simply reduced with the stragglers in finish() (a few hundred KB)
+        self.direct_flat = None
+        direct = [m for m in direct_modules if getattr(m, "weight", None) is not None and m.weight.requires_grad
+                  and m.bias is not None and m.bias.requires_grad and m.weight.is_cuda]
+        if direct:
+            total = sum(2 * m.weight.numel() for m in direct)
+            self.direct_flat = torch.zeros(total, dtype=torch.float32, device=direct[0].weight.device)
+            off, taken = 0, set()
+            for m in direct:
+                C = m.weight.numel()
+                m.bias.grad = self.direct_flat[off:off + C]
+                m.weight.grad = self.direct_flat[off + C:off + 2 * C]
+                m._direct_grads = (self.direct_flat[off:off + 2 * C], self.direct_flat.data_ptr() + 4 * off)
+                taken.add(m.weight); taken.add(m.bias)
+                off += 2 * C
+            params = [p for p in params if p not in taken]
+            self._direct_modules = direct
         self.params = params
         self.device = params[0].device if params else torch.device("cpu")
         self.on_gpu = self.device.type == "cuda"
@@ -99,6 +118,16 @@ class GradReducer:
     # -- per step ------------------------------------------------------------------------------
     def zero_grad(self):
         """One memset per bucket instead of one per tensor; keeps the grad views alive."""
+        if self.direct_flat is not None:
+            self.direct_flat.zero_()
+            off = 0
+            for m in self._direct_modules:                      # re-attach views dropped by set_to_none
+                C = m.weight.numel()
+                if m.bias.grad is None:
+                    m.bias.grad = self.direct_flat[off:off + C]
+                if m.weight.grad is None:
+                    m.weight.grad = self.direct_flat[off + C:off + 2 * C]
+                off += 2 * C
         for b in self.buckets:
             b.flat.zero_()
             b.pending = len(b.params)
@@ -164,6 +193,15 @@ class GradReducer:
                 self._complete(b)
         if self.world == 1:
             return
+        if self.direct_flat is not None:                        # kernel-written ABN parameter gradients: one small reduce
+            if self.overlap:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(self.stream):
+                    self.stream.wait_event(ev)
+                    self._reduce_flat(self.direct_flat)
+            else:
+                self._reduce_flat(self.direct_flat)
         for b in self._inflight:
             if self.overlap:
                 with torch.cuda.stream(self.stream):
@@ -182,6 +220,13 @@ class GradReducer:
         if self.overlap:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
         self._inflight = []
+
+    def _reduce_flat(self, flat):
+        if self.use_avg:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(self.world)
 
     def remove(self):
         for h in self._hooks:
@@ -211,8 +256,9 @@ class DistributedDataParallel(nn.Module):
             from .master import Bf16Weights
             self.bf16_weights = Bf16Weights(module)
             shadow_of = self.bf16_weights.shadow_of
+        direct = [m for m in module.modules() if getattr(m, "ucd_fused_abn", False)] if (params and params[0].is_cuda) else []
         if params:
-            self.reducer = GradReducer(params, bucket_mb, wire_dtype, group, overlap, shadow_of)
+            self.reducer = GradReducer(params, bucket_mb, wire_dtype, group, overlap, shadow_of, direct)
 
     def forward(self, *args, **kwargs):
         if self.bf16_weights is not None:

@@ -60,7 +60,7 @@ SIGNATURES = {
     "ucd_abn_sync_forward_comm": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _f,
                                        _p, _z, _p]),
     "ucd_abn_sync_backward_comm": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p,
-                                        _p, _i, _f, _p, _z, _p]),
+                                        _p, _p, _i, _f, _p, _z, _p]),
     "ucd_abn_sync_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _z, _p]),
     "ucd_abn_sync_forward": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _f, _p]),
     "ucd_abn_sync_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
@@ -375,7 +375,8 @@ def abn_sync_backward_comm(comm, world, x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, 
     ws = workspace(nbytes, x.device)
     _check(lib.ucd_abn_sync_backward_comm(comm, world, ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, ptr(dx), ld_dx, ptr(dz),
                                           ld_dz, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale),
-                                          ptr(bias), ptr(weight), ptr(sums4), act, float(slope), ptr(ws), nbytes, stream()),
+                                          ptr(bias), ptr(weight), ptr(sums4), sums4.data_ptr() + 8 * Cc, act, float(slope),
+                                          ptr(ws), nbytes, stream()),
            "ucd_abn_sync_backward_comm")
 
 
