@@ -311,6 +311,8 @@ def test_direct_parameter_gradients_under_the_reducer():
         wrapped.finish_grad_sync()
         for (n, p), (_, q) in zip(plain.named_parameters(), wrapped.module.named_parameters()):
             assert q.grad is not None, n
-            torch.testing.assert_close(q.grad, p.grad, rtol=1e-5, atol=1e-6, msg=n)
+            # convolution weight gradients come from MIOpen (atomics in its fp32 wrw solvers): looser than the ABN ones
+            tol = dict(rtol=1e-5, atol=1e-6) if q.dim() == 1 else dict(rtol=1e-3, atol=1e-4)
+            torch.testing.assert_close(q.grad, p.grad, msg=n, **tol)
     flat = wrapped.reducer.direct_flat
     assert torch.equal(flat[:64], wrapped.module[1].bias.grad) and torch.equal(flat[64:128], wrapped.module[1].weight.grad)
