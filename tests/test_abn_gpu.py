@@ -316,3 +316,33 @@ def test_direct_parameter_gradients_under_the_reducer():
             torch.testing.assert_close(q.grad, p.grad, msg=n, **tol)
     flat = wrapped.reducer.direct_flat
     assert torch.equal(flat[:64], wrapped.module[1].bias.grad) and torch.equal(flat[64:128], wrapped.module[1].weight.grad)
+
+
+@pytest.mark.parametrize("shape", [(24, 256, 129, 129), (24, 2048, 33, 33), (24, 64, 257, 257)])
+def test_full_size_batchnorm_invariants(shape):
+    """The largest layers of the benchmark workload (up to 204 MB in bf16), through properties batch norm has at any size:
+    with identity activation the output has per-channel mean = bias and variance = weight^2 (up to eps), and the input
+    gradient is orthogonal to the constant and to the normalised input (sum dx = 0, sum dx*xhat = 0)."""
+    from ucd_amd import abn
+    dev = torch.device("cuda:0")
+    B, C, H, W = shape
+    g = torch.Generator(dev).manual_seed(C + H)
+    x = (torch.randn(shape, device=dev, generator=g) * 1.5 + 0.7).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    m = abn.InPlaceABN(C, activation="identity").to(dev).train()
+    with torch.no_grad():
+        m.weight.copy_(torch.linspace(0.5, 2.0, C)); m.bias.copy_(torch.linspace(-1, 1, C))
+    y = m(x * 1.0)
+    yf = y.float()
+    mean, var = yf.mean(dim=(0, 2, 3)), yf.var(dim=(0, 2, 3), unbiased=False)
+    torch.testing.assert_close(mean, m.bias.detach(), rtol=0, atol=2e-2)              # bf16 output rounding: 2^-9 relative
+    torch.testing.assert_close(var.sqrt(), m.weight.detach(), rtol=1e-2, atol=1e-3)
+    dy = torch.randn(shape, device=dev, generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(dy)
+    dx = x.grad.float()
+    xf = x.detach().float()
+    xhat = (xf - xf.mean(dim=(0, 2, 3), keepdim=True)) / xf.std(dim=(0, 2, 3), keepdim=True, unbiased=False)
+    n = B * H * W
+    scale = dx.abs().mean().item() * n
+    assert (dx.sum(dim=(0, 2, 3)).abs().max().item()) / scale < 2e-3                  # bf16 dx: sums cancel to rounding noise
+    assert ((dx * xhat).sum(dim=(0, 2, 3)).abs().max().item()) / scale < 2e-3
