@@ -48,3 +48,28 @@ def test_fused_seg_losses_vs_oracle(B, Ctot, K, h, H, with_kd):
     g, gr = s_dev.grad.cpu(), s_ref.grad
     assert (g - gr).abs().max().item() / gr.abs().max().item() < 1e-3
     assert (g - gr).norm().item() / gr.norm().item() < 1e-4
+
+
+def test_full_size_invariants_b24_513():
+    """The benchmark shape (24 x 21 classes, 33x33 logits up-sampled to 513x513) against properties that hold at any size:
+    (1) the fused kernel equals the un-fused torch composition ON THE GPU (bilinear up-sampling, then the unbiased CE / KD
+    modules of this package, which tests above pin to the oracle); (2) every loss term is a difference of log-sum-exps of
+    the same logits, so its gradient sums to zero over the classes at every low-resolution cell."""
+    from ucd_amd.loss import UnbiasedCrossEntropy, UnbiasedKnowledgeDistillationLoss, fused_seg_losses
+    dev = torch.device("cuda:0")
+    B, Ctot, K, h, H = 24, 21, 16, 33, 513
+    sem = synth.t_normal(91, (B, Ctot, h, h), stream=2).to(dev).mul_(2.0).requires_grad_(True)
+    sem_t = synth.t_normal(92, (B, K, h, h), stream=2).to(dev).mul_(2.0)
+    labels = synth.seg_labels(93, B, H, H, range(16, 21)).to(dev)
+    total, ce, kd = fused_seg_losses(sem, sem_t, labels, K, 1.0, 10.0)
+    total.backward()
+    g = sem.grad.clone()
+    ref_in = sem.detach().clone().requires_grad_(True)
+    up = lambda t: F.interpolate(t, size=(H, H), mode="bilinear", align_corners=False)
+    ce_ref = UnbiasedCrossEntropy(old_cl=K, ignore_index=255, reduction="none")(up(ref_in), labels.clone()).mean()
+    kd_ref = UnbiasedKnowledgeDistillationLoss(alpha=1.0)(up(ref_in), up(sem_t))
+    (ce_ref + 10.0 * kd_ref).backward()
+    assert ce.item() == pytest.approx(ce_ref.item(), rel=1e-4)
+    assert kd.item() == pytest.approx(kd_ref.item(), rel=1e-4)
+    assert ((g - ref_in.grad).norm() / ref_in.grad.norm()).item() < 1e-4
+    assert (g.sum(dim=1).abs().max() / g.abs().max()).item() < 1e-4
