@@ -113,18 +113,46 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
     const bool ignored = lab64 == ignore_index;
     int lab = ignored ? 0 : (int)lab64;
     if (lab < K) lab = 0;                                    // loss.py:104-105
+    // CT > 0: every interpolated logit is formed ONCE and kept in a register (the three passes below would otherwise
+    // redo the 4 LDS reads + 6 flops of the interpolation three times per class: ~450 LDS reads per pixel)
+    float zc[CTA], tc[CTA];
+    if (CT > 0) {
+#pragma unroll
+      for (int c = 0; c < CTA; ++c) {
+        zc[c] = c < Ctot ? interp(s_log, Ctot, c) : -INFINITY;
+        tc[c] = (sem_t && c < K) ? interp(t_log, K, c) : -INFINITY;
+      }
+    }
     // pass A: maxima
     float mz = -INFINITY;
-    for (int c = 0; c < Ctot; ++c) mz = fmaxf(mz, interp(s_log, Ctot, c));
+    if (CT > 0) {
+#pragma unroll
+      for (int c = 0; c < CTA; ++c) mz = fmaxf(mz, zc[c]);
+    } else {
+      for (int c = 0; c < Ctot; ++c) mz = fmaxf(mz, interp(s_log, Ctot, c));
+    }
     // pass B: the three sums, the labelled logit
     float s_all = 0.f, s_old = 0.f, s_bn = 0.f, z_lab = 0.f;
-    for (int c = 0; c < Ctot; ++c) {
-      const float z = interp(s_log, Ctot, c);
-      const float e = __expf(z - mz);
-      s_all += e;
-      if (c < K) s_old += e;
-      if (c == 0 || c >= K) s_bn += e;
-      if (c == lab) z_lab = z;
+    if (CT > 0) {
+#pragma unroll
+      for (int c = 0; c < CTA; ++c)
+        if (c < Ctot) {
+          const float z = zc[c];
+          const float e = __expf(z - mz);
+          s_all += e;
+          if (c < K) s_old += e;
+          if (c == 0 || c >= K) s_bn += e;
+          if (c == lab) z_lab = z;
+        }
+    } else {
+      for (int c = 0; c < Ctot; ++c) {
+        const float z = interp(s_log, Ctot, c);
+        const float e = __expf(z - mz);
+        s_all += e;
+        if (c < K) s_old += e;
+        if (c == 0 || c >= K) s_bn += e;
+        if (c == lab) z_lab = z;
+      }
     }
     const float den = mz + __logf(s_all);
     const float lse_old = mz + __logf(s_old), lse_bn = mz + __logf(s_bn);
@@ -133,21 +161,32 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
     // teacher soft-max
     float mt = -INFINITY, st = 0.f, q0 = 0.f, kd_pix = 0.f;
     if (sem_t) {
-      for (int c = 0; c < K; ++c) mt = fmaxf(mt, interp(t_log, K, c));
-      for (int c = 0; c < K; ++c) st += __expf(interp(t_log, K, c) - mt);
-      q0 = __expf(interp(t_log, K, 0) - mt) / st;
+      if (CT > 0) {
+#pragma unroll
+        for (int c = 0; c < CTA; ++c) mt = fmaxf(mt, tc[c]);
+#pragma unroll
+        for (int c = 0; c < CTA; ++c) {
+          tc[c] = c < K ? __expf(tc[c] - mt) : 0.f;      // from here on: un-normalised teacher probabilities
+          st += tc[c];
+        }
+        q0 = tc[0] / st;
+      } else {
+        for (int c = 0; c < K; ++c) mt = fmaxf(mt, interp(t_log, K, c));
+        for (int c = 0; c < K; ++c) st += __expf(interp(t_log, K, c) - mt);
+        q0 = __expf(interp(t_log, K, 0) - mt) / st;
+      }
       kd_pix = q0 * (lse_bn - den);
     }
     // pass C: gradients (and the old-class part of the KD loss)
     const float ce_w = ignored ? 0.f : ce_scale;
-    auto grad_c = [&](int c) {
-      const float z = interp(s_log, Ctot, c);
+    const float inv_st = sem_t ? 1.f / st : 0.f;
+    auto grad_c = [&](int c, float z, float te) {   // te: exp(teacher_c - mt) (CT > 0) or unused
       const float p = __expf(z - den);
       float g = ce_w * (p - (lab == 0 ? (c < K ? __expf(z - lse_old) : 0.f) : (c == lab ? 1.f : 0.f)));
       if (sem_t) {
         float qc = 0.f;
         if (c >= 1 && c < K) {
-          qc = __expf(interp(t_log, K, c) - mt) / st;
+          qc = CT > 0 ? te * inv_st : __expf(interp(t_log, K, c) - mt) / st;
           kd_pix += qc * (z - den);
         }
         const float bn = (c == 0 || c >= K) ? q0 * __expf(z - lse_bn) : 0.f;
@@ -159,14 +198,14 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
 #pragma unroll
       for (int c = 0; c < CTA; ++c)
         if (c < Ctot) {
-          const float g = grad_c(c);
+          const float g = grad_c(c, zc[c], tc[c]);
           acc0[c] += ly0 * g;
           acc1[c] += ly1 * g;
         }
     } else {
       const float w00 = ly0 * lx0, w01 = ly0 * lx1, w10 = ly1 * lx0, w11 = ly1 * lx1;
       for (int c = 0; c < Ctot; ++c) {
-        const float g = grad_c(c);
+        const float g = grad_c(c, interp(s_log, Ctot, c), 0.f);
         atomicAdd(&g_acc[c00 * Ctot + c], w00 * g);
         atomicAdd(&g_acc[c01 * Ctot + c], w01 * g);
         atomicAdd(&g_acc[c10 * Ctot + c], w10 * g);
