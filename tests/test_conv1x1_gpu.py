@@ -62,3 +62,28 @@ def test_cpp_gemm_node_equals_python_function():
             blocks._node_cache[0] = node
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("ci,co,hw,d", [(256, 256, 33, 1), (512, 512, 33, 2), (2048, 256, 33, 12), (64, 64, 65, 1)])
+def test_conv3x3_input_gradient_on_the_forward_solver(ci, co, hw, d):
+    """ucd_amd/blocks.py::Conv3x3 computes dx with the forward solver on the flipped / transposed weight: the same
+    arithmetic as conv2d's own backward (reference: nn.Conv2d(k=3, padding=dilation), modules/residual.py:69,
+    modules/deeplab.py:27-29), compared in fp32 on bf16-rounded operands."""
+    from ucd_amd.blocks import Conv3x3
+    dev = torch.device("cuda:0")
+    torch.manual_seed(ci + co + d)
+    B = 8
+    conv = Conv3x3(ci, co, 3, stride=1, padding=d, dilation=d, bias=False).to(dev).to(memory_format=torch.channels_last)
+    x32 = torch.randn(B, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    dy32 = torch.randn(B, co, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    x = x32.to(torch.bfloat16).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x)
+    assert type(y.grad_fn).__name__ == "_Conv3x3FnBackward"
+    y.backward(dy32.to(torch.bfloat16))
+    xr = x32.to(torch.bfloat16).float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, d, d)
+    yr.backward(dy32.to(torch.bfloat16).float())
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
+    assert rel(y, yr) < 1e-2 and rel(x.grad, xr.grad) < 1e-2 and rel(conv.weight.grad, wr.grad) < 1e-2

@@ -20,6 +20,7 @@ fall back to the literal op sequence of the reference.
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import torch
@@ -131,6 +132,47 @@ def try_index(scalar_or_list, i):
         return scalar_or_list
 
 
+class _Conv3x3Fn(torch.autograd.Function):
+    """Stride-1 3x3 convolution (dilation d, padding d) whose INPUT gradient runs on the forward solver:
+    dx = conv2d(dy, w.flip(2, 3).transpose(0, 1), padding=d, dilation=d).  Measured on MI355X with MIOpen's solver
+    search (tools/dgrad_probe.py, bf16 channels-last, B = 24): the backward-data solvers take 75 / 217 / 367 us where the
+    forward ones take 58 / 138 / 275 us on the same problem (256x256 at 33^2 / 512x512 dilated / the ASPP branches)."""
+
+    @staticmethod
+    def forward(ctx, x, w, d):
+        ctx.d = d
+        ctx.save_for_backward(x, w)
+        return F.conv2d(x, w, None, 1, d, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        d = ctx.d
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+            dx = F.conv2d(dy, wt, None, 1, d, d)
+        if ctx.needs_input_grad[1]:
+            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return dx, dw, None
+
+
+class Conv3x3(Conv2d):
+    """3x3, stride 1, padding = dilation: the bottleneck conv2 layers and the ASPP branches (modules/residual.py:69,
+    modules/deeplab.py:27-29).  Same parameters and state_dict keys as nn.Conv2d."""
+
+    def forward(self, x):
+        if (x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is None
+                and x.dtype == torch.bfloat16 and x.shape[0] * x.shape[2] * x.shape[3] >= 8192
+                and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
+            w = self.working_weight()
+            if w is None:
+                w = self.weight.to(x.dtype)
+            return _Conv3x3Fn.apply(x, w, self.dilation[0])
+        return super().forward(x)
+
+
 class Conv1x1(Conv2d):
     """1x1 stride-1 convolution with the reference's parameter shape ([Cout, Cin, 1, 1]).  On the GPU, for
     the wide layers of the network (mod4 / mod5 / ASPP at the stride-16 resolution), it runs as ONE plain
@@ -204,6 +246,8 @@ class ResidualBlock(nn.Module):
             if k == 1 and s == 1 and g == 1:
                 return Conv1x1(cin, cout)
             pad = dilation if k == 3 else 0
+            if k == 3 and s == 1 and g == 1:
+                return Conv3x3(cin, cout, 3, stride=1, padding=dilation, dilation=dilation, bias=False)
             return Conv2d(cin, cout, k, stride=s, padding=pad, dilation=dilation if k == 3 else 1,
                              groups=g, bias=False)
 
@@ -266,7 +310,7 @@ class DeeplabV3(nn.Module):
         self.hidden_channels = hidden_channels
 
         branches = [Conv1x1(in_channels, hidden_channels)]
-        branches += [Conv2d(in_channels, hidden_channels, 3, bias=False, dilation=d, padding=d)
+        branches += [Conv3x3(in_channels, hidden_channels, 3, bias=False, dilation=d, padding=d)
                      for d in dilations]
         self.map_convs = nn.ModuleList(branches)
         self.map_bn = norm_act(hidden_channels * len(branches))
