@@ -79,11 +79,34 @@ def test_conv3x3_input_gradient_on_the_forward_solver(ci, co, hw, d):
     x = x32.to(torch.bfloat16).requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = conv(x)
-    assert type(y.grad_fn).__name__ == "_Conv3x3FnBackward"
+    assert type(y.grad_fn).__name__ == "_StrideOneConvFnBackward"
     y.backward(dy32.to(torch.bfloat16))
     xr = x32.to(torch.bfloat16).float().requires_grad_(True)
     wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
     yr = F.conv2d(xr, wr, None, 1, d, d)
+    yr.backward(dy32.to(torch.bfloat16).float())
+    rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
+    assert rel(y, yr) < 1e-2 and rel(x.grad, xr.grad) < 1e-2 and rel(conv.weight.grad, wr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("ci,co,hw", [(256, 64, 65), (64, 256, 65), (512, 128, 33)])
+def test_narrow_conv1x1_input_gradient_on_the_forward_solver(ci, co, hw):
+    """The narrow 1x1 convolutions stay with MIOpen; their input gradient is the forward solver on the transposed weight."""
+    dev = torch.device("cuda:0")
+    torch.manual_seed(ci + co)
+    B = 8
+    conv = Conv1x1(ci, co).to(dev).to(memory_format=torch.channels_last)
+    assert not conv.as_gemm
+    x32 = torch.randn(B, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    dy32 = torch.randn(B, co, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
+    x = x32.to(torch.bfloat16).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x)
+    assert type(y.grad_fn).__name__ == "_StrideOneConvFnBackward"
+    y.backward(dy32.to(torch.bfloat16))
+    xr = x32.to(torch.bfloat16).float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr)
     yr.backward(dy32.to(torch.bfloat16).float())
     rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
     assert rel(y, yr) < 1e-2 and rel(x.grad, xr.grad) < 1e-2 and rel(conv.weight.grad, wr.grad) < 1e-2

@@ -132,28 +132,31 @@ def try_index(scalar_or_list, i):
         return scalar_or_list
 
 
-class _Conv3x3Fn(torch.autograd.Function):
-    """Stride-1 3x3 convolution (dilation d, padding d) whose INPUT gradient runs on the forward solver:
+class _StrideOneConvFn(torch.autograd.Function):
+    """Stride-1 convolution (3x3 with dilation d and padding d, or 1x1) whose INPUT gradient runs on the forward solver:
     dx = conv2d(dy, w.flip(2, 3).transpose(0, 1), padding=d, dilation=d).  Measured on MI355X with MIOpen's solver
-    search (tools/dgrad_probe.py, bf16 channels-last, B = 24): the backward-data solvers take 75 / 217 / 367 us where the
-    forward ones take 58 / 138 / 275 us on the same problem (256x256 at 33^2 / 512x512 dilated / the ASPP branches)."""
+    search (tools/dgrad_probe.py, tools/dgrad1x1_probe.py; bf16 channels-last, B = 24): the backward-data solvers take
+    75 / 217 / 367 us where the forward ones take 58 / 138 / 275 us on the same problem (3x3: 256x256 at 33^2 / 512x512
+    dilated / the ASPP branches), and 89 / 62 / 110 us against 43 / 32 / 73 us on the narrow 1x1 layers
+    (256->64 at 129^2 / 512->128 at 65^2 / 256->128 at 129^2)."""
 
     @staticmethod
     def forward(ctx, x, w, d):
         ctx.d = d
         ctx.save_for_backward(x, w)
-        return F.conv2d(x, w, None, 1, d, d)
+        return F.conv2d(x, w, None, 1, d * (w.shape[2] // 2), d)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         d = ctx.d
+        pad = d * (w.shape[2] // 2)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
-            dx = F.conv2d(dy, wt, None, 1, d, d)
+            wt = w.transpose(0, 1) if w.shape[2] == 1 else w.flip(2, 3).transpose(0, 1)
+            dx = F.conv2d(dy, wt.contiguous(memory_format=torch.channels_last), None, 1, pad, d)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [d, d], [d, d], False, [0, 0], 1,
+            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [pad, pad], [d, d], False, [0, 0], 1,
                                                      [False, True, False])[1]
         return dx, dw, None
 
@@ -169,7 +172,7 @@ class Conv3x3(Conv2d):
             w = self.working_weight()
             if w is None:
                 w = self.weight.to(x.dtype)
-            return _Conv3x3Fn.apply(x, w, self.dilation[0])
+            return _StrideOneConvFn.apply(x, w, self.dilation[0])
         return super().forward(x)
 
 
@@ -189,6 +192,11 @@ class Conv1x1(Conv2d):
         # bf16 activations only: in the fp32 parity mode (--opt_level O0) every convolution stays on one code
         # path (MIOpen), which is what the 1e-3 logit comparison with the reference was validated on
         if not (self.as_gemm and x.is_cuda and x.dim() == 4 and (x.dtype != torch.float32 or torch.is_autocast_enabled())):
+            if (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and self.bias is None
+                    and self.weight.requires_grad and x.shape[0] * x.shape[2] * x.shape[3] >= 8192
+                    and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
+                w = self.working_weight()
+                return _StrideOneConvFn.apply(x, w if w is not None else self.weight.to(x.dtype), 1)   # narrow layer: MIOpen
             return super().forward(x)
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1)                      # a view of a channels-last tensor
