@@ -161,6 +161,15 @@ class _StrideOneConvFn(torch.autograd.Function):
         return dx, dw, None
 
 
+def _stride_one_conv(x, w, d):
+    """The C++ autograd node when built (no Python in the backward), else the Python Function: same ATen calls."""
+    from . import abn
+    node = abn._abn_node()
+    if node is not None and hasattr(node, "conv_stride1"):
+        return node.conv_stride1(x, w, d)
+    return _StrideOneConvFn.apply(x, w, d)
+
+
 class Conv3x3(Conv2d):
     """3x3, stride 1, padding = dilation: the bottleneck conv2 layers and the ASPP branches (modules/residual.py:69,
     modules/deeplab.py:27-29).  Same parameters and state_dict keys as nn.Conv2d."""
@@ -172,7 +181,7 @@ class Conv3x3(Conv2d):
             w = self.working_weight()
             if w is None:
                 w = self.weight.to(x.dtype)
-            return _StrideOneConvFn.apply(x, w, self.dilation[0])
+            return _stride_one_conv(x, w, self.dilation[0])
         return super().forward(x)
 
 
@@ -196,7 +205,7 @@ class Conv1x1(Conv2d):
                     and self.weight.requires_grad and x.shape[0] * x.shape[2] * x.shape[3] >= 8192
                     and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
                 w = self.working_weight()
-                return _StrideOneConvFn.apply(x, w if w is not None else self.weight.to(x.dtype), 1)   # narrow layer: MIOpen
+                return _stride_one_conv(x, w if w is not None else self.weight.to(x.dtype), 1)   # narrow layer: MIOpen
             return super().forward(x)
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1)                      # a view of a channels-last tensor

@@ -216,6 +216,38 @@ class Gemm1x1Node : public torch::autograd::Function<Gemm1x1Node> {
 
 at::Tensor gemm1x1(at::Tensor rows, at::Tensor w4, int64_t stream) { return Gemm1x1Node::apply(rows, w4, stream); }
 
+// ---- stride-1 convolution (3x3 with padding = dilation, or 1x1) whose input gradient runs on the FORWARD solver --------
+// dx = conv2d(dy, w.flip(2,3).transpose(0,1), padding, dilation): MIOpen's backward-data solvers are 1.3-2x slower than its
+// forward solvers on these problems (tools/dgrad_probe.py, tools/dgrad1x1_probe.py).  ucd_amd/blocks.py::_StrideOneConvFn is
+// the Python twin.
+class StrideOneConvNode : public torch::autograd::Function<StrideOneConvNode> {
+ public:
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor w, int64_t d) {
+    const int64_t pad = d * (w.size(2) / 2);
+    ctx->save_for_backward({x, w});
+    ctx->saved_data["d"] = d;
+    return at::conv2d(x, w, {}, {1, 1}, {pad, pad}, {d, d}, 1);
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    at::Tensor x = saved[0], w = saved[1], dy = grads[0];
+    const int64_t d = ctx->saved_data["d"].toInt(), pad = d * (w.size(2) / 2);
+    at::Tensor dx, dw;
+    if (ctx->needs_input_grad(0)) {
+      at::Tensor wt = w.size(2) == 1 ? w.transpose(0, 1) : w.flip({2, 3}).transpose(0, 1);
+      dx = at::conv2d(dy, wt.contiguous(at::MemoryFormat::ChannelsLast), {}, {1, 1}, {pad, pad}, {d, d}, 1);
+    }
+    if (ctx->needs_input_grad(1)) {
+      dw = std::get<1>(at::convolution_backward(dy, x, w, c10::nullopt, {1, 1}, {pad, pad}, {d, d}, false, {0, 0}, 1,
+                                                {false, true, false}));
+    }
+    return {dx, dw, at::Tensor()};
+  }
+};
+
+at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d) { return StrideOneConvNode::apply(x, w, d); }
+
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,
                      at::Tensor running_mean, at::Tensor running_var, double momentum, double eps, int64_t act, double slope,
                      int64_t comm, int64_t world, int64_t stream, int64_t param_grad) {
@@ -229,5 +261,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node of the training-mode ABN layer over libucd_hip.so";
   m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
   m.def("dense_channels_last", &dense_channels_last);
+  m.def("conv_stride1", &conv_stride1, "stride-1 conv (3x3 pad=dilation, or 1x1) with the input gradient on the forward solver");
   m.def("gemm1x1", &gemm1x1, "rows[M, Ci] x w[Co, Ci, 1, 1]^T with autograd in C++ (call ucd_gemm_load first)");
 }
