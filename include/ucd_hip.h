@@ -178,6 +178,12 @@ int ucd_gemm_load(const char* hipblaslt_path);
 size_t ucd_gemm_workspace_bytes(void);
 int ucd_gemm_bf16(int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
                   void* workspace, size_t workspace_bytes, int tune, ucd_stream_t stream);
+/* C += op(A) op(B) with the plan ucd_gemm_bf16 holds for the shape (the residual-branch gradient folded into the input
+ * gradient of a block's first 1x1 convolution); never tunes - warm the shape through ucd_gemm_bf16 first
+ * (ucd_gemm_has_plan tells) or it takes the library's first suggestion */
+int ucd_gemm_bf16_acc(int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                      void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+int ucd_gemm_has_plan(int mode, int M, int N, int K, int lda, int ldb, int ldc);
 float ucd_gemm_last_tuned_us(void);
 int ucd_gemm_last_candidates(void);
 

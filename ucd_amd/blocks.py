@@ -230,6 +230,25 @@ class Conv1x1(Conv2d):
         return y.view(B, H, W, self.out_channels).permute(0, 3, 1, 2)
 
 
+def _conv1_with_skip(conv, x):
+    """(conv(x), x') for the first 1x1 convolution of an identity-shortcut block, x' an alias of x to use as the residual:
+    the C++ node folds the shortcut's gradient into the input-gradient GEMM (dx = dskip + dy w, beta = 1) instead of
+    leaving a separate 3-pass add to autograd.  None when that path does not apply (then the caller does the usual)."""
+    if not (isinstance(conv, Conv1x1) and conv.as_gemm and conv.bias is None and x.is_cuda and x.dim() == 4
+            and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and conv.weight.requires_grad and x.requires_grad):
+        return None
+    node = _gemm_node()
+    if node is None or not hasattr(node, "gemm1x1_skip"):
+        return None
+    B, C, H, W = x.shape
+    rows = x.permute(0, 2, 3, 1)
+    if not rows.is_contiguous():
+        return None
+    w16 = conv.working_weight()
+    y, skip = node.gemm1x1_skip(rows.reshape(B * H * W, C), w16 if w16 is not None else conv.weight.to(x.dtype), _hip_stream())
+    return (y.view(B, H, W, conv.out_channels).permute(0, 3, 1, 2), skip.view(B, H, W, C).permute(0, 3, 1, 2))
+
+
 def _is_fused_abn(m) -> bool:
     return getattr(m, "ucd_fused_abn", False)
 
@@ -298,10 +317,16 @@ class ResidualBlock(nn.Module):
         last = getattr(self.convs, self._last_bn)
         if _is_fused_abn(last) and last.activation == "identity" and act in ("leaky_relu", "identity"):
             # fused epilogue: act(bn(conv_out) + residual) in one HBM pass
-            h = x
+            h, first = x, None
+            if residual is x and self.training:
+                first = _conv1_with_skip(self.convs.conv1, x)
+                if first is not None:
+                    h, residual = first
             for name, mod in self.convs.named_children():
                 if mod is last:
                     h = mod(h, residual=residual, activation=act, activation_param=slope)
+                elif first is not None and name == "conv1":
+                    continue                                   # already applied together with the shortcut
                 else:
                     h = mod(h)
             return h

@@ -216,6 +216,82 @@ class Gemm1x1Node : public torch::autograd::Function<Gemm1x1Node> {
 
 at::Tensor gemm1x1(at::Tensor rows, at::Tensor w4, int64_t stream) { return Gemm1x1Node::apply(rows, w4, stream); }
 
+// First 1x1 convolution of an identity-shortcut bottleneck block, together with the shortcut itself: returns (y, rows) so
+// that the block input has ONE consumer.  The backward then receives the shortcut's gradient next to dy and folds it
+// into the input-gradient GEMM, dx = dskip + dy . w (beta = 1, in place on dskip), instead of autograd adding two
+// [M, Ci] tensors afterwards (one 3-pass elementwise kernel per block, 24 blocks).
+class Gemm1x1SkipNode : public torch::autograd::Function<Gemm1x1SkipNode> {
+ public:
+  static variable_list forward(AutogradContext* ctx, at::Tensor rows, at::Tensor w4, int64_t stream) {
+    TORCH_CHECK(rows.dim() == 2 && rows.is_contiguous() && rows.scalar_type() == at::kBFloat16 && w4.dim() == 4 &&
+                    w4.scalar_type() == at::kBFloat16 && w4.size(1) == rows.size(1) && w4.size(2) == 1 && w4.size(3) == 1,
+                "ucd gemm1x1 skip node: rows [M, Ci] bf16 contiguous and weight [Co, Ci, 1, 1] bf16 expected");
+    const int64_t M = rows.size(0), Ci = rows.size(1), Co = w4.size(0);
+    at::Tensor y = at::empty({M, Co}, rows.options());
+    const size_t wsb = ucd_gemm_workspace_bytes();
+    check(ucd_gemm_bf16(0, (int)M, (int)Co, (int)Ci, rows.data_ptr(), (int)Ci, w4.data_ptr(), (int)Ci, y.data_ptr(), (int)Co,
+                        workspace(rows, wsb, stream, 1), wsb, 1, (ucd_stream_t)stream),
+          "ucd_gemm_bf16");
+    ctx->save_for_backward({rows, w4});
+    ctx->saved_data["stream"] = stream;
+    return {y, rows};          // an input returned as an output: autograd hands out an alias with this node as grad_fn
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    at::Tensor rows = saved[0], w4 = saved[1];
+    const int64_t stream = ctx->saved_data["stream"].toInt();
+    const int64_t M = rows.size(0), Ci = rows.size(1), Co = w4.size(0);
+    const size_t wsb = ucd_gemm_workspace_bytes();
+    void* ws = workspace(rows, wsb, stream, 1);
+    at::Tensor dy = grads[0], dskip = grads[1], dx, dw;
+    if (dy.defined()) {
+      dy = dy.contiguous();
+      if (dy.scalar_type() != at::kBFloat16) dy = dy.to(at::kBFloat16);
+    }
+    if (ctx->needs_input_grad(0)) {
+      if (dskip.defined() && dy.defined() && dskip.scalar_type() == at::kBFloat16) {
+        dskip = dskip.contiguous();
+        if (!ucd_gemm_has_plan(1, (int)M, (int)Ci, (int)Co, (int)Co, (int)Ci, (int)Ci)) {   // tune once, into scratch
+          at::Tensor scratch = at::empty_like(rows);
+          check(ucd_gemm_bf16(1, (int)M, (int)Ci, (int)Co, dy.data_ptr(), (int)Co, w4.data_ptr(), (int)Ci, scratch.data_ptr(),
+                              (int)Ci, ws, wsb, 1, (ucd_stream_t)stream),
+                "ucd_gemm_bf16");
+        }
+        check(ucd_gemm_bf16_acc(1, (int)M, (int)Ci, (int)Co, dy.data_ptr(), (int)Co, w4.data_ptr(), (int)Ci, dskip.data_ptr(),
+                                (int)Ci, ws, wsb, (ucd_stream_t)stream),
+              "ucd_gemm_bf16_acc");
+        dx = dskip;
+      } else if (dy.defined()) {
+        dx = at::empty_like(rows);
+        check(ucd_gemm_bf16(1, (int)M, (int)Ci, (int)Co, dy.data_ptr(), (int)Co, w4.data_ptr(), (int)Ci, dx.data_ptr(), (int)Ci, ws,
+                            wsb, 1, (ucd_stream_t)stream),
+              "ucd_gemm_bf16");
+        if (dskip.defined()) dx = dx + dskip;
+      } else {
+        dx = dskip;
+      }
+    }
+    if (ctx->needs_input_grad(1) && dy.defined()) {
+      const int64_t S = wgrad_split(M);
+      if (S > 1) {
+        dw = at::bmm(dy.view({S, M / S, Co}).transpose(1, 2), rows.view({S, M / S, Ci})).sum(0);
+      } else {
+        dw = at::empty({Co, Ci}, rows.options());
+        check(ucd_gemm_bf16(2, (int)Co, (int)Ci, (int)M, dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, dw.data_ptr(), (int)Ci,
+                            ws, wsb, 1, (ucd_stream_t)stream),
+              "ucd_gemm_bf16");
+      }
+      dw = dw.as_strided(w4.sizes(), w4.strides());
+    }
+    return {dx, dw, at::Tensor()};
+  }
+};
+
+std::vector<at::Tensor> gemm1x1_skip(at::Tensor rows, at::Tensor w4, int64_t stream) {
+  return Gemm1x1SkipNode::apply(rows, w4, stream);
+}
+
 // ---- stride-1 convolution (3x3 with padding = dilation, or 1x1) whose input gradient runs on the FORWARD solver --------
 // dx = conv2d(dy, w.flip(2,3).transpose(0,1), padding, dilation): MIOpen's backward-data solvers are 1.3-2x slower than its
 // forward solvers on these problems (tools/dgrad_probe.py, tools/dgrad1x1_probe.py).  ucd_amd/blocks.py::_StrideOneConvFn is
@@ -262,5 +338,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
   m.def("dense_channels_last", &dense_channels_last);
   m.def("conv_stride1", &conv_stride1, "stride-1 conv (3x3 pad=dilation, or 1x1) with the input gradient on the forward solver");
+  m.def("gemm1x1_skip", &gemm1x1_skip, "(rows x w^T, rows): first 1x1 conv of an identity-shortcut block with the shortcut");
   m.def("gemm1x1", &gemm1x1, "rows[M, Ci] x w[Co, Ci, 1, 1]^T with autograd in C++ (call ucd_gemm_load first)");
 }

@@ -57,8 +57,8 @@ constexpr size_t kWorkspace = (size_t)64 << 20;
     }                                                                    \
   } while (0)
 
-int launch(const Plan& p, const void* ltA, const void* ltB, void* C, void* ws, hipStream_t s) {
-  const float alpha = 1.f, beta = 0.f;
+int launch(const Plan& p, const void* ltA, const void* ltB, void* C, void* ws, hipStream_t s, float beta = 0.f) {
+  const float alpha = 1.f;
   UCD_LT("hipblasLtMatmul", g_lt.Matmul(g_lt.handle, p.desc, &alpha, ltA, p.la, ltB, p.lb, &beta, C, p.lc, C, p.lc, &p.algo, ws,
                                         p.workspace, s));
   return 0;
@@ -156,9 +156,8 @@ int ucd_gemm_load(const char* path) {
 
 size_t ucd_gemm_workspace_bytes(void) { return kWorkspace; }
 
-int ucd_gemm_bf16(int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
-                  void* workspace, size_t workspace_bytes, int tune, ucd_stream_t stream) {
-  static const char* fn = "ucd_gemm_bf16";
+static int gemm_impl(const char* fn, int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C,
+                     int ldc, void* workspace, size_t workspace_bytes, int tune, float beta, ucd_stream_t stream) {
   UCD_REQUIRE(g_lt.handle, UCD_EINVAL, "%s: call ucd_gemm_load first", fn);
   UCD_REQUIRE(mode >= 0 && mode <= 2 && M > 0 && N > 0 && K > 0 && A && B && C, UCD_EINVAL, "%s: bad arguments", fn);
   UCD_REQUIRE(lda >= (mode == 2 ? M : K) && ldb >= (mode == 0 ? K : N) && ldc >= N, UCD_EINVAL, "%s: leading dimension too small", fn);
@@ -181,7 +180,24 @@ int ucd_gemm_bf16(int mode, int M, int N, int K, const void* A, int lda, const v
     g_last_candidates = plan->candidates;
   }
   UCD_REQUIRE(plan->workspace <= workspace_bytes || plan->workspace == 0, UCD_EWORKSPACE, "%s: workspace too small", fn);
-  return launch(*plan, ltA, ltB, C, workspace, s);
+  return launch(*plan, ltA, ltB, C, workspace, s, beta);
+}
+
+int ucd_gemm_bf16(int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                  void* workspace, size_t workspace_bytes, int tune, ucd_stream_t stream) {
+  return gemm_impl("ucd_gemm_bf16", mode, M, N, K, A, lda, B, ldb, C, ldc, workspace, workspace_bytes, tune, 0.f, stream);
+}
+
+/* C += op(A) op(B): same plan (algorithm) as ucd_gemm_bf16 for the shape; never tunes (tuning relaunches, which would
+ * accumulate several times) - warm the shape with ucd_gemm_bf16(tune = 1) into a scratch matrix first */
+int ucd_gemm_bf16_acc(int mode, int M, int N, int K, const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                      void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  return gemm_impl("ucd_gemm_bf16_acc", mode, M, N, K, A, lda, B, ldb, C, ldc, workspace, workspace_bytes, 0, 1.f, stream);
+}
+
+int ucd_gemm_has_plan(int mode, int M, int N, int K, int lda, int ldb, int ldc) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return g_plans.count(Key(mode, M, N, K, lda, ldb, ldc)) ? 1 : 0;
 }
 
 /* introspection for tools/tests: tuned duration (us, -1 if not tuned) and number of candidates of the last plan used */

@@ -49,6 +49,8 @@ SIGNATURES = {
     "ucd_gemm_load": (_i, [C.c_char_p]),
     "ucd_gemm_workspace_bytes": (_z, []),
     "ucd_gemm_bf16": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _z, _i, _p]),
+    "ucd_gemm_bf16_acc": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _z, _p]),
+    "ucd_gemm_has_plan": (_i, [_i, _i, _i, _i, _i, _i, _i]),
     "ucd_gemm_last_tuned_us": (_f, []),
     "ucd_gemm_last_candidates": (_i, []),
     "ucd_comm_load": (_i, [C.c_char_p]),
