@@ -13,8 +13,12 @@ MI355X design notes
     (the frozen teacher) InPlaceABN / InPlaceABNSync do overwrite their input, as their contract says;
   * the block epilogue ``+ residual -> leaky_relu`` and the ASPP ``cat`` / ``+= pool`` ride in the
     same passes (``forward(..., residual=)``, ``forward_branches``, ``forward(..., plane_bias=)``);
-  * InPlaceABNSync all-reduces one packed ``[sum, sum_sq, count]`` (forward) / ``[sum_dz, sum_dz_xhat]``
-    (backward) vector per layer over RCCL; without an initialised process group it is InPlaceABN.
+  * InPlaceABNSync exchanges one packed ``(mean_r, M2_r)`` vector per layer in the forward (all-gather, combined with
+    Chan's formula on the device) and ``[sum_dz, sum_dz_xhat]`` in the backward (all-reduce) - over a library-owned RCCL
+    communicator on the compute stream inside the layer's library call (``ucd_amd/comm.py``), or ``torch.distributed``
+    when that is unavailable; without an initialised process group it is InPlaceABN;
+  * the student's training-mode layers run through a C++ autograd node (``csrc/abn_node.cpp``) when it is built; the
+    Python ``_ABNFunction`` below is the complete implementation and the fallback.
 Semantics follow ``F.batch_norm`` + ``leaky_relu`` (biased batch variance, unbiased running variance,
 eps 1e-5, momentum 0.1); inplace_abn's ``abs(gamma) + eps`` re-parameterisation is not reproduced
 (its source is not in the reference tree; the two coincide for the positive gammas of the pretrained
