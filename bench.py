@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--no_kernel_timing", action="store_true")
     p.add_argument("--no_miopen_find", action="store_true", help="skip the MIOpen solver search (default: search; ~2 min of warm-up, 25 % faster convolutions)")
     p.add_argument("--pixcon_precision", default=None, choices=["f32", "f16"])
+    # test hooks: run the N > 1 code path with several ranks on ONE GPU (RCCL refuses that; gloo carries CUDA tensors)
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    p.add_argument("--device", type=int, default=None, help=argparse.SUPPRESS)
     return p.parse_args()
 
 
@@ -139,11 +142,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank if args.device is None else args.device)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=args.backend)
     assert args.global_batch % world == 0
     per_rank = args.global_batch // world
     torch.backends.cudnn.benchmark = not args.no_miopen_find

@@ -7,6 +7,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -191,3 +192,21 @@ def test_library_owned_rccl_communicator_world1(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIRECT_RCCL_OK" in r.stdout
+
+
+def test_bench_multi_rank_path_two_ranks_one_gpu(tmp_path):
+    """bench.py's N > 1 branch (rank-sharded batch, DDP + SyncBN, barrier-bracketed timing, MAX over ranks, one JSON line
+    from rank 0) with two ranks on one GPU over gloo, at a small crop."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29725", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "3", "--global_batch", "4", "--crop", "129",
+                        "--backend", "gloo", "--device", "0", "--no_miopen_find", "--no_cpu_baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
+    assert all(np.isfinite(v) for v in d["losses"].values())
