@@ -208,3 +208,24 @@ def test_bf16_working_weights_equal_per_call_casts(tmp_path):
               "module.head.red_conv.weight", "module.body.mod5.block1.convs.bn3.weight"):
         d = (sa[k] - sb[k]).norm() / sa[k].norm()
         assert d < 1e-6, (k, d.item())
+
+
+def test_validation_loop_device_metrics():
+    """Trainer.validate (train.py:185-270 of the reference): class loss + confusion matrix accumulated on the device;
+    an untrained student predicts some class everywhere, so only the invariants are asserted: every labelled pixel is
+    counted once and the scores are consistent with the matrix."""
+    from ucd_amd.metrics import StreamSegMetrics
+    from ucd_amd.run import SyntheticSegmentation
+    from ucd_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    opts = _opts(["--opt_level", "O1"])
+    model, model_old, classes = _build(opts, dev)
+    trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+    ds = SyntheticSegmentation(4, 129, list(range(16, 21)), seed=3)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2)
+    metrics = StreamSegMetrics(21)
+    (class_loss, reg_loss), score, _ = trainer.validate(loader, metrics)
+    assert torch.isfinite(class_loss).item() and class_loss.item() > 0
+    labelled = sum(int(((lab >= 0) & (lab < 21)).sum()) for _, lab in loader)
+    assert metrics.confusion_matrix.is_cuda and int(metrics.confusion_matrix.sum().item()) == labelled
+    assert score["Total samples"] == 4 and 0.0 <= score["Mean IoU"] <= 1.0 and 0.0 <= score["Overall Acc"] <= 1.0
