@@ -341,6 +341,17 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
                    float ce_weight, float kd_weight, float* loss_out, float* d_sem, int ld_d,
                    void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
+/* ---- label path of the training data pipeline on the device (first piece) ------------------------
+ * Replaces, for the label maps of a batch, the reference's host-side RandomResizedCrop (crop + PIL NEAREST resize,
+ * dataset/transform.py:481-553), RandomHorizontalFlip (:300-318) and the per-pixel Python lambda that remaps labels for
+ * the incremental step (dataset/voc.py:176-203).  Bit-exact (index arithmetic of Pillow's NEAREST resize).
+ *   src     B device pointers (array in device memory) to uint8 label maps, image b is [H0_b][W0_b] row-major
+ *   desc    int32 [B][8] in device memory: {H0, W0, i, j, h, w, flip, 0}  (crop box top-left (i, j), size (h, w))
+ *   lut     uint8 [256]: value after remapping for every stored label (inverted_order / masking_value)
+ *   tables  int32 workspace [B][2][S];  out  int64 [B][S][S] (the labels tensor the train step takes) */
+int ucd_label_path(const uint8_t* const* src, const int* desc, int B, int S, const uint8_t* lut, int* tables,
+                   int64_t* out, ucd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,95 @@
+"""Label path of the training data pipeline on the device (first piece).
+
+Host-side mirror of what the reference does per image on the CPU: the target transform of
+``dataset/voc.py:143-203`` (``VOCSegmentationIncremental``: re-ordering of the label ids for the incremental step and
+masking of the classes that are not visible, executed there as a Python lambda per pixel) and, for the label map,
+``RandomResizedCrop`` + ``RandomHorizontalFlip`` of ``dataset/transform.py:300-318,481-553``.  The random parameters are
+drawn exactly like the reference draws them (``RandomResizedCrop.get_params``, ``random.random() < 0.5``); the pixel work
+of the whole batch is one ``ucd_label_path`` call on label maps that stay resident in HBM.
+
+The image half of the pipeline (PIL BILINEAR resize with its 8-bit fixed-point coefficients, ToTensor, Normalize) is not
+built yet; see DESIGN.md section 8.
+"""
+from __future__ import annotations
+
+import math
+import random
+
+import torch
+
+from . import hip
+
+
+def target_lut(labels, labels_old, masking=True, data_masking="current"):
+    """uint8 [256] table: stored label id -> id seen by the step (``voc.py:143-203``)."""
+    labels = [0] + [l for l in labels if l != 0]
+    labels_old = [0] + [l for l in labels_old if l != 0]
+    order = [0] + labels_old[1:] + labels[1:]
+    inverted_order = {label: order.index(label) for label in order}
+    inverted_order[255] = 255
+    masking_value = 0                       # future classes are background
+    if not masking:
+        raise AssertionError("masking=False is not a path of the reference (voc.py:206 asserts)")
+    if data_masking == "current":
+        tmp_labels = labels + [255]
+    elif data_masking == "current+old":
+        tmp_labels = labels_old[1:] + labels + [255]
+    elif data_masking == "new":
+        tmp_labels = labels
+        masking_value = 255
+    else:
+        raise NotImplementedError(f"data_masking={data_masking} not yet implemented sorry not sorry.")   # voc.py:196-198
+    return torch.tensor([inverted_order[x] if x in tmp_labels else masking_value for x in range(256)], dtype=torch.uint8)
+
+
+def random_resized_crop_params(height, width, scale=(0.5, 2.0), ratio=(3. / 4., 4. / 3.)):
+    """``RandomResizedCrop.get_params`` (transform.py:505-540): (i, j, h, w), same draws from ``random`` in the same order."""
+    area = width * height
+    for _ in range(10):
+        target_area = random.uniform(*scale) * area
+        log_ratio = (math.log(ratio[0]), math.log(ratio[1]))
+        aspect_ratio = math.exp(random.uniform(*log_ratio))
+        w = int(round(math.sqrt(target_area * aspect_ratio)))
+        h = int(round(math.sqrt(target_area / aspect_ratio)))
+        if w <= width and h <= height:
+            i = random.randint(0, height - h)
+            j = random.randint(0, width - w)
+            return i, j, h, w
+    in_ratio = width / height
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+class DeviceLabelPath:
+    """labels of a batch: ``__call__(label_maps, boxes, flips) -> int64 [B, S, S]`` on the device.
+    ``label_maps``: list of uint8 device tensors [H0_b, W0_b]; ``boxes``: list of (i, j, h, w); ``flips``: list of bool."""
+
+    def __init__(self, size, lut):
+        self.size = int(size)
+        self.lut = lut
+
+    def __call__(self, label_maps, boxes, flips):
+        B, S = len(label_maps), self.size
+        dev = label_maps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("ucd_amd.datapipe runs on the GPU only (there is no CPU fallback)")
+        maps = [m if (m.dtype == torch.uint8 and m.is_contiguous()) else m.to(torch.uint8).contiguous() for m in label_maps]
+        lut = self.lut.to(dev)
+        desc = torch.tensor([[m.shape[0], m.shape[1], b[0], b[1], b[2], b[3], int(bool(f)), 0]
+                             for m, b, f in zip(maps, boxes, flips)], dtype=torch.int32).to(dev, non_blocking=True)
+        for m, (i, j, h, w) in zip(maps, boxes):
+            if not (0 <= i and 0 <= j and h > 0 and w > 0 and i + h <= m.shape[0] and j + w <= m.shape[1]):
+                raise ValueError(f"crop box {(i, j, h, w)} outside a {tuple(m.shape)} label map")
+        ptrs = torch.tensor([m.data_ptr() for m in maps], dtype=torch.int64).to(dev, non_blocking=True)
+        tables = torch.empty(B * 2 * S, dtype=torch.int32, device=dev)
+        out = torch.empty(B, S, S, dtype=torch.int64, device=dev)
+        hip._check(hip.load().ucd_label_path(hip.ptr(ptrs), hip.ptr(desc), B, S, hip.ptr(lut), hip.ptr(tables), hip.ptr(out),
+                                             hip.stream()), "ucd_label_path")
+        return out
