@@ -352,6 +352,17 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
 int ucd_label_path(const uint8_t* const* src, const int* desc, int B, int S, const uint8_t* lut, int* tables,
                    int64_t* out, ucd_stream_t stream);
 
+/* Image half of the same pipeline: crop + Pillow BILINEAR resize (8-bit, separable, anti-aliased when down-scaling; the
+ * fixed-point arithmetic of Pillow's Resample.c, bit-exact) + horizontal flip + ToTensor + Normalize
+ * (dataset/transform.py:481-553, 300-318, 37-86; run.py:49-55).
+ *   src   B device pointers to decoded uint8 RGB images [H0_b][W0_b][3];   desc as in ucd_label_path
+ *   kmax  >= ceil(max(1, max crop extent / S)) * 2 + 1;   hmax >= max crop height of the batch
+ *   mean_* / std_*  the Normalize constants;   coeff_ws int32 [B][2][S][kmax + 2];   tmp uint8 [B][hmax][S][3]
+ *   out   float32 [B][S][S][3] = the channels-last storage of the [B, 3, S, S] batch */
+int ucd_image_path(const uint8_t* const* src, const int* desc, int B, int S, int kmax, int hmax, float mean_r, float mean_g,
+                   float mean_b, float std_r, float std_g, float std_b, int* coeff_ws, uint8_t* tmp, float* out,
+                   ucd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

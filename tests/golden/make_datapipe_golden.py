@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 sys.path.insert(0, "/root/reference")
 import tasks as ref_tasks                                  # the reference's own task tables
-from oracle.datapipe import label_path_pil
+from oracle.datapipe import label_path_pil, image_path_pil
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 out = {}
@@ -43,5 +43,22 @@ for k in range(12):
     if S <= 64:
         out[f"case{k}::out"] = res.astype(np.uint8)
 out["cases"] = np.array(cases, dtype=np.int64)
+# ---- image half: crop + Pillow BILINEAR resize + flip + ToTensor + Normalize (torch) ----
+rng = np.random.RandomState(4048)
+icases = []
+for k in range(10):
+    H0, W0 = int(rng.randint(100, 501)), int(rng.randint(100, 501))
+    img = (rng.randint(0, 256, size=(H0 // 4 + 1, W0 // 4 + 1, 3)).repeat(4, 0).repeat(4, 1)[:H0, :W0]
+           + rng.randint(-9, 10, size=(H0, W0, 3))).clip(0, 255).astype(np.uint8)
+    h, w = int(rng.randint(30, H0 + 1)), int(rng.randint(30, W0 + 1))
+    i, j = int(rng.randint(0, H0 - h + 1)), int(rng.randint(0, W0 - w + 1))
+    S = [33, 64, 129, 513, 48][k % 5]
+    flip = int(k % 2 == 1)
+    res = image_path_pil(img, (i, j, h, w), S, flip)
+    icases.append([H0, W0, i, j, h, w, flip, S])
+    out[f"img{k}::crc"] = np.array([zlib.crc32(np.ascontiguousarray(res).tobytes())], dtype=np.int64)
+    if S <= 48:
+        out[f"img{k}::out"] = res
+out["icases"] = np.array(icases, dtype=np.int64)
 np.savez_compressed(os.path.join(HERE, "datapipe.npz"), **out)
 print("wrote datapipe.npz:", len(cases), "cases")

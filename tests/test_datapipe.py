@@ -11,7 +11,7 @@ import torch
 from conftest import load_golden
 from oracle import datapipe as OD
 from ucd_amd import tasks
-from ucd_amd.datapipe import DeviceLabelPath, random_resized_crop_params, target_lut
+from ucd_amd.datapipe import DeviceImagePath, DeviceLabelPath, random_resized_crop_params, target_lut
 
 LUTS = {"voc_15-5_s1": ("voc", "15-5", 1, "current"), "voc_15-5s_s3": ("voc", "15-5s", 3, "current"),
         "voc_19-1_s1_old": ("voc", "19-1", 1, "current+old"), "voc_10-10_s1_new": ("voc", "10-10", 1, "new")}
@@ -91,3 +91,45 @@ def test_device_label_path_bit_exact():
             res = out[n].cpu().numpy()
             assert zlib.crc32(res.tobytes()) == int(g[f"case{k}::crc"][0]), (k, S)
             assert np.array_equal(res, OD.label_path(lbl, box, S, flip, g["lut::voc_15-5_s1"]))
+
+
+def _image(rng, H0, W0):
+    return (rng.randint(0, 256, size=(H0 // 4 + 1, W0 // 4 + 1, 3)).repeat(4, 0).repeat(4, 1)[:H0, :W0]
+            + rng.randint(-9, 10, size=(H0, W0, 3))).clip(0, 255).astype(np.uint8)
+
+
+def _icases(g):
+    rng = np.random.RandomState(4048)
+    for k, (H0, W0, i, j, h, w, flip, S) in enumerate(g["icases"].tolist()):
+        a, b = int(rng.randint(100, 501)), int(rng.randint(100, 501))
+        assert (a, b) == (H0, W0)
+        img = _image(rng, H0, W0)
+        rng.randint(30, H0 + 1); rng.randint(30, W0 + 1); rng.randint(0, H0 - h + 1); rng.randint(0, W0 - w + 1)
+        yield k, img, (i, j, h, w), bool(flip), S
+
+
+def test_oracle_image_path_matches_pillow_torch_golden():
+    """Pillow's 8-bit BILINEAR resampler (fixed-point coefficients, anti-aliased down-scaling) + ToTensor + Normalize,
+    restated in numpy: bit-identical float32 output to Pillow + torch on ten crops (up- and down-scaling, flips)."""
+    g = load_golden("datapipe.npz")
+    for k, img, box, flip, S in _icases(g):
+        res = np.ascontiguousarray(OD.image_path(img, box, S, flip))
+        assert zlib.crc32(res.tobytes()) == int(g[f"img{k}::crc"][0]), k
+        if S <= 48:
+            assert np.array_equal(res, g[f"img{k}::out"])
+
+
+@pytest.mark.gpu
+def test_device_image_path_bit_exact():
+    g = load_golden("datapipe.npz")
+    dev = torch.device("cuda:0")
+    by_size = {}
+    for k, img, box, flip, S in _icases(g):
+        by_size.setdefault(S, []).append((k, img, box, flip))
+    for S, items in by_size.items():
+        out = DeviceImagePath(S)([torch.from_numpy(im).to(dev) for _, im, _, _ in items], [b for _, _, b, _ in items],
+                                 [f for _, _, _, f in items])
+        assert out.shape == (len(items), 3, S, S) and out.is_contiguous(memory_format=torch.channels_last)
+        for n, (k, img, box, flip) in enumerate(items):
+            res = np.ascontiguousarray(out[n].cpu().numpy())
+            assert zlib.crc32(res.tobytes()) == int(g[f"img{k}::crc"][0]), (k, S)

@@ -7,8 +7,9 @@ masking of the classes that are not visible, executed there as a Python lambda p
 drawn exactly like the reference draws them (``RandomResizedCrop.get_params``, ``random.random() < 0.5``); the pixel work
 of the whole batch is one ``ucd_label_path`` call on label maps that stay resident in HBM.
 
-The image half of the pipeline (PIL BILINEAR resize with its 8-bit fixed-point coefficients, ToTensor, Normalize) is not
-built yet; see DESIGN.md section 8.
+``DeviceImagePath`` is the image half: crop + Pillow's BILINEAR resize (its 8-bit separable resampler with 22-bit
+fixed-point coefficients, bit-exact) + flip + ``ToTensor`` + ``Normalize`` (``transform.py:37-86``, ``run.py:49-55``) for
+decoded uint8 RGB images resident in HBM; JPEG decoding itself stays on the host.
 """
 from __future__ import annotations
 
@@ -93,3 +94,35 @@ class DeviceLabelPath:
         hip._check(hip.load().ucd_label_path(hip.ptr(ptrs), hip.ptr(desc), B, S, hip.ptr(lut), hip.ptr(tables), hip.ptr(out),
                                              hip.stream()), "ucd_label_path")
         return out
+
+
+class DeviceImagePath:
+    """images of a batch: ``__call__(images, boxes, flips) -> float32 [B, 3, S, S]`` (channels-last storage) on the
+    device.  ``images``: list of uint8 device tensors [H0_b, W0_b, 3] (decoded RGB)."""
+
+    def __init__(self, size, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+        self.size, self.mean, self.std = int(size), tuple(float(v) for v in mean), tuple(float(v) for v in std)
+
+    def __call__(self, images, boxes, flips):
+        B, S = len(images), self.size
+        dev = images[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("ucd_amd.datapipe runs on the GPU only (there is no CPU fallback)")
+        imgs = [m if (m.dtype == torch.uint8 and m.is_contiguous()) else m.to(torch.uint8).contiguous() for m in images]
+        for m, (i, j, h, w) in zip(imgs, boxes):
+            if m.dim() != 3 or m.shape[2] != 3:
+                raise ValueError("images must be [H, W, 3] uint8 RGB")
+            if not (0 <= i and 0 <= j and h > 0 and w > 0 and i + h <= m.shape[0] and j + w <= m.shape[1]):
+                raise ValueError(f"crop box {(i, j, h, w)} outside a {tuple(m.shape)} image")
+        hmax = max(b[2] for b in boxes)
+        extent = max(max(b[2], b[3]) for b in boxes)
+        kmax = int(math.ceil(max(1.0, extent / S))) * 2 + 1
+        desc = torch.tensor([[m.shape[0], m.shape[1], b[0], b[1], b[2], b[3], int(bool(f)), 0]
+                             for m, b, f in zip(imgs, boxes, flips)], dtype=torch.int32).to(dev, non_blocking=True)
+        ptrs = torch.tensor([m.data_ptr() for m in imgs], dtype=torch.int64).to(dev, non_blocking=True)
+        coeff = torch.empty(B * 2 * S * (kmax + 2), dtype=torch.int32, device=dev)
+        tmp = torch.empty(B * hmax * S * 3, dtype=torch.uint8, device=dev)
+        out = torch.empty(B, S, S, 3, dtype=torch.float32, device=dev)
+        hip._check(hip.load().ucd_image_path(hip.ptr(ptrs), hip.ptr(desc), B, S, kmax, hmax, *self.mean, *self.std,
+                                             hip.ptr(coeff), hip.ptr(tmp), hip.ptr(out), hip.stream()), "ucd_image_path")
+        return out.permute(0, 3, 1, 2)            # [B, 3, S, S] with channels-last strides

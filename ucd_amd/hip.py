@@ -47,6 +47,7 @@ SIGNATURES = {
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
     "ucd_label_path": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
+    "ucd_image_path": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
     "ucd_gemm_load": (_i, [C.c_char_p]),
     "ucd_gemm_workspace_bytes": (_z, []),
     "ucd_gemm_bf16": (_i, [_i, _i, _i, _i, _p, _i, _p, _i, _p, _i, _p, _z, _i, _p]),
