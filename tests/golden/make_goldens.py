@@ -259,8 +259,41 @@ def gold_model():
          running_mean_after=student.body.mod1.bn1.running_mean.numpy().copy())
 
 
+def gold_cfg0():
+    """BASELINE.json configs[0]: VOC 19-1 step 0, --method FT (plain cross entropy, no teacher), 2 synthetic 256x256
+    images, single-process CPU fp32, through the reference's own model classes (train.py:108,116 with model_old None;
+    run.py:175-186 optimiser with the step-0 learning rate 0.01)."""
+    models, modules, segm = import_reference_model()
+    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    body = models.net_resnet101(norm_act=norm, output_stride=16)
+    head = modules.DeeplabV3(body.out_channels, 256, 256, norm_act=norm, out_stride=16, pooling_size=32)
+    model = segm.IncrementalSegmentationModule(body, head, 256, classes=[20])
+    model.load_state_dict(synth.fill_state_dict(model.state_dict(), 43))
+    model.train()
+    img = synth.images(777, 2, 256)
+    labels = synth.seg_labels(777, 2, 256, 256, range(1, 20))
+    groups = [{"params": [p for p in m.parameters() if p.requires_grad], "weight_decay": 1e-4}
+              for m in (model.body, model.head, model.cls)]
+    opt = torch.optim.SGD(groups, lr=1e-2, momentum=0.9, nesterov=True)
+    opt.zero_grad()
+    out, feat = model(img)
+    loss = torch.nn.CrossEntropyLoss(ignore_index=255, reduction="none")(out, labels).mean()
+    loss.backward()
+    names = ["body.mod1.conv1.weight", "body.mod4.block7.convs.bn2.weight", "head.red_conv.weight", "head.map_bn.bias", "body.mod5.block1.proj_conv.weight"]
+    params = dict(model.named_parameters())
+    grads = {f"grad_abs::{n}": params[n].grad.double().abs().sum().item() for n in names}
+    opt.step()
+    upd = {f"after_step::{n}": params[n].detach().flatten()[:16].numpy().copy() for n in names}
+    idx = sample_idx(out.numel(), 256)
+    save("cfg0_step.npz", cfg=np.array([777, 2, 256]), loss=loss.item(), logits_abs=out.double().abs().sum().item(),
+         logits_sample=out.detach().flatten()[idx].numpy(), sample_idx=idx, sem=feat["sem"].detach().numpy()[:, :, ::4, ::4].copy(),
+         **grads, **upd)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pixcon", "logit", "v1", "model"]
+    which = sys.argv[1:] or ["pixcon", "logit", "v1", "model", "cfg0"]
+    if "cfg0" in which:
+        gold_cfg0()
     if "pixcon" in which:
         gold_pixcon()
     if "logit" in which:

@@ -94,3 +94,24 @@ def test_ucd_step_matches_reference():
     for n in names:
         np.testing.assert_allclose(Ps[n].detach().flatten()[:16].numpy(), g[f"after_step::{n}"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(Ps["body.mod1.bn1.running_mean"].numpy(), g["running_mean_after"], rtol=1e-5, atol=1e-6)
+
+
+def test_config0_voc_19_1_step0_ft_matches_reference():
+    """BASELINE.json configs[0]: VOC 19-1 step 0, --method FT (plain cross entropy, no teacher), 2 synthetic 256x256
+    images on the CPU - the reference's own CPU-runnable case (golden: tests/golden/make_goldens.py::gold_cfg0)."""
+    from oracle.params import template_state
+    g = load_golden("cfg0_step.npz")
+    P = OS.make_params(synth.fill_state_dict(template_state([20]), 43))
+    P["cls.0.weight"].requires_grad_(False); P["cls.0.bias"].requires_grad_(False)      # segmentation_module.py:75-78
+    img = synth.images(777, 2, 256)
+    labels = synth.seg_labels(777, 2, 256, 256, range(1, 20))
+    out, feat = OM.segmentation_forward(img, P, 1, training=True)
+    loss = torch.nn.functional.cross_entropy(out, labels, ignore_index=255, reduction="none").mean()     # train.py:30,116
+    assert loss.item() == pytest.approx(float(g["loss"]), rel=1e-4)
+    assert out.double().abs().sum().item() == pytest.approx(float(g["logits_abs"]), rel=1e-4)
+    np.testing.assert_allclose(feat["sem"].detach().numpy()[:, :, ::4, ::4], g["sem"], rtol=1e-3, atol=1e-3)
+    loss.backward()
+    for k in g:
+        if k.startswith("grad_abs::"):
+            n = k.split("::")[1]
+            assert P[n].grad.double().abs().sum().item() == pytest.approx(float(g[k]), rel=2e-3), n

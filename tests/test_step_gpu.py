@@ -229,3 +229,44 @@ def test_validation_loop_device_metrics():
     labelled = sum(int(((lab >= 0) & (lab < 21)).sum()) for _, lab in loader)
     assert metrics.confusion_matrix.is_cuda and int(metrics.confusion_matrix.sum().item()) == labelled
     assert score["Total samples"] == 4 and 0.0 <= score["Mean IoU"] <= 1.0 and 0.0 <= score["Overall Acc"] <= 1.0
+
+
+def test_config0_voc_19_1_step0_ft_matches_reference_golden():
+    """BASELINE.json configs[0] on the GPU path: VOC 19-1 step 0, --method FT (no teacher: plain CE through the fused
+    up-sampling + loss kernel), 2 synthetic 256x256 images, fp32 - loss and logits within 1e-3 of the reference's CPU
+    run (golden captured through the reference's own model classes)."""
+    from ucd_amd.run import build_models, make_optimizer
+    from ucd_amd.train import Trainer
+    g = load_golden("cfg0_step.npz")
+    dev = torch.device("cuda:0")
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
+        ["--method", "FT", "--task", "19-1", "--step", "0", "--lr", "0.01", "--no_pretrained", "--norm_act", "iabn_sync"]))
+    classes = tasks.get_per_task_classes("voc", "19-1", 0)
+    assert classes == [20]
+    torch.backends.cudnn.allow_tf32 = False
+    model, model_old = build_models(opts, dev, classes)
+    assert model_old is None
+    model.load_state_dict(synth.fill_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, 43))
+    trainer = Trainer(model, None, device=dev, opts=opts, classes=classes)
+    optim = make_optimizer(opts, model)
+    img = synth.images(777, 2, 256)
+    labels = synth.seg_labels(777, 2, 256, 256, range(1, 20))
+    model.train()
+    with torch.no_grad():
+        pass
+    before = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}
+    r = trainer.train_step(img, labels, optim, None)
+    torch.cuda.synchronize()
+    assert r["loss"].item() == pytest.approx(float(g["loss"]), rel=1e-3)
+    assert r["ce"].item() == pytest.approx(float(g["loss"]), rel=1e-3)
+    params = dict(model.named_parameters())
+    for k in g:
+        if k.startswith("grad_abs::"):
+            n = k.split("::")[1]
+            assert params[n].grad.double().abs().sum().item() == pytest.approx(float(g[k]), rel=0.1), n   # see module docstring
+            p0 = before[n].flatten()[:16].double().numpy()
+            up = params[n].detach().flatten()[:16].cpu().double().numpy() - p0
+            ur = g[f"after_step::{n}"].astype(np.float64) - p0
+            if np.linalg.norm(ur) > 1e-7:
+                cos = float(up @ ur / (np.linalg.norm(up) * np.linalg.norm(ur) + 1e-30))
+                assert cos > 0.9, (n, cos)
