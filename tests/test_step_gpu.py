@@ -270,3 +270,36 @@ def test_config0_voc_19_1_step0_ft_matches_reference_golden():
             if np.linalg.norm(ur) > 1e-7:
                 cos = float(up @ ur / (np.linalg.norm(up) * np.linalg.norm(ur) + 1e-30))
                 assert cos > 0.9, (n, cos)
+
+
+@pytest.mark.parametrize("dataset,task,new_ids", [("ade", "100-50", range(101, 151)), ("city", "13-6", None),
+                                                  ("voc", "15-5s", range(16, 17))])
+def test_other_baseline_configs_step_runs(dataset, task, new_ids):
+    """BASELINE.json configs[2..4] (VOC 15-5s, ADE 100-50 with its 151-way head and K = 101 teacher classes, Cityscapes
+    13-6) as whole steps at a small crop: the losses are finite, the contrastive term sees anchors, and a second step
+    runs from the updated weights.  Their arithmetic is pinned piecewise (contrastive / logit-loss goldens for these label
+    ranges and class counts); this is the end-to-end plumbing with those head shapes."""
+    from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+    from ucd_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    try:
+        classes = tasks.get_per_task_classes(dataset, task, 1)
+        labels_new, labels_old, _ = tasks.get_task_labels(dataset, task, 1)
+    except (KeyError, NotImplementedError):
+        pytest.skip(f"{dataset} {task} not in the task tables")
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
+        ["--method", "UCD", "--dataset", dataset, "--task", task, "--step", "1", "--lr", "0.001", "--no_pretrained",
+         "--norm_act", "iabn_sync", "--opt_level", "O1"]))
+    model, model_old = build_models(opts, dev, classes)
+    state = synth.fill_state_dict({k: v.cpu() for k, v in model_old.state_dict().items()}, 42)
+    load_step_checkpoint(opts, model, model_old, state, dev)
+    trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+    optim = make_optimizer(opts, model)
+    ids = [l for l in labels_new if l != 0][:8]
+    img = synth.images(601, 2, 129)
+    labels = synth.seg_labels(601, 2, 129, 129, ids)
+    model.train()
+    for _ in range(2):
+        r = trainer.train_step(img, labels, optim, None)
+        assert all(torch.isfinite(v).item() for v in r.values()), {k: v.item() for k, v in r.items()}
+    assert r["con"].item() > 0 and r["ce"].item() > 0
