@@ -137,6 +137,15 @@ def main(opts):
             p.requires_grad = False
         model_old.eval()
     trainer = Trainer(model, model_old, device=device, opts=opts, classes=classes)
+    # validation set + streaming metrics (run.py:161-164, 304-338): synthetic images carrying every class seen so far
+    n_classes = sum(classes)
+    seen = [l for l in (list(labels_old) + list(labels)) if l != 0] or [1]
+    val_dst = SyntheticSegmentation(max(2 * opts.batch_size, 2), opts.crop_size, seen, seed=1000 + opts.step)
+    val_loader = torch.utils.data.DataLoader(
+        val_dst, batch_size=opts.batch_size if opts.crop_val else 1,
+        sampler=torch.utils.data.distributed.DistributedSampler(val_dst, num_replicas=world_size, rank=rank, shuffle=False),
+        num_workers=opts.num_workers)
+    val_metrics = StreamSegMetrics(n_classes)
 
     cur_epoch, best_score = 0, 0.0
     if opts.ckpt is not None and os.path.isfile(opts.ckpt):
@@ -150,6 +159,16 @@ def main(opts):
         epoch_loss = trainer.train(cur_epoch=cur_epoch, optim=optimizer, train_loader=train_loader,
                                    scheduler=scheduler, print_int=opts.print_interval, logger=logger)
         logger.info(f"End of Epoch {cur_epoch}/{opts.epochs}, Average Loss={float(epoch_loss[0]) + float(epoch_loss[1])}")
+        if (cur_epoch + 1) % opts.val_interval == 0:                     # run.py:304-316
+            logger.info("validate on val set...")
+            model.eval()
+            val_loss, val_score, _ = trainer.validate(loader=val_loader, metrics=val_metrics, logger=logger)
+            logger.info(f"End of Validation {cur_epoch}/{opts.epochs}, Validation Loss={float(val_loss[0]) + float(val_loss[1])},"
+                        f" Class Loss={float(val_loss[0])}, Reg Loss={float(val_loss[1])}")
+            if rank == 0:
+                logger.info(val_metrics.to_str(val_score))
+                best_score = val_score["Mean IoU"]
+            model.train()
         if rank == 0 and (cur_epoch + 1) % opts.ckpt_interval == 0:
             save_ckpt(ckpt_path, model, trainer, optimizer, scheduler, cur_epoch, best_score)
         dist.barrier()
