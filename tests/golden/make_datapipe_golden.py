@@ -60,5 +60,26 @@ for k in range(10):
     if S <= 48:
         out[f"img{k}::out"] = res
 out["icases"] = np.array(icases, dtype=np.int64)
+# ---- crop parameters: the reference's own RandomResizedCrop.get_params (dataset/transform.py:505-540), imported with an
+# empty stand-in for the torchvision module it pulls in at import time (not installed here; get_params does not use it)
+import importlib.util, random, types
+sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+sys.modules.setdefault("torchvision.transforms", types.ModuleType("torchvision.transforms"))
+sys.modules.setdefault("torchvision.transforms.functional", types.ModuleType("torchvision.transforms.functional"))
+spec = importlib.util.spec_from_file_location("ref_transform", "/root/reference/dataset/transform.py")
+ref_transform = importlib.util.module_from_spec(spec); spec.loader.exec_module(ref_transform)
+
+
+class _Size:
+    def __init__(self, w, h): self.size = (w, h)
+
+
+crops = []
+for seed in range(40):
+    H0, W0 = [(375, 500), (500, 333), (281, 500), (442, 500)][seed % 4]
+    random.seed(seed)
+    i, j, h, w = ref_transform.RandomResizedCrop.get_params(_Size(W0, H0), (0.5, 2.0), (3. / 4., 4. / 3.))
+    crops.append([seed, H0, W0, i, j, h, w])
+out["crop_params"] = np.array(crops, dtype=np.int64)
 np.savez_compressed(os.path.join(HERE, "datapipe.npz"), **out)
 print("wrote datapipe.npz:", len(cases), "cases")

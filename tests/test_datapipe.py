@@ -51,28 +51,13 @@ def test_oracle_label_path_matches_pillow_golden():
 
 
 def test_crop_parameters_follow_the_reference_draws():
-    """RandomResizedCrop.get_params (transform.py:505-540) restated literally here: same (i, j, h, w) from the same seed."""
-    import math
-    def ref(height, width, scale, ratio):                   # the reference's code path, with img.size = (width, height)
-        area = width * height
-        for attempt in range(10):
-            target_area = random.uniform(*scale) * area
-            log_ratio = (math.log(ratio[0]), math.log(ratio[1]))
-            aspect_ratio = math.exp(random.uniform(*log_ratio))
-            w = int(round(math.sqrt(target_area * aspect_ratio)))
-            h = int(round(math.sqrt(target_area / aspect_ratio)))
-            if w <= width and h <= height:
-                i = random.randint(0, height - h)
-                j = random.randint(0, width - w)
-                return i, j, h, w
-        return None
-    for seed in range(20):
-        random.seed(seed); a = random_resized_crop_params(375, 500)
-        random.seed(seed); b = ref(375, 500, (0.5, 2.0), (3. / 4., 4. / 3.))
-        if b is not None:
-            assert a == b
-        i, j, h, w = a
-        assert 0 <= i and 0 <= j and i + h <= 375 and j + w <= 500
+    """random_resized_crop_params against (i, j, h, w) produced by the reference's own RandomResizedCrop.get_params
+    (transform.py:505-540, imported by the golden generator) from the same `random` seeds, incl. the fall-back branch."""
+    g = load_golden("datapipe.npz")
+    for seed, H0, W0, i, j, h, w in g["crop_params"].tolist():
+        random.seed(seed)
+        assert random_resized_crop_params(H0, W0, (0.5, 2.0), (3. / 4., 4. / 3.)) == (i, j, h, w), seed
+        assert 0 <= i and 0 <= j and i + h <= H0 and j + w <= W0
 
 
 @pytest.mark.gpu
