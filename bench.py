@@ -189,6 +189,13 @@ def main():
     if not args.no_kernel_timing:
         kernels = kernel_timing(trainer, optimizer, scheduler, images, labels, min(args.steps, 3))
         ev_us = kernels.pop("_event_pair_overhead_us")
+        for kname, kv in kernels.items():                    # per-call-type roofline fractions
+            secs = max(kv["ms_total"] * 1e-3, 1e-12)
+            if kname.startswith("ucd_pixcon_loss"):
+                pk = PEAK_F16_MFMA_TF if "f16" in kname else PEAK_F32_MFMA_TF
+                kv.update(bound="mfma", achieved=kv["work"] / secs / 1e12, unit="TFLOP/s", frac=kv["work"] / secs / 1e12 / pk)
+            else:
+                kv.update(bound="hbm", achieved=kv["work"] / secs / 1e9, unit="GB/s", frac=kv["work"] / secs / 1e9 / PEAK_HBM_GBS)
         name = max(kernels, key=lambda k: kernels[k]["ms_total"])
         k = kernels[name]
         if name.startswith("ucd_pixcon_loss"):
