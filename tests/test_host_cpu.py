@@ -182,3 +182,29 @@ def test_cpp_autograd_node_builds_and_imports():
     import torch
     assert node.dense_channels_last(torch.zeros(2, 8, 3, 3).contiguous(memory_format=torch.channels_last))
     assert not node.dense_channels_last(torch.zeros(2, 8, 3, 3))
+
+
+def test_reducer_widens_working_copy_gradients_into_master_buckets():
+    """ucd_amd.ddp.GradReducer with bf16 working copies (the N = 1 and N > 1 O1 configuration), on the CPU: autograd
+    differentiates the bf16 copy, the bucket's fp32 slot (= master.grad) receives the widened gradient when the bucket
+    completes, a second step does not accumulate on top of the first, and parameters without a working copy still
+    accumulate directly."""
+    import torch
+    from ucd_amd.ddp import GradReducer
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(6, 4, 3, 3).contiguous(memory_format=torch.channels_last))   # conv weight, master
+    b = torch.nn.Parameter(torch.randn(6))                                                            # fp32-only parameter
+    w16 = w.detach().to(torch.bfloat16).requires_grad_(True)                                           # working copy
+    red = GradReducer([w, b], bucket_mb=1.0, shadow_of={w: w16})
+    assert w.grad.stride() == w.stride() and w.grad.dtype == torch.float32
+    x = torch.randn(2, 4, 8, 8)
+    for step in range(2):
+        red.zero_grad()
+        y = torch.nn.functional.conv2d(x.to(torch.bfloat16), w16, padding=1).float() + b.view(1, -1, 1, 1)
+        y.square().mean().backward()
+        red.finish()
+        ref_w, ref_b = torch.autograd.grad((torch.nn.functional.conv2d(x.to(torch.bfloat16), w16, padding=1).float()
+                                            + b.view(1, -1, 1, 1)).square().mean(), (w16, b))
+        assert w16.grad is None                                        # handed over, not kept
+        assert torch.allclose(w.grad, ref_w.float(), rtol=1e-2, atol=1e-3)
+        assert torch.allclose(b.grad, ref_b, rtol=1e-5, atol=1e-6)
