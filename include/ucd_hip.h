@@ -35,7 +35,12 @@ typedef void* ucd_stream_t; /* hipStream_t */
 typedef void* ucd_comm_t;   /* RCCL communicator owned by this library (ucd_comm_init) */
 
 enum ucd_dtype { UCD_F32 = 0, UCD_BF16 = 1 };
-enum ucd_act { UCD_ACT_IDENTITY = 0, UCD_ACT_LEAKY_RELU = 1 };
+enum ucd_act { UCD_ACT_IDENTITY = 0, UCD_ACT_LEAKY_RELU = 1, UCD_ACT_ELU = 2 /* slope = alpha */ };
+/* Flag bits OR-ed into an `act` (or `flags`) argument.  UCD_NORM_ABS_GAMMA selects the parameterisation of
+ * inplace_abn's InPlaceABN / InPlaceABNSync, gamma~ = |weight| + eps in place of weight (their published forward;
+ * d weight = sign(weight) * sum dz*xhat, sign(0) = +1); without it the layer is F.batch_norm (inplace_abn.ABN). */
+#define UCD_ACT_MASK 0xff
+#define UCD_NORM_ABS_GAMMA 0x100
 enum ucd_pixcon_precision { UCD_PIXCON_F32 = 0, UCD_PIXCON_F16 = 1 };
 enum ucd_error {
   UCD_OK = 0,
@@ -77,22 +82,22 @@ int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C,
 int ucd_abn_stats_finalize(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW,
                            float* sums, float* kshift, const float* weight,
                            float* running_mean, float* running_var, float momentum, float eps,
-                           float* mean, float* invstd, float* scale,
+                           float* mean, float* invstd, float* scale, int flags /* 0 or UCD_NORM_ABS_GAMMA */,
                            void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
 /* Batch statistics -> normalisation constants.  With d = sums[c]/count:
  *   mean = kshift + d,  var = (sums[C+c] - sums[c]*d)/count (biased),  invstd = 1/sqrt(var + eps),
- *   scale = weight * invstd;  running_mean / running_var are updated in place with `momentum`
- *   (unbiased variance) unless NULL.  kshift NULL means 0; weight NULL means 1.
+ *   scale = weight * invstd ((|weight| + eps) * invstd with flags = UCD_NORM_ABS_GAMMA);  running_mean / running_var
+ *   are updated in place with `momentum` (unbiased variance) unless NULL.  kshift NULL means 0; weight NULL means 1.
  * For statistics combined across ranks pass kshift = global mean, sums[0:C] = 0, sums[C:2C] = global M2. */
 int ucd_abn_finalize(const float* sums, const float* kshift, float count, int C, const float* weight,
                      float* running_mean, float* running_var, float momentum, float eps,
-                     float* mean, float* invstd, float* scale, ucd_stream_t stream);
+                     float* mean, float* invstd, float* scale, int flags, ucd_stream_t stream);
 
 /* Evaluation mode (teacher; --fix_bn): invstd = 1/sqrt(running_var + eps), scale = weight * invstd; the
  * mean is running_mean itself. */
 int ucd_abn_eval_params(const float* weight, const float* running_var, float eps, int C,
-                        float* invstd, float* scale, ucd_stream_t stream);
+                        float* invstd, float* scale, int flags /* 0 or UCD_NORM_ABS_GAMMA */, ucd_stream_t stream);
 
 /* y = act((x + plane_bias - mean) * scale + shift + residual); shift is the affine bias (NULL = 0);
  * y may alias x (in place) or be a channel slice of a wider buffer (ld_y > C); residual / plane_bias
@@ -106,11 +111,13 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
  *   sums[0:C] = sum dz            (= d bias)
  *   sums[C:2C] = sum dz * xhat    (= d weight),   xhat = (x' - mean) * invstd.
  * The sign of z is taken from y when y != NULL (needed when a residual was fused), else z =
- * (x' - mean) * scale + shift is recomputed from x (shift = the affine bias, NULL = 0). */
+ * (x' - mean) * scale + shift is recomputed from x (shift = the affine bias, NULL = 0).  With UCD_NORM_ABS_GAMMA in
+ * `act`, sums[C:2C] is multiplied by sign(weight[c]) (d weight of gamma~ = |weight| + eps); ucd_abn_bwd_apply with the
+ * same flag undoes the sign, so the pair stays consistent (also across an all-reduce: the sign is rank-independent). */
 int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
                        int dtype, int M, int C, const float* plane_bias, int HW,
                        const float* mean, const float* invstd, const float* scale, const float* shift,
-                       int act, float slope,
+                       const float* weight /* read only with UCD_NORM_ABS_GAMMA */, int act, float slope,
                        float* sums /* [2*C] */, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
 /* Backward, stage 2: dx = (dz - sums[0]/count - xhat * sums[1]/count) * weight * invstd
@@ -164,7 +171,7 @@ int ucd_abn_sync_forward(const void* x, int ld_x, void* y, int ld_y, const void*
 int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
                             int dtype, int M, int C, const float* plane_bias, int HW,
                             const float* mean, const float* invstd, const float* scale, const float* shift,
-                            int act, float slope, float* sums /* [2*C] */, float* local_sums /* [2*C] */,
+                            const float* weight, int act, float slope, float* sums /* [2*C] */, float* local_sums /* [2*C] */,
                             void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
 /* ---- row-major bf16 GEMMs of the wide 1x1 convolutions (modules/residual.py:57-63 builds them as nn.Conv2d(k=1);
@@ -315,6 +322,20 @@ int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label,
                     float temperature, int shift_pos, int use_prob,
                     float* loss_out, float* grad_a /* [BHW, ldg] */, int ldg, float* row_stats,
                     void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* The same loss with the weight matrix P MATERIALISED by the caller: the literal signature of the reference's
+ * PixelConLossV2.forward(anchor_features, contrast_feature, anchor_labels, contrast_labels, P) (utils/loss.py:412), for
+ * callers that hold plain tensors instead of a prepared batch.  chat [Cpad, 256] holds the anchors in rows [0, A) and the
+ * remaining contrast rows (contrast_feature[A:]) in rows [meta->Apad, meta->Apad + Co); contrast_feature[:A] must be the
+ * anchors themselves (the reference's construction, utils/utils.py:362; its self-pair mask `mask_p[:, :A] -= eye`
+ * assumes it).  P is [A, A + Co] row-major in the reference's column order with leading dimension ld_P, or NULL for
+ * P = 1; rows need not be normalised (the row maximum of S is computed, not assumed).  meta: A, Co, Apad, Cpad,
+ * n_valid, sorted = 0 and label_count_c must be filled (device memory); max_anchors sizes the workspace
+ * (ucd_pixcon_loss_workspace_bytes(max_anchors, N, 0)) and must be >= A.  float32 MFMA path only. */
+int ucd_pixcon_loss_given_p(const float* chat, int ldc, int N, const uint8_t* row_label, const float* P, int ld_P,
+                            const ucd_pixcon_meta* meta, int max_anchors, float temperature, int shift_pos,
+                            float* loss_out, float* grad_a, int ldg, float* row_stats,
+                            void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
 /* Chain rule through F.normalize and scatter to the student map:
  *   d f_n[pix(r), :] = grad_scale[0] * inv_norm[r] * (g_r - (g_r . a_r) a_r),  zero for unkept pixels.

@@ -1,6 +1,7 @@
-"""GPU: the HIP ABN kernels (through the C ABI) against torch's batch_norm + leaky_relu on CPU fp32
-(the documented semantics of inplace_abn.ABN - SURVEY.md section 8-c; tolerance 1e-5 abs/rel in
-fp32, bf16 I/O checked against the same fp32 reference at bf16 resolution)."""
+"""GPU: the HIP ABN kernels (through the C ABI) against the oracle's restatement of inplace_abn (oracle/abn.py: CPU fp32
+batch norm + activation; raw gamma for ABN, |gamma| + eps for the in-place variants - third-party wheel, parity unpinned
+by the reference).  Tolerance 1e-5 abs/rel in fp32; bf16 I/O is checked against the same fp32
+oracle at bf16 resolution."""
 import numpy as np
 import pytest
 import torch
@@ -11,13 +12,9 @@ from ucd_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _ref(x, w, b, rm, rv, training, act, slope, residual=None, plane_bias=None, eps=1e-5, momentum=0.1):
-    if plane_bias is not None:
-        x = x + plane_bias
-    y = F.batch_norm(x, rm, rv, w, b, training, momentum, eps)
-    if residual is not None:
-        y = y + residual
-    return F.leaky_relu(y, slope) if act == "leaky_relu" else y
+def _ref(x, w, b, rm, rv, training, act, slope, residual=None, plane_bias=None, eps=1e-5, momentum=0.1, abs_gamma=False):
+    from oracle.abn import abn_forward
+    return abn_forward(x, w, b, rm, rv, training, momentum, eps, act, slope, abs_gamma, residual, plane_bias)
 
 
 def _mk(seed, shape, dev=None, dtype=torch.float32):
@@ -83,7 +80,7 @@ def test_abn_fused_residual_and_plane_bias(B, C, H, W):
     w, b = st["weight"].clone().requires_grad_(True), st["bias"].clone().requires_grad_(True)
     xr, rr, pr = x.clone().requires_grad_(True), r.clone().requires_grad_(True), pb.clone().requires_grad_(True)
     yr = F.leaky_relu(_ref(xr, w, b, st["running_mean"].clone(), st["running_var"].clone(), True, "identity", 0.01,
-                           plane_bias=pr) + rr, 0.01)
+                           plane_bias=pr, abs_gamma=True) + rr, 0.01)
     yr.backward(g)
     m = m.to(dev).train()
     cl = torch.channels_last
@@ -159,8 +156,8 @@ def test_inplace_contract_and_eval_no_grad():
     with torch.no_grad():
         y = m(x)
     assert y.data_ptr() == x.data_ptr()          # overwritten in place, like inplace_abn
-    ref = F.leaky_relu(F.batch_norm(keep.cpu(), m.running_mean.cpu(), m.running_var.cpu(), m.weight.detach().cpu(),
-                                    m.bias.detach().cpu(), False, 0.1, 1e-5), 0.01)
+    ref = _ref(keep.cpu(), m.weight.detach().cpu(), m.bias.detach().cpu(), m.running_mean.cpu(), m.running_var.cpu(), False,
+               "leaky_relu", 0.01, abs_gamma=True)
     torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
 
 
@@ -346,3 +343,203 @@ def test_full_size_batchnorm_invariants(shape):
     scale = dx.abs().mean().item() * n
     assert (dx.sum(dim=(0, 2, 3)).abs().max().item()) / scale < 2e-3                  # bf16 dx: sums cancel to rounding noise
     assert ((dx * xhat).sum(dim=(0, 2, 3)).abs().max().item()) / scale < 2e-3
+
+
+def _signed_state(m, seed):
+    """A state dict whose gammas have both signs (as stored gammas of a trained inplace_abn checkpoint may)."""
+    st = synth.fill_state_dict(m.state_dict(), seed=seed)
+    sign = torch.where(synth.t_normal(seed + 1, st["weight"].shape, stream=9) < 0.3, -1.0, 1.0)
+    st["weight"] = st["weight"] * sign
+    assert (st["weight"] < 0).any() and (st["weight"] > 0).any()
+    return st
+
+
+@pytest.mark.parametrize("cls_name,abs_gamma", [("ABN", False), ("InPlaceABN", True), ("InPlaceABNSync", True)])
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_negative_gamma_parameterisation(cls_name, abs_gamma, training, with_res):
+    """Stored gammas of either sign: ABN is F.batch_norm (raw gamma); InPlaceABN / InPlaceABNSync normalise with
+    |gamma| + eps and return d gamma = sign(gamma) * sum dz*xhat (inplace_abn's published algorithm).  Through the Python
+    Function and (training, no plane bias) the C++ node, with and without the fused residual."""
+    from ucd_amd import abn
+    dev = torch.device("cuda:0")
+    B, C, H, W = 3, 64, 9, 11
+    x = synth.t_normal(61, (B, C, H, W), stream=1) * 1.3 + 0.2
+    r = synth.t_normal(62, (B, C, H, W), stream=1)
+    g = synth.t_normal(63, (B, C, H, W), stream=1)
+    m = getattr(abn, cls_name)(C, activation="identity" if with_res else "leaky_relu")
+    st = _signed_state(m, 17)
+    m.load_state_dict(st)
+    w, b = st["weight"].clone().requires_grad_(True), st["bias"].clone().requires_grad_(True)
+    rm, rv = st["running_mean"].clone(), st["running_var"].clone()
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if with_res else None
+    yr = _ref(xr, w, b, rm, rv, training, "identity" if with_res else "leaky_relu", 0.01, abs_gamma=abs_gamma)
+    if with_res:
+        yr = F.leaky_relu(yr + rr, 0.01)
+    yr.backward(g)
+    m = m.to(dev).train(training)
+    cl = torch.channels_last
+    xg = x.to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    rg = r.to(dev).contiguous(memory_format=cl).requires_grad_(True) if with_res else None
+    yg = m(xg * 1.0, residual=None if rg is None else rg * 1.0, activation="leaky_relu", activation_param=0.01)
+    yg.backward(g.to(dev))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(yg.detach().cpu(), yr.detach(), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(xg.grad.cpu(), xr.grad, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(m.weight.grad.cpu(), w.grad, rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(m.bias.grad.cpu(), b.grad, rtol=2e-4, atol=2e-4)
+    if with_res:
+        torch.testing.assert_close(rg.grad.cpu(), rr.grad, rtol=2e-4, atol=2e-5)
+    if abs_gamma and not with_res:     # the sign matters: the raw-gamma formula gives different activations
+        y_raw = _ref(x, st["weight"], st["bias"], st["running_mean"].clone(), st["running_var"].clone(), training,
+                     "leaky_relu", 0.01, abs_gamma=False)
+        assert (y_raw - yr.detach()).abs().max() > 0.1
+
+
+def test_negative_gamma_state_dict_whole_block_and_branches():
+    """A ResidualBlock and the ASPP branch norm with mixed-sign gammas loaded through load_state_dict (the way a
+    reference checkpoint arrives): the product's InPlaceABNSync layers against the oracle's |gamma| + eps."""
+    from ucd_amd import abn
+    dev = torch.device("cuda:0")
+    B, H, W = 2, 7, 9
+    xs = [synth.t_normal(70 + i, (B, 32, H, W), stream=1) for i in range(4)]
+    g = synth.t_normal(79, (B, 128, H, W), stream=2)
+    for training in (True, False):
+        m = abn.InPlaceABNSync(128)
+        st = _signed_state(m, 23)
+        m.load_state_dict(st)
+        w, b = st["weight"].clone().requires_grad_(True), st["bias"].clone().requires_grad_(True)
+        xr = [x.clone().requires_grad_(True) for x in xs]
+        yr = _ref(torch.cat(xr, 1), w, b, st["running_mean"].clone(), st["running_var"].clone(), training, "leaky_relu", 0.01,
+                  abs_gamma=True)
+        yr.backward(g)
+        m = m.to(dev).train(training)
+        xg = [x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for x in xs]
+        yg = m.forward_branches(xg)
+        yg.backward(g.to(dev))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(yg.detach().cpu(), yr.detach(), rtol=2e-5, atol=2e-5)
+        for a, r in zip(xg, xr):
+            torch.testing.assert_close(a.grad.cpu(), r.grad, rtol=2e-4, atol=2e-5)
+        if training:
+            torch.testing.assert_close(m.weight.grad.cpu(), w.grad, rtol=2e-4, atol=2e-4)
+            torch.testing.assert_close(m.bias.grad.cpu(), b.grad, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_elu_activation(dtype, with_res):
+    """activation="elu" (modules/residual.py:94-95 applies it after the residual add; inplace_abn's ACT_ELU)."""
+    from ucd_amd import abn
+    dev = torch.device("cuda:0")
+    B, C, H, W = 2, 64, 9, 7
+    x = synth.t_normal(81, (B, C, H, W), stream=1).to(dtype)
+    r = synth.t_normal(82, (B, C, H, W), stream=1).to(dtype)
+    g = synth.t_normal(83, (B, C, H, W), stream=1).to(dtype)
+    m = abn.InPlaceABN(C, activation="identity" if with_res else "elu", activation_param=0.9)
+    st = synth.fill_state_dict(m.state_dict(), seed=5)
+    m.load_state_dict(st)
+    w, b = st["weight"].clone().requires_grad_(True), st["bias"].clone().requires_grad_(True)
+    xr = x.float().requires_grad_(True)
+    rr = r.float().requires_grad_(True)
+    yr = _ref(xr, w, b, st["running_mean"].clone(), st["running_var"].clone(), True, "identity" if with_res else "elu", 0.9,
+              abs_gamma=True)
+    if with_res:
+        yr = F.elu(yr + rr, 0.9)
+    yr.backward(g.float())
+    m = m.to(dev).train()
+    cl = torch.channels_last
+    xg = x.to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    rg = r.to(dev).contiguous(memory_format=cl).requires_grad_(True)
+    yg = m(xg * 1.0, residual=rg * 1.0 if with_res else None, activation="elu", activation_param=0.9)
+    yg.backward(g.to(dev))
+    torch.cuda.synchronize()
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=8e-3, atol=8e-3)
+    gtol = dict(rtol=2e-4, atol=5e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1.6e-2)
+    torch.testing.assert_close(yg.detach().float().cpu(), yr.detach(), **tol)
+    torch.testing.assert_close(xg.grad.float().cpu(), xr.grad, **gtol)
+    if with_res:
+        torch.testing.assert_close(rg.grad.float().cpu(), rr.grad, **gtol)
+    if dtype == torch.float32:
+        torch.testing.assert_close(m.weight.grad.cpu(), w.grad, rtol=2e-4, atol=2e-4)
+        torch.testing.assert_close(m.bias.grad.cpu(), b.grad, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_eval_constants_follow_training_and_optimizer_steps(fused):
+    """eval -> train step (kernels update running_var through raw pointers, fused SGD updates gamma without bumping its
+    version counter) -> eval: the cached evaluation-mode constants must be rebuilt (run.py validates after every epoch)."""
+    from ucd_amd import abn
+    dev = torch.device("cuda:0")
+    C = 64
+    m = abn.InPlaceABNSync(C).to(dev)
+    m.load_state_dict(synth.fill_state_dict(m.state_dict(), seed=9))
+    opt = torch.optim.SGD(m.parameters(), lr=0.5, momentum=0.9, fused=fused)
+    x = (synth.t_normal(91, (4, C, 8, 8), stream=1) * 2 + 1).to(dev).contiguous(memory_format=torch.channels_last)
+
+    def eval_out():
+        m.eval()
+        with torch.no_grad():
+            y = m(x.clone())
+        ref = _ref(x.cpu(), m.weight.detach().cpu(), m.bias.detach().cpu(), m.running_mean.cpu(), m.running_var.cpu(), False,
+                   "leaky_relu", 0.01, abs_gamma=True)
+        torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
+        return y
+
+    y0 = eval_out()
+    for _ in range(2):
+        m.train()
+        opt.zero_grad()
+        m(x.clone().requires_grad_(True) * 1.0).square().mean().backward()
+        opt.step()
+        y1 = eval_out()
+        assert (y1 - y0).abs().max() > 1e-3          # the parameters and running statistics did move
+        y0 = y1
+    # a frozen layer (the teacher) keeps its cached constants across optimiser steps of OTHER parameters
+    t = abn.InPlaceABNSync(C).to(dev).eval()
+    for p in t.parameters():
+        p.requires_grad = False
+    with torch.no_grad():
+        t(x.clone())
+    c0 = t._eval_constants()
+    opt.step()
+    assert t._eval_constants() is c0
+
+
+@pytest.mark.parametrize("zero_where", ["before", "after"])
+def test_wrapper_under_the_references_plain_loop(zero_where):
+    """``optim.zero_grad(); loss.backward(); optim.step()`` (train.py:104,137-138,149) on the wrapped model with NO
+    reducer-specific call: the parameters follow the unwrapped model's trajectory, the kernel-written ABN gradients and the
+    bucket views survive ``set_to_none``."""
+    from ucd_amd import abn
+    from ucd_amd.ddp import DistributedDataParallel
+    dev = torch.device("cuda:0")
+
+    def net():
+        torch.manual_seed(0)
+        m = torch.nn.Sequential(torch.nn.Conv2d(8, 64, 3, padding=1, bias=False), abn.InPlaceABN(64),
+                                torch.nn.Conv2d(64, 32, 1, bias=False), abn.InPlaceABN(32, activation="identity")).to(dev)
+        return m.to(memory_format=torch.channels_last).train()
+
+    x = synth.t_normal(31, (4, 8, 12, 10), stream=1).to(dev).contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(32, (4, 32, 12, 10), stream=1).to(dev).contiguous(memory_format=torch.channels_last)
+    plain, wrapped = net(), DistributedDataParallel(net())
+    opts = [torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9, nesterov=True) for m in (plain, wrapped)]
+    for step in range(3):
+        for m, opt in zip((plain, wrapped), opts):
+            if zero_where == "before":
+                opt.zero_grad()
+                y = m(x)
+            else:
+                y = m(x)
+                opt.zero_grad()
+            (y * dy).sum().backward()
+            opt.step()
+        for (n, p), (_, q) in zip(plain.named_parameters(), wrapped.module.named_parameters()):
+            tol = dict(rtol=1e-5, atol=1e-6) if q.dim() == 1 else dict(rtol=1e-3, atol=1e-4)
+            torch.testing.assert_close(q, p, msg=f"{n} step {step}", **tol)
+    if zero_where == "before":        # the fast path stayed on: gradients live in the reducer's flat buffers
+        assert wrapped.module[1]._direct_grad_ptr() != 0
+        assert wrapped.module[0].weight.grad.data_ptr() == wrapped.reducer._bucket_of[wrapped.module[0].weight].flat.data_ptr() \
+            or wrapped.module[0].weight.grad.untyped_storage().data_ptr() == wrapped.reducer._bucket_of[wrapped.module[0].weight].flat.untyped_storage().data_ptr()

@@ -134,6 +134,67 @@ def test_bucketed_gradient_averaging_gloo_world2(tmp_path):
     assert r.stdout.count("DDP_OK") == 2
 
 
+_DDP_PLAIN_WORKER = r"""
+import sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from ucd_amd.ddp import DistributedDataParallel
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(1234 + rank)
+net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+ref = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+ddp = DistributedDataParallel(net, delay_allreduce=True, bucket_mb=0.0002)
+ref.load_state_dict(net.state_dict())
+optim = torch.optim.SGD(ddp.parameters(), lr=0.1, momentum=0.9, nesterov=True)
+ropt = torch.optim.SGD(ref.parameters(), lr=0.1, momentum=0.9, nesterov=True)
+torch.manual_seed(7)
+X = torch.randn(8, 8); Y = torch.randn(8, 4)
+xs, ys = X[rank::world], Y[rank::world]
+mode = sys.argv[2]
+for step in range(3):
+    # the reference's loop, verbatim in structure (train.py:104,108,137-138,149): NO reducer-specific call
+    if mode == "before":
+        optim.zero_grad()                          # set_to_none=True: drops the bucket views
+        loss = ((ddp(xs) - ys) ** 2).mean()
+    else:
+        loss = ((ddp(xs) - ys) ** 2).mean()
+        optim.zero_grad()                          # after the forward: the views come back at bucket completion
+    loss.backward()
+    ropt.zero_grad()
+    (sum(((ref(X[r::world]) - Y[r::world]) ** 2).mean() for r in range(world)) / world).backward()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert p.grad is not None and torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6), (step, (p.grad - q.grad).abs().max())
+    optim.step(); ropt.step()
+    for p, q in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+# gradient accumulation is refused, not silently mis-reduced
+loss = ((ddp(xs) - ys) ** 2).mean()
+loss.backward(retain_graph=True)
+try:
+    loss.backward()
+    raise SystemExit("second backward did not raise")
+except RuntimeError as e:
+    assert "accumulation" in str(e)
+print("DDP_PLAIN_OK", rank)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("mode,port", [("before", "29621"), ("after", "29623")])
+def test_ddp_wrapper_averages_with_the_references_plain_loop_gloo_world2(tmp_path, mode, port):
+    """apex.parallel.DistributedDataParallel call shape (run.py:204) under the reference's unchanged loop
+    ``optim.zero_grad(); loss.backward(); optim.step()``: the gradients are averaged by the end-of-backward callback, the
+    parameters of both ranks follow the single-process mean-loss trajectory."""
+    script = tmp_path / "ddp_plain_worker.py"
+    script.write_text(_DDP_PLAIN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), ROOT, mode],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("DDP_PLAIN_OK") == 2
+
+
 _SYNCBN_WORKER = r"""
 import sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])

@@ -248,3 +248,64 @@ def test_full_size_invariants_b24_513():
     assert abs(l16s - l32s) / abs(l32s) < 1e-3 and abs(l16u - l32u) / abs(l32u) < 1e-3
     assert ((g16s - g32s).norm() / g32s.norm()).item() < 2e-3
     assert ((g16u - g16s).norm() / g16s.norm()).item() < 2e-3
+
+
+@pytest.mark.parametrize("name", PIXCON)
+def test_pixelconlossv2_plain_tensor_call(name):
+    """The reference's literal call shape (train.py:115-116): ``a, c, la, lc, P = pre_contractive_pixel(...)`` then
+    ``PixelConLossV2()(a, c, la, lc, P)`` with five plain tensors - (i) the unpacked tensors of this package's own prep
+    (found through the anchors tensor: fused kernel), (ii) foreign tensors holding the same values (``ucd_pixcon_loss_given_p``
+    reads the materialised P), (iii) foreign tensors built by the ORACLE's prep, with and without P."""
+    from ucd_amd.contrastive import PixelConLossV2, pre_contractive_pixel
+    g = load_golden(f"pixcon_{name}.npz")
+    f_n, f_o, l_po, labels = _case(g)
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    crit = PixelConLossV2(temperature=0.07)
+    # (i)
+    x = fn_d.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    a, c, la, lc, P = pre_contractive_pixel(x, lab_d, l_po=lpo_d, f_o=fo_d)
+    loss = crit(a, c, la, lc, P)
+    assert abs(loss.item() - float(g["loss"])) / abs(float(g["loss"])) < 1e-4
+    loss.backward()
+    assert_matches_compact(g, "grad_f_n", x.grad.cpu().numpy(), rtol=1e-3, atol=1e-7)
+    a2, c2, la2, lc2, _ = pre_contractive_pixel(x.detach(), lab_d, l_po=lpo_d, f_o=fo_d)
+    assert crit(a2, c2, la2, lc2).item() == pytest.approx(float(g["loss_noP"]), rel=1e-4)
+    # (ii) same values, different tensor objects: nothing to look up
+    af = a.detach().clone().requires_grad_(True)
+    lf = crit(af, c.clone(), la.clone(), lc.clone(), P.clone())
+    assert abs(lf.item() - float(g["loss"])) / abs(float(g["loss"])) < 1e-4
+    lf.backward()
+    # (iii) the oracle's tuple moved to the device
+    ref_in = f_n.clone().requires_grad_(True)
+    prep = OC.pre_contrastive_pixel(ref_in, labels, l_po, f_o)
+    ao = prep["a"].detach().clone().requires_grad_(True)
+    ref = OC.pixcon_loss(ao, prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    ref.backward()
+    ad = prep["a"].detach().to(fn_d.device).requires_grad_(True)
+    args = [prep["c"].to(fn_d.device), prep["la"].to(fn_d.device), prep["lc"].to(fn_d.device)]
+    lo = crit(ad, *args, prep["P"].to(fn_d.device))
+    lo.backward()
+    assert abs(lo.item() - ref.item()) / abs(ref.item()) < 1e-4
+    err = (ad.grad.cpu() - ao.grad).abs().max().item() / ao.grad.abs().max().item()
+    assert err < 1e-3, err
+    err2 = (af.grad.cpu() - ao.grad).abs().max().item() / ao.grad.abs().max().item()
+    assert err2 < 1e-3, err2
+    ref_nop = OC.pixcon_loss(prep["a"].detach(), prep["c"], prep["la"], prep["lc"], None, 0.07)
+    assert crit(ad.detach(), *args).item() == pytest.approx(ref_nop.item(), rel=1e-4)
+
+
+def test_v1_pixelconloss_on_the_hip_path():
+    """the dead-file PixelConLoss (utils/loss_new.py:359-400) is the V2 kernel's special case contrast = anchors,
+    P = 1, no row-max shift - run that way through the C ABI and compared with the goldens captured from the reference."""
+    import torch.nn.functional as F
+    from ucd_amd.contrastive import PixelConLoss
+    g = load_golden("v1_losses.npz")
+    seed, n, d = [int(v) for v in g["cfg"]]
+    f = F.normalize(synth.t_normal(seed, (n, d), stream=1), dim=1)
+    lab = torch.from_numpy(synth.randint(seed, (n,), 0, 5, stream=2))
+    dev = torch.device("cuda:0")
+    fd, ld = f[:, None, :].to(dev), lab.to(dev)
+    assert PixelConLoss(temperature=0.07)(fd, ld).item() == pytest.approx(float(g["pixcon_T007"]), rel=1e-4)
+    assert PixelConLoss()(fd, ld).item() == pytest.approx(float(g["pixcon_T1"]), rel=1e-4)
+    with pytest.raises(NotImplementedError):
+        PixelConLoss()(fd.clone().requires_grad_(True), ld).backward()

@@ -19,10 +19,12 @@ MI355X design notes
     when that is unavailable; without an initialised process group it is InPlaceABN;
   * the student's training-mode layers run through a C++ autograd node (``csrc/abn_node.cpp``) when it is built; the
     Python ``_ABNFunction`` below is the complete implementation and the fallback.
-Semantics follow ``F.batch_norm`` + ``leaky_relu`` (biased batch variance, unbiased running variance,
-eps 1e-5, momentum 0.1); inplace_abn's ``abs(gamma) + eps`` re-parameterisation is not reproduced
-(its source is not in the reference tree; the two coincide for the positive gammas of the pretrained
-files - SURVEY.md section 8-a5).
+Semantics: biased batch variance, unbiased running variance, eps 1e-5, momentum 0.1, then ``leaky_relu`` / ``elu`` /
+identity.  ``ABN`` is ``F.batch_norm`` (raw gamma), as in the wheel.  ``InPlaceABN`` / ``InPlaceABNSync`` normalise with
+``gamma~ = |gamma| + eps`` like the wheel's in-place kernels (inplace-abn 1.0.x, the published forward ``(x - mean) *
+rsqrt(var + eps) * (abs(weight) + eps) + bias`` and backward ``d weight = sign(weight) * sum dz*xhat``; the wheel's
+source is not in the reference tree, so this restates its published algorithm - SURVEY.md section 8-a5): a reference
+checkpoint with negative gammas therefore gives the same activations here as there.
 """
 from __future__ import annotations
 
@@ -31,6 +33,7 @@ import os
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 from . import hip
 from .comm import direct_comm
@@ -40,7 +43,19 @@ def _act_code(name):
     try:
         return hip.ACT_CODES[name]
     except KeyError:
-        raise RuntimeError(f"activation {name!r} is not supported by the HIP ABN (leaky_relu, identity)") from None
+        raise RuntimeError(f"activation {name!r} is not supported by the HIP ABN (leaky_relu, elu, identity)") from None
+
+
+# Bumped after every optimiser step (fused optimisers update parameters without touching their version counters):
+# part of the key of the cached evaluation-mode constants of layers whose affine parameters are trainable.
+_param_epoch = [0]
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    _param_epoch[0] += 1
+
+
+register_optimizer_step_post_hook(_after_optimizer_step)
 
 
 _FORCE_SYNC = os.environ.get("UCD_ABN_FORCE_SYNC") == "1"   # profiling aid: take the multi-rank code path at world 1
@@ -129,7 +144,7 @@ class _ABNFunction(torch.autograd.Function):
             buf = torch.cat((torch.empty(4 * Cc, dtype=torch.float32, device=dev), eval_cache.reshape(-1))) \
                 if ctx.needs_input_grad[0] else eval_cache
         mean = running_mean if not training else None
-        needs_y = residual is not None and act != hip.ACT_IDENTITY
+        needs_y = residual is not None and (act & hip.ACT_MASK) != hip.ACT_IDENTITY
         ctx.save_for_backward(x, y if needs_y else None, plane_bias, weight, bias, buf, mean)
         ctx.cfg = (M, Cc, HW, ld_x, ld_y, training, act, slope, group, count, sync, residual is not None,
                    plane_bias is not None, x.shape[0])
@@ -166,7 +181,7 @@ class _ABNFunction(torch.autograd.Function):
         else:
             local, sums = sums[2 * Cc:], sums[:2 * Cc]           # this rank's sums = its d bias / d weight
             hip.abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_yy, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act,
-                                    slope, sums, local)
+                                    slope, sums, local, weight)
             dbias = dweight = None
             if need_param_grad:
                 dbias, dweight = local[:Cc], local[Cc:]
@@ -214,11 +229,11 @@ class _ABNBranchesFunction(torch.autograd.Function):
             if training:
                 hip.abn_stats(x, ld, M, c, None, HW, sums, kshift)
                 hip.abn_finalize(sums, kshift, count, c, w, running_mean[sl], running_var[sl], momentum, eps, mean[sl],
-                                 invstd[sl], scale[sl])
+                                 invstd[sl], scale[sl], act)
                 mu = mean[sl]
             else:
                 mu = running_mean[sl]
-                hip.abn_eval_params(w, running_var[sl], eps, c, invstd[sl], scale[sl])
+                hip.abn_eval_params(w, running_var[sl], eps, c, invstd[sl], scale[sl], act)
             hip.abn_apply(x, ld, out[:, sl], Ct, None, 0, M, c, None, HW, mu, scale[sl], b, act, slope)
         if not training:
             mean.copy_(running_mean)
@@ -271,7 +286,7 @@ class _ABNBranchesFunction(torch.autograd.Function):
             for x, c, o, ld in zip(xs, chans, offs, lds):
                 sl = slice(o, o + c)
                 hip.abn_bwd_reduce(x, ld, dy[:, sl], ld_dy, None, 0, M, c, None, HW, mean[sl], invstd[sl], scale[sl],
-                                   shift[sl], act, slope, sums[2 * o:2 * (o + c)])
+                                   shift[sl], act, slope, sums[2 * o:2 * (o + c)], weight[sl] if weight is not None else None)
         dweight = dbias = None
         if training and weight is not None and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
             dbias = torch.cat([sums[2 * o:2 * o + c] for c, o in zip(chans, offs)])
@@ -317,6 +332,7 @@ class ABN(nn.Module):
     ucd_fused_abn = True
     _inplace_contract = False
     _sync = False
+    _abs_gamma = False          # F.batch_norm's raw gamma (inplace_abn.ABN); the in-place variants use |gamma| + eps
 
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, activation="leaky_relu",
                  activation_param=0.01, group=None):
@@ -346,8 +362,10 @@ class ABN(nn.Module):
     def forward(self, x, residual=None, activation=None, activation_param=None, plane_bias=None, out=None):
         if not x.is_cuda:
             raise RuntimeError("ucd_amd.abn runs on the GPU only (there is no CPU fallback)")
-        act = _act_code(self.activation if activation is None else activation)
+        act = _act_code(self.activation if activation is None else activation) | (hip.NORM_ABS_GAMMA if self._abs_gamma else 0)
         slope = self.activation_param if activation_param is None else activation_param
+        if self.training:
+            self.__dict__.pop("_eval_cache", None)     # the running statistics are about to change
         inplace = self._inplace_contract and not torch.is_grad_enabled() and out is None
         if not torch.is_grad_enabled() and not self.training and residual is None and plane_bias is None and out is None:
             return self._forward_eval_nograd(x, act, slope, inplace)
@@ -393,13 +411,18 @@ class ABN(nn.Module):
     def _eval_constants(self):
         """invstd / scale of the running statistics, cached until a parameter or buffer changes (the frozen
         teacher never recomputes them)."""
+        # what can change the constants: in-place writes seen by the version counters (load_state_dict, copy_), a
+        # training-mode forward of this layer (it drops the cache: the kernels update running_var through raw pointers),
+        # and an optimiser step on a trainable gamma (fused optimisers do not bump versions: _param_epoch does)
+        w = self.weight
         key = (self.running_var._version, self.running_var.data_ptr(), self.eps,
-               None if self.weight is None else (self.weight._version, self.weight.data_ptr()))
+               None if w is None else (w._version, w.data_ptr(), _param_epoch[0] if w.requires_grad else -1))
         cache = self.__dict__.get("_eval_cache")
         if cache is None or cache[0] != key:
             Cc = self.num_features
             c = torch.empty(2, Cc, dtype=torch.float32, device=self.running_var.device)
-            hip.abn_eval_params(self.weight, self.running_var, self.eps, Cc, c[0], c[1])
+            hip.abn_eval_params(self.weight, self.running_var, self.eps, Cc, c[0], c[1],
+                                hip.NORM_ABS_GAMMA if self._abs_gamma else 0)
             cache = (key, c)
             self.__dict__["_eval_cache"] = cache
         return cache[1]
@@ -407,8 +430,9 @@ class ABN(nn.Module):
     def forward_branches(self, xs):
         """``self(torch.cat(xs, 1))`` without the concatenation."""
         return _ABNBranchesFunction.apply(self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                          self.momentum, self.eps, _act_code(self.activation), self.activation_param,
-                                          self._group(), *xs)
+                                          self.momentum, self.eps,
+                                          _act_code(self.activation) | (hip.NORM_ABS_GAMMA if self._abs_gamma else 0),
+                                          self.activation_param, self._group(), *xs)
 
     def extra_repr(self):
         s = "{num_features}, eps={eps}, momentum={momentum}, affine={affine}, activation={activation}"
@@ -418,8 +442,10 @@ class ABN(nn.Module):
 
 
 class InPlaceABN(ABN):
-    """Same arithmetic; under ``no_grad`` the input tensor is overwritten (inplace_abn's contract)."""
+    """``gamma~ = |gamma| + eps`` like inplace_abn's in-place kernels; under ``no_grad`` the input tensor is overwritten
+    (inplace_abn's contract)."""
     _inplace_contract = True
+    _abs_gamma = True
 
 
 class InPlaceABNSync(InPlaceABN):

@@ -16,6 +16,7 @@ allocates worst-case buffers (A <= BHW, C <= 2 BHW) - there is no ``.cpu()`` rou
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -191,6 +192,32 @@ class PixconTuple(tuple):
     batch = None
 
 
+# anchors tensor -> (weak reference to it, prepared batch, the P it was returned with): lets
+# ``PixelConLossV2()(a, c, la, lc, P)`` - the reference's literal call, train.py:115-116 unpacks the tuple first - find the
+# device batch behind plain tensors.  Entries die with their anchors tensor.
+_batches_by_anchor = {}
+
+
+def _remember(a, pb, P):
+    key = id(a)
+
+    def _drop(_ref, key=key):
+        _batches_by_anchor.pop(key, None)
+    _batches_by_anchor[key] = (weakref.ref(a, _drop), pb, None if P is None else weakref.ref(P))
+
+
+def _recall(a, P):
+    """(prepared batch, use_prob) when ``a`` (and ``P``, if given) are the very tensors pre_contractive_pixel returned."""
+    ent = _batches_by_anchor.get(id(a))
+    if ent is None or ent[0]() is not a:
+        return None
+    if P is None:
+        return ent[1], False
+    if ent[2] is not None and ent[2]() is P:
+        return ent[1], True
+    return None
+
+
 def pre_contractive_pixel(f_n, l_n, l_po=None, f_o=None, max_label=20, materialize_P=True):
     """Reference signature and return order (utils/utils.py:256,393): anchors ``a`` [A, N] (grad flows to
     ``f_n``), contrast ``c`` [C, N], labels ``la`` [A] / ``lc`` [C] (int8 like the reference) and the
@@ -217,6 +244,7 @@ def pre_contractive_pixel(f_n, l_n, l_po=None, f_o=None, max_label=20, materiali
         P = torch.where(gt_a[:, None] & gt_c[None, :], torch.ones_like(P), P)
     out = PixconTuple((a, c, la, lc, P))
     out.batch = pb
+    _remember(a, pb, P)
     return out
 
 
@@ -232,10 +260,86 @@ class _LossOnBatch(torch.autograd.Function):
         return ctx.grad_a[:ctx.A, :ctx.N] * g, None, None, None, None
 
 
+def _meta_from_labels(A, Co, la, lc):
+    """Device-built ``ucd_pixcon_meta`` for plain tensors: the sizes are host-known shapes, the label histograms and the
+    number of anchors with a positive are computed on the device (no synchronisation)."""
+    dev = la.device
+    tile = hip.PIX_TILE
+    Apad = (A + tile - 1) // tile * tile
+    Cpad = (Apad + Co + tile - 1) // tile * tile
+    la64, lc64 = la.long(), lc.long()
+    count_a = torch.bincount(la64, minlength=256)[:256]
+    count_c = torch.bincount(lc64, minlength=256)[:256]
+    n_valid = (count_c[la64] > 1).sum().reshape(1)
+    head = torch.tensor([A, Co, 256, 0, Apad, Cpad], dtype=torch.int64, device=dev)
+    z = torch.zeros
+    meta = torch.cat((head, n_valid, z(1 + 257 + 257, dtype=torch.int64, device=dev), count_a, count_c,
+                      z(2, dtype=torch.int64, device=dev))).to(torch.int32)
+    assert meta.numel() * 4 == hip.META_BYTES
+    return meta, Apad, Cpad
+
+
+class _LossOnTensors(torch.autograd.Function):
+    """PixelConLossV2 on plain ``(a, c, la, lc, P)`` tensors through ``ucd_pixcon_loss_given_p`` (exact-fp32 MFMA sweeps;
+    the [A, C] score matrices of utils/loss.py:435-462 are still never built, only the caller's P is read)."""
+
+    @staticmethod
+    def forward(ctx, a, c, la, lc, P, temperature, shift_pos, one_sided):
+        lib = hip.load()
+        A, N = a.shape
+        Ct = c.shape[0]
+        if a.dim() != 2 or c.dim() != 2 or c.shape[1] != N or Ct < A or la.numel() != A or lc.numel() != Ct:
+            raise RuntimeError("PixelConLossV2: expected a [A, N], c [C >= A, N] (c[:A] = the anchors), la [A], lc [C]")
+        if N > hip.PIXCON_LD:
+            raise RuntimeError(f"feature dimension {N} > {hip.PIXCON_LD} is not supported")
+        if P is not None and tuple(P.shape) != (A, Ct):
+            raise RuntimeError(f"PixelConLossV2: P must be [A, C] = [{A}, {Ct}], got {tuple(P.shape)}")
+        dev = a.device
+        Co = Ct - A
+        meta, Apad, Cpad = _meta_from_labels(A, Co, la.reshape(-1), lc.reshape(-1))
+        chat = torch.zeros(Cpad, hip.PIXCON_LD, dtype=torch.float32, device=dev)
+        chat[:A, :N] = a.detach()
+        chat[Apad:Apad + Co, :N] = c.detach()[A:]
+        row_label = torch.full((Cpad,), 255, dtype=torch.uint8, device=dev)
+        row_label[:A] = la.reshape(-1).to(torch.uint8)
+        row_label[Apad:Apad + Co] = lc.reshape(-1)[A:].to(torch.uint8)
+        if P is not None:
+            P = P.detach().float()
+            if P.stride(1) != 1:
+                P = P.contiguous()
+        maxA = max(A, 1)
+        loss_out = torch.empty(2, dtype=torch.float32, device=dev)
+        grad_a = torch.empty(maxA, hip.PIXCON_LD, dtype=torch.float32, device=dev)
+        nbytes = lib.ucd_pixcon_loss_workspace_bytes(maxA, N, 0)
+        ws = hip.workspace(nbytes, dev, "pixloss")
+        hip._check(lib.ucd_pixcon_loss_given_p(hip.ptr(chat), hip.PIXCON_LD, N, hip.ptr(row_label), hip.ptr(P),
+                                               P.stride(0) if P is not None else 0, hip.ptr(meta), maxA, float(temperature),
+                                               int(bool(shift_pos)), hip.ptr(loss_out), hip.ptr(grad_a), hip.PIXCON_LD, None,
+                                               hip.ptr(ws),
+                                               nbytes, hip.stream()), "ucd_pixcon_loss_given_p")
+        ctx.grad_a, ctx.A, ctx.N, ctx.dtype, ctx.one_sided = grad_a, A, N, a.dtype, one_sided
+        return loss_out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.one_sided:
+            raise NotImplementedError("PixelConLoss (utils/loss_new.py:359-400, never imported by the reference) differentiates "
+                                      "through both sides of f f^T; the HIP sweeps produce the anchor-side gradient only "
+                                      "(the wired PixelConLossV2 detaches the contrast side)")
+        return (ctx.grad_a[:ctx.A, :ctx.N] * g).to(ctx.dtype), None, None, None, None, None, None, None
+
+
 class PixelConLossV2(nn.Module):
-    """``forward(anchor_features, contrast_feature, anchor_labels, contrast_labels, P=None)`` like the
-    reference (utils/loss.py:412).  The tensors must come from :func:`pre_contractive_pixel` of this
-    package (they carry the prepared device batch); the loss runs the fused MFMA kernel on it."""
+    """``forward(anchor_features, contrast_feature, anchor_labels, contrast_labels, P=None)`` like the reference
+    (utils/loss.py:412).  Three ways in, all on the HIP kernels:
+
+    * the tuple returned by this package's :func:`pre_contractive_pixel` (or ``batch=tuple.batch``): the fused kernel on
+      the prepared device batch, P formed in-tile from the teacher probabilities;
+    * the five tensors of that tuple unpacked, as the reference's trainer passes them (train.py:115-116): the batch is
+      found through the anchors tensor - same kernel;
+    * any other plain tensors: ``ucd_pixcon_loss_given_p`` reads the given ``P`` ([A, C]); ``contrast_feature[:A]`` must be
+      the anchors (the reference's construction, utils/utils.py:362).  Gradient flows to ``anchor_features`` only, as in the
+      reference (``contrast_feature`` and ``P`` arrive detached)."""
 
     def __init__(self, sample_method="none", temperature=0.07):
         super().__init__()
@@ -246,7 +350,37 @@ class PixelConLossV2(nn.Module):
         if isinstance(anchor_features, PixconTuple):
             tup = anchor_features
             anchor_features, batch, P = tup[0], tup.batch, tup[4]
+        if not anchor_features.is_cuda:
+            raise RuntimeError("ucd_amd.contrastive runs on the GPU only (there is no CPU fallback)")
+        use_prob = P is not None
         if batch is None:
-            raise RuntimeError("PixelConLossV2 needs the PixconTuple returned by ucd_amd.contrastive."
-                               "pre_contractive_pixel (pass the tuple itself, or batch=tuple.batch)")
-        return _LossOnBatch.apply(anchor_features, batch, float(self.temperature), P is not None, True)
+            hit = _recall(anchor_features, P)
+            if hit is not None:
+                batch, use_prob = hit
+        if batch is not None:
+            return _LossOnBatch.apply(anchor_features, batch, float(self.temperature), use_prob, True)
+        if contrast_feature is None or anchor_labels is None or contrast_labels is None:
+            raise RuntimeError("PixelConLossV2: pass (anchor_features, contrast_feature, anchor_labels, contrast_labels[, P])")
+        return _LossOnTensors.apply(anchor_features, contrast_feature, anchor_labels, contrast_labels, P,
+                                    float(self.temperature), True, True)
+
+
+class PixelConLoss(nn.Module):
+    """The older single-set loss of the reference's dead file (utils/loss_new.py:352-400; nothing imports it):
+    ``forward(features [n, 1, d], labels [n])`` = the V2 form with contrast == anchors, ``P = 1`` and no row-max shift,
+    which is how it runs here (``ucd_pixcon_loss_given_p(shift_pos = 0, P = NULL)``).  Forward value only: the reference
+    differentiates through both factors of ``f f^T``, the kernels through the anchor side (backward raises).
+    ``SupConLoss`` of the same file (loss_new.py:264-350) has no HIP path: it is pinned in ``oracle/`` only."""
+
+    def __init__(self, temperature=1.0):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, features, labels):
+        f = torch.cat(torch.unbind(features.reshape(features.shape[0], features.shape[1], -1), dim=1), dim=0)
+        if not f.is_cuda:
+            raise RuntimeError("ucd_amd.contrastive runs on the GPU only (there is no CPU fallback)")
+        if features.shape[1] != 1:
+            raise NotImplementedError("one view per pixel ([n, 1, d]), as loss_new.py:359-400 is written for")
+        lab = labels.reshape(-1)
+        return _LossOnTensors.apply(f, f, lab, lab, None, float(self.temperature), False, False)

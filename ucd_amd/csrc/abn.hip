@@ -167,6 +167,7 @@ struct FinalizeArgs {
   float* scale;
   float count, momentum, eps;
   float* pack;   // PACK mode: [mean_r | M2_r] of this rank for the cross-rank combination
+  int abs_gamma; // scale = (|weight| + eps) * invstd (InPlaceABN / InPlaceABNSync) instead of weight * invstd
 };
 
 __device__ __forceinline__ void finalize_moments(int c, float mean, float m2, const FinalizeArgs& f) {
@@ -179,7 +180,7 @@ __device__ __forceinline__ void finalize_moments(int c, float mean, float m2, co
   }
   f.mean[c] = mean;
   f.invstd[c] = invstd;
-  f.scale[c] = (f.weight ? f.weight[c] : 1.f) * invstd;
+  f.scale[c] = (f.weight ? gamma_eff(f.weight[c], f.eps, f.abs_gamma) : 1.f) * invstd;
 }
 
 __device__ __forceinline__ void finalize_channel(int c, float s, float ss, const FinalizeArgs& f) {
@@ -195,14 +196,15 @@ __device__ __forceinline__ void finalize_channel(int c, float s, float ss, const
   }
   f.mean[c] = mean;
   f.invstd[c] = invstd;
-  f.scale[c] = (f.weight ? f.weight[c] : 1.f) * invstd;
+  f.scale[c] = (f.weight ? gamma_eff(f.weight[c], f.eps, f.abs_gamma) : 1.f) * invstd;
 }
 
 // MODE 0: sums only (and an optional second copy), 1: + finalize, 2: + pack [mean_r | M2_r] for the SyncBN gather
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int C,
                                                               float* __restrict__ sums, FinalizeArgs fin,
-                                                              float* __restrict__ sums2 = nullptr) {
+                                                              float* __restrict__ sums2 = nullptr,
+                                                              const float* __restrict__ sign_of = nullptr) {
   __shared__ float lds[16][17];
   const int kl = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int c = blockIdx.x * 8 + (kl & 7);
@@ -225,6 +227,8 @@ __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __res
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) t += lds[i][kl];
+    // abs-gamma layers: the second row holds d weight = sign(weight) * sum dz*xhat (bwd_apply undoes the sign)
+    if (sign_of && kl >= 8 && sign_of[c] < 0.f) t = -t;
     sums[k] = t;
     if (sums2) sums2[k] = t;
     lds[0][kl] = t;
@@ -269,12 +273,12 @@ __global__ void abn_finalize_kernel(const float* __restrict__ sums, int C, Final
 }
 
 __global__ void abn_eval_params_kernel(const float* __restrict__ weight, const float* __restrict__ rv, float eps, int C,
-                                       float* __restrict__ invstd, float* __restrict__ scale) {
+                                       float* __restrict__ invstd, float* __restrict__ scale, int abs_gamma) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float is = 1.f / sqrtf(rv[c] + eps);
   invstd[c] = is;
-  scale[c] = (weight ? weight[c] : 1.f) * is;
+  scale[c] = (weight ? gamma_eff(weight[c], eps, abs_gamma) : 1.f) * is;
 }
 
 // ---- forward apply ------------------------------------------------------------------------------
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
         float f = v.get(i);
         if (pb) f += pb[i];
         float sgn = yout ? yo.get(i) : (f - mu[i]) * sc[i] + sh[i];
-        float dz = g.get(i) * act_grad<ACT>(sgn, slope);
+        float dz = g.get(i) * act_grad<ACT>(sgn, slope, yout != nullptr);
         float xh = (f - mu[i]) * is[i];
         acc[i] += dz;
         acc[VEC + i] += dz * xh;
@@ -428,7 +432,8 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
     T* dx, int ld_dx, T* dz_out, int ld_dz, int M, int C,
     const float* __restrict__ plane_bias, int HW, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ weight,
-    const float* __restrict__ sums, float inv_count, int frozen, float slope, int TX, int TY, int rows_per_band) {
+    const float* __restrict__ sums, float inv_count, int frozen, int abs_gamma, float slope, int TX, int TY,
+    int rows_per_band) {
   constexpr int VEC = Vec<T>::N;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cg = blockIdx.x * TX + tx;
@@ -447,7 +452,12 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
       is[i] = invstd[c];
       k0[i] = sums[c] * inv_count;       // mean(dz)
       k1[i] = sums[C + c] * inv_count;   // mean(dz * xhat)
-      gw[i] = (weight ? weight[c] : 1.f) * is[i];
+      if (abs_gamma) {                   // sums[C + c] is d weight = sign(weight) * sum dz*xhat; scale = (|w| + eps) * invstd
+        if (weight && weight[c] < 0.f) k1[i] = -k1[i];
+        gw[i] = sc[i];
+      } else {
+        gw[i] = (weight ? weight[c] : 1.f) * is[i];
+      }
     }
   }
   const int r_begin = blockIdx.y * rows_per_band;
@@ -461,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
       float f = v.get(i);
       if (pb) f += pb[i];
       float sgn = yout ? yo.get(i) : (f - mu[i]) * sc[i] + sh[i];
-      float dz = g.get(i) * act_grad<ACT>(sgn, slope);
+      float dz = g.get(i) * act_grad<ACT>(sgn, slope, yout != nullptr);
       float xh = (f - mu[i]) * is[i];
       o.set(i, (dz - k0[i] - xh * k1[i]) * gw[i]);
       oz.set(i, dz);
@@ -601,7 +611,8 @@ int check_common(const char* fn, int dtype, int M, int C, int act) {
   UCD_REQUIRE(M > 0 && C > 0, UCD_EINVAL, "%s: empty tensor (M=%d, C=%d)", fn, M, C);
   const int vec = dtype == UCD_BF16 ? 8 : 4;
   UCD_REQUIRE(C % vec == 0, UCD_EALIGN, "%s: C=%d is not a multiple of %d", fn, C, vec);
-  UCD_REQUIRE(act == UCD_ACT_IDENTITY || act == UCD_ACT_LEAKY_RELU, UCD_EINVAL, "%s: unknown activation %d", fn, act);
+  UCD_REQUIRE((act & ~(UCD_ACT_MASK | UCD_NORM_ABS_GAMMA)) == 0 && (act & UCD_ACT_MASK) <= UCD_ACT_ELU, UCD_EINVAL,
+              "%s: unknown activation / flags 0x%x", fn, act);
   return 0;
 }
 
@@ -662,28 +673,31 @@ int ucd_abn_stats(const void* x, int ld_x, int dtype, int M, int C, const float*
 
 int ucd_abn_stats_finalize(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW,
                            float* sums, float* kshift, const float* weight, float* running_mean, float* running_var,
-                           float momentum, float eps, float* mean, float* invstd, float* scale, void* workspace,
-                           size_t workspace_bytes, ucd_stream_t stream) {
+                           float momentum, float eps, float* mean, float* invstd, float* scale, int flags,
+                           void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   UCD_REQUIRE(mean && invstd && scale && kshift, UCD_EINVAL, "ucd_abn_stats_finalize: NULL output");
-  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, (float)M, momentum, eps, nullptr};
+  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, (float)M, momentum, eps, nullptr,
+                   (flags & UCD_NORM_ABS_GAMMA) != 0};
   return abn_stats_impl(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, workspace, workspace_bytes, stream, &fin);
 }
 
 int ucd_abn_finalize(const float* sums, const float* kshift, float count, int C, const float* weight,
                      float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                     float* scale, ucd_stream_t stream) {
+                     float* scale, int flags, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_finalize";
   UCD_REQUIRE(sums && mean && invstd && scale && C > 0 && count > 0.f, UCD_EINVAL, "%s: bad arguments", fn);
-  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, count, momentum, eps, nullptr};
+  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, count, momentum, eps, nullptr,
+                   (flags & UCD_NORM_ABS_GAMMA) != 0};
   abn_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(sums, C, fin);
   return check_launch(fn);
 }
 
 int ucd_abn_eval_params(const float* weight, const float* running_var, float eps, int C, float* invstd, float* scale,
-                        ucd_stream_t stream) {
+                        int flags, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_eval_params";
   UCD_REQUIRE(running_var && invstd && scale && C > 0, UCD_EINVAL, "%s: bad arguments", fn);
-  abn_eval_params_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(weight, running_var, eps, C, invstd, scale);
+  abn_eval_params_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(weight, running_var, eps, C, invstd, scale,
+                                                                            (flags & UCD_NORM_ABS_GAMMA) != 0);
   return check_launch(fn);
 }
 
@@ -706,11 +720,14 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
                                                                  HW, mean, scale, shift, slope, g.TX, g.TY,    \
                                                                  g.rows_per_band);                             \
   }
+  const int a = act & UCD_ACT_MASK;
   if (dtype == UCD_BF16) {
-    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    if (a == UCD_ACT_LEAKY_RELU) LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    else if (a == UCD_ACT_ELU) LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_ELU)
     else LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_IDENTITY)
   } else {
-    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_APPLY(float, 4, UCD_ACT_LEAKY_RELU)
+    if (a == UCD_ACT_LEAKY_RELU) LAUNCH_APPLY(float, 4, UCD_ACT_LEAKY_RELU)
+    else if (a == UCD_ACT_ELU) LAUNCH_APPLY(float, 4, UCD_ACT_ELU)
     else LAUNCH_APPLY(float, 4, UCD_ACT_IDENTITY)
   }
 #undef LAUNCH_APPLY
@@ -719,8 +736,9 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
 
 static int bwd_reduce_impl(const char* fn, const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y,
                            int dtype, int M, int C, const float* plane_bias, int HW, const float* mean,
-                           const float* invstd, const float* scale, const float* shift, int act, float slope,
-                           float* sums, float* sums_copy, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+                           const float* invstd, const float* scale, const float* shift, const float* weight, int act,
+                           float slope, float* sums, float* sums_copy, void* workspace, size_t workspace_bytes,
+                           ucd_stream_t stream) {
   UCD_TRY(check_common(fn, dtype, M, C, act));
   UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
   UCD_TRY(check_act_tensor(fn, "dy", dy, ld_dy, dtype, C, false));
@@ -738,25 +756,29 @@ static int bwd_reduce_impl(const char* fn, const void* x, int ld_x, const void* 
         (const T*)x, ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, M, C, plane_bias, HW, mean, invstd, scale,     \
         shift, slope, g.TX, g.TY, g.rows_per_band, partial);                                                       \
   }
+  const int a = act & UCD_ACT_MASK;
   if (dtype == UCD_BF16) {
-    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    if (a == UCD_ACT_LEAKY_RELU) LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    else if (a == UCD_ACT_ELU) LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_ELU)
     else LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_IDENTITY)
   } else {
-    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_RED(float, 4, UCD_ACT_LEAKY_RELU)
+    if (a == UCD_ACT_LEAKY_RELU) LAUNCH_RED(float, 4, UCD_ACT_LEAKY_RELU)
+    else if (a == UCD_ACT_ELU) LAUNCH_RED(float, 4, UCD_ACT_ELU)
     else LAUNCH_RED(float, 4, UCD_ACT_IDENTITY)
   }
 #undef LAUNCH_RED
   UCD_TRY(check_launch(fn));
-  reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{}, sums_copy);
+  reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{}, sums_copy,
+                                                           (act & UCD_NORM_ABS_GAMMA) ? weight : nullptr);
   return check_launch(fn);
 }
 
 int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,
                        int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
-                       const float* scale, const float* shift, int act, float slope, float* sums, void* workspace,
-                       size_t workspace_bytes, ucd_stream_t stream) {
+                       const float* scale, const float* shift, const float* weight, int act, float slope, float* sums,
+                       void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   return bwd_reduce_impl("ucd_abn_bwd_reduce", x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale,
-                         shift, act, slope, sums, nullptr, workspace, workspace_bytes, stream);
+                         shift, weight, act, slope, sums, nullptr, workspace, workspace_bytes, stream);
 }
 
 // ---- SyncBN (one process per GPU): the three library calls around the two collectives of a layer ----
@@ -765,7 +787,7 @@ int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const
 int ucd_abn_sync_stats(const void* x, int ld_x, int dtype, int M, int C, const float* plane_bias, int HW, float* sums,
                        float* kshift, float* pack, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   UCD_REQUIRE(sums && kshift && pack, UCD_EINVAL, "ucd_abn_sync_stats: NULL output");
-  FinalizeArgs fin{kshift, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (float)M, 0.f, 0.f, pack};
+  FinalizeArgs fin{kshift, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, (float)M, 0.f, 0.f, pack, 0};
   return abn_stats_impl(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, workspace, workspace_bytes, stream, &fin);
 }
 
@@ -777,7 +799,7 @@ int ucd_abn_sync_forward(const void* x, int ld_x, void* y, int ld_y, const void*
   UCD_REQUIRE(gathered && buf && world >= 1 && C > 0 && M > 0, UCD_EINVAL, "%s: bad arguments", fn);
   float *mean = buf + 3 * C, *invstd = buf + 4 * C, *scale = buf + 5 * C;
   FinalizeArgs fin{nullptr, weight, running_mean, running_var, mean, invstd, scale, (float)M * (float)world, momentum, eps,
-                   nullptr};
+                   nullptr, (act & UCD_NORM_ABS_GAMMA) != 0};
   abn_combine_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(gathered, world, C, (float)M, fin);
   UCD_TRY(check_launch(fn));
   return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, mean, scale, bias, act, slope, stream);
@@ -802,8 +824,8 @@ int ucd_abn_sync_backward_comm(ucd_comm_t comm, int world, const void* x, int ld
                                const float* bias, const float* weight, float* sums, float* local_sums, int act, float slope,
                                void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   UCD_REQUIRE(comm && sums && local_sums && world >= 1, UCD_EINVAL, "ucd_abn_sync_backward_comm: bad arguments");
-  UCD_TRY(ucd_abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale, bias, act,
-                                  slope, sums, local_sums, workspace, workspace_bytes, stream));
+  UCD_TRY(ucd_abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale, bias, weight,
+                                  act, slope, sums, local_sums, workspace, workspace_bytes, stream));
   UCD_TRY(comm_all_reduce_sum_f32(comm, sums, (size_t)2 * C, (hipStream_t)stream));
   return ucd_abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz_out, ld_dz, dtype, M, C, plane_bias, HW, mean, invstd,
                            scale, bias, weight, sums, (float)M * (float)world, 0, act, slope, stream);
@@ -811,10 +833,10 @@ int ucd_abn_sync_backward_comm(ucd_comm_t comm, int world, const void* x, int ld
 
 int ucd_abn_sync_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, int dtype, int M,
                             int C, const float* plane_bias, int HW, const float* mean, const float* invstd,
-                            const float* scale, const float* shift, int act, float slope, float* sums, float* local_sums,
-                            void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+                            const float* scale, const float* shift, const float* weight, int act, float slope,
+                            float* sums, float* local_sums, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   return bwd_reduce_impl("ucd_abn_sync_bwd_reduce", x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd,
-                         scale, shift, act, slope, sums, local_sums, workspace, workspace_bytes, stream);
+                         scale, shift, weight, act, slope, sums, local_sums, workspace, workspace_bytes, stream);
 }
 
 int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, void* dx, int ld_dx,
@@ -839,14 +861,17 @@ int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const 
     Geom g = make_geom<VECN>(M, C, 512, 4);                                                                    \
     abn_bwd_apply_kernel<T, ACT><<<dim3(g.gx, g.gy), kBlock, 0, s>>>(                                              \
         (const T*)x, ld_x, (const T*)dy, ld_dy, (const T*)y, ld_y, (T*)dx, ld_dx, (T*)dz_out, ld_dz, M, C,        \
-        plane_bias, HW, mean, invstd, scale, shift, weight, sums, inv_count, frozen, slope, g.TX, g.TY,           \
-        g.rows_per_band);                                                                                          \
+        plane_bias, HW, mean, invstd, scale, shift, weight, sums, inv_count, frozen,                              \
+        (act & UCD_NORM_ABS_GAMMA) != 0, slope, g.TX, g.TY, g.rows_per_band);                                                                                          \
   }
+  const int a = act & UCD_ACT_MASK;
   if (dtype == UCD_BF16) {
-    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    if (a == UCD_ACT_LEAKY_RELU) LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
+    else if (a == UCD_ACT_ELU) LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_ELU)
     else LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_IDENTITY)
   } else {
-    if (act == UCD_ACT_LEAKY_RELU) LAUNCH_BWD(float, 4, UCD_ACT_LEAKY_RELU)
+    if (a == UCD_ACT_LEAKY_RELU) LAUNCH_BWD(float, 4, UCD_ACT_LEAKY_RELU)
+    else if (a == UCD_ACT_ELU) LAUNCH_BWD(float, 4, UCD_ACT_ELU)
     else LAUNCH_BWD(float, 4, UCD_ACT_IDENTITY)
   }
 #undef LAUNCH_BWD
@@ -865,7 +890,8 @@ int ucd_abn_forward(const void* x, int ld_x, void* y, int ld_y, const void* resi
     UCD_REQUIRE(buf, UCD_EINVAL, "%s: buf is NULL", fn);
     float *sums = buf, *kshift = buf + 2 * C, *mean = buf + 3 * C, *invstd = buf + 4 * C, *scale = buf + 5 * C;
     UCD_TRY(ucd_abn_stats_finalize(x, ld_x, dtype, M, C, plane_bias, HW, sums, kshift, weight, running_mean, running_var,
-                                   momentum, eps, mean, invstd, scale, workspace, workspace_bytes, stream));
+                                   momentum, eps, mean, invstd, scale, act & UCD_NORM_ABS_GAMMA, workspace, workspace_bytes,
+                                   stream));
     return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, mean, scale, bias, act, slope, stream);
   }
   const float* scale = nullptr;
@@ -873,7 +899,7 @@ int ucd_abn_forward(const void* x, int ld_x, void* y, int ld_y, const void* resi
     scale = eval_consts + C;   // [invstd | scale], computed once for a frozen layer
   } else {
     UCD_REQUIRE(buf, UCD_EINVAL, "%s: buf is NULL", fn);
-    UCD_TRY(ucd_abn_eval_params(weight, running_var, eps, C, buf + 4 * C, buf + 5 * C, stream));
+    UCD_TRY(ucd_abn_eval_params(weight, running_var, eps, C, buf + 4 * C, buf + 5 * C, act & UCD_NORM_ABS_GAMMA, stream));
     scale = buf + 5 * C;
   }
   return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, running_mean, scale, bias, act, slope,
@@ -886,8 +912,8 @@ int ucd_abn_backward(const void* x, int ld_x, const void* dy, int ld_dy, const v
                      float count, int training, int need_sums, int act, float slope, void* workspace,
                      size_t workspace_bytes, ucd_stream_t stream) {
   if (training || need_sums)
-    UCD_TRY(ucd_abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale, bias, act, slope,
-                               sums, workspace, workspace_bytes, stream));
+    UCD_TRY(ucd_abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale, bias, weight, act,
+                               slope, sums, workspace, workspace_bytes, stream));
   return ucd_abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz_out, ld_dz, dtype, M, C, plane_bias, HW, mean, invstd,
                            scale, bias, weight, sums, count, training ? 0 : 1, act, slope, stream);
 }

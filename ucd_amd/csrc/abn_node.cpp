@@ -92,7 +92,7 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
                             buf.data_ptr<float>(), nullptr, (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
             "ucd_abn_forward");
     }
-    const bool needs_y = has_res && act != UCD_ACT_IDENTITY;   // the sign of z is not recoverable from x alone
+    const bool needs_y = has_res && (act & UCD_ACT_MASK) != UCD_ACT_IDENTITY;  // the sign of z is not recoverable from x alone
     ctx->save_for_backward({x, needs_y ? y : at::Tensor(), weight, bias, buf});
     ctx->saved_data["act"] = act;
     ctx->saved_data["slope"] = slope;

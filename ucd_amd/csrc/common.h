@@ -25,6 +25,19 @@ int check_launch(const char* what);  // hipGetLastError -> 0 or positive hipErro
     }                                     \
   } while (0)
 
+// Opt a kernel in to `bytes` of dynamic LDS (> 64 KiB needs it).  Done on every call: the attribute belongs to the
+// current device's copy of the code object, so caching "already set" in a static would be wrong for a second device
+// and racy between threads; the call is a host-side table update (no device work).
+#define UCD_TRY_LDS(kernel, bytes)                                                                                  \
+  do {                                                                                                              \
+    hipError_t _e = hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+    if (_e != hipSuccess) {                                                                                         \
+      (void)hipGetLastError();                                                                                      \
+      ucd::set_error("%s: hipFuncSetAttribute(%s): %s", fn, #kernel, hipGetErrorString(_e));                        \
+      return (int)_e;                                                                                               \
+    }                                                                                                               \
+  } while (0)
+
 // RCCL on the caller's stream (comm.hip)
 int comm_all_gather_f32(void* comm, const float* send, float* recv, size_t count, hipStream_t s);
 int comm_all_reduce_sum_f32(void* comm, float* buf, size_t count, hipStream_t s);
@@ -65,13 +78,22 @@ template <> struct Vec<__hip_bfloat16> {
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float z, float slope) {
   if (ACT == UCD_ACT_LEAKY_RELU) return z > 0.f ? z : z * slope;
+  if (ACT == UCD_ACT_ELU) return z > 0.f ? z : slope * expm1f(z);      // slope = alpha
   return z;
 }
-// derivative selected by the sign of z (== sign of y for leaky_relu with slope > 0)
+// derivative at z, given z itself or (from_y) the activation's output y: leaky_relu needs only the sign
+// (sign y == sign z for slope > 0); elu has d/dz = alpha * exp(z) = y + alpha on the negative side
 template <int ACT>
-__device__ __forceinline__ float act_grad(float z_or_y, float slope) {
+__device__ __forceinline__ float act_grad(float z_or_y, float slope, bool from_y = false) {
   if (ACT == UCD_ACT_LEAKY_RELU) return z_or_y > 0.f ? 1.f : slope;
+  if (ACT == UCD_ACT_ELU) return z_or_y > 0.f ? 1.f : (from_y ? z_or_y + slope : slope * __expf(z_or_y));
   return 1.f;
+}
+
+// inplace_abn's in-place variants normalise with gamma~ = |gamma| + eps (the published forward of InPlaceABN /
+// InPlaceABNSync; plain ABN keeps F.batch_norm's raw gamma): selected by the UCD_NORM_ABS_GAMMA bit of `act`
+__host__ __device__ __forceinline__ float gamma_eff(float w, float eps, int abs_gamma) {
+  return abs_gamma ? fabsf(w) + eps : w;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

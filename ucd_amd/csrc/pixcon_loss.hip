@@ -207,7 +207,9 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon_pos_kernel(
     const float* __restrict__ chat, int ldc, const uint8_t* __restrict__ row_label, const float* __restrict__ pcat, int ldp,
     int KP2, const ucd_pixcon_meta* __restrict__ meta, float inv_T, int shift_pos, int use_prob, int nsplit1, int nsplit2,
     int maxA, const float* __restrict__ negp, const float* __restrict__ maxp, float* __restrict__ lossp,
-    float* __restrict__ qsump, float* __restrict__ Vp) {
+    float* __restrict__ qsump, float* __restrict__ Vp, const float* __restrict__ Pmat, int ldP) {
+  // Pmat != NULL (ucd_pixcon_loss_given_p): the weight P_ij is read from a caller-materialised [A, C] matrix in the
+  // reference's column order (anchors first, teacher rows after them) instead of being formed from the probabilities
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int ppitch = KP2 + 1;
   float* cs0 = smem;                                             // [2][32][kPitch]
@@ -305,7 +307,13 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon_pos_kernel(
         const bool pos = row_ok && lc == la && (j0 + jl) != i_row;  // padding rows carry label 255 != la
         float q = 0.f;
         if (pos) {
-          const float pw = (use_prob && !(gt_i && lc >= min_new)) ? pm[reg] : 1.f;
+          float pw;
+          if (Pmat) {
+            const int j = j0 + jl;
+            pw = Pmat[(size_t)i_row * ldP + (j < Apad ? j : A + (j - Apad))];
+          } else {
+            pw = (use_prob && !(gt_i && lc >= min_new)) ? pm[reg] : 1.f;
+          }
           const float sp = x[reg] * inv_T - m_i;
           const float d = __expf(sp) + neg_i;
           lossacc += pw * (sp - __logf(d));
@@ -448,11 +456,11 @@ size_t ucd_pixcon_loss_workspace_bytes(int BHW, int N, int K) {
   return a > b ? a : b;
 }
 
-int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label, const float* pcat, int ldp, int K,
-                    const void* ch16, const void* p16, int precision, const ucd_pixcon_meta* meta, int BHW,
-                    float temperature, int shift_pos, int use_prob, float* loss_out, float* grad_a, int ldg,
-                    float* row_stats, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
-  static const char* fn = "ucd_pixcon_loss";
+static int pixcon_loss_impl(const char* fn, const float* chat, int ldc, int N, const uint8_t* row_label, const float* pcat,
+                            int ldp, int K, const void* ch16, const void* p16, int precision, const ucd_pixcon_meta* meta,
+                            int BHW, float temperature, int shift_pos, int use_prob, const float* Pmat, int ldP,
+                            float* loss_out, float* grad_a, int ldg, float* row_stats, void* workspace,
+                            size_t workspace_bytes, ucd_stream_t stream) {
   UCD_REQUIRE(row_label && meta && loss_out && workspace, UCD_EINVAL, "%s: NULL argument", fn);
   UCD_REQUIRE(BHW > 0 && N > 0 && temperature > 0.f, UCD_EINVAL, "%s: bad sizes", fn);
   UCD_REQUIRE(precision == UCD_PIXCON_F32 || precision == UCD_PIXCON_F16, UCD_EINVAL, "%s: unknown precision %d", fn, precision);
@@ -487,14 +495,9 @@ int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label,
   const int maxA = BHW;
 
   const size_t lds1 = (size_t)(2 * kTJ * kPitch + 2 * kTJ) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    // opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per workgroup)
-    hipFuncSetAttribute((const void*)pixcon_neg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute((const void*)pixcon_pos_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  // opt in to more than 64 KiB of dynamic LDS (gfx950 has 160 KiB per workgroup); per call, no process-wide state
+  UCD_TRY_LDS(pixcon_neg_kernel, 160 * 1024);
+  UCD_TRY_LDS(pixcon_pos_kernel, 160 * 1024);
   pixcon_neg_kernel<<<dim3(p.nt_i, p.nsplit1), kThreads, lds1, s>>>(chat, ldc, row_label, meta, inv_T, p.nsplit1, maxA,
                                                                     negp, maxp, Up);
   int rc = check_launch(fn);
@@ -503,7 +506,7 @@ int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label,
   const size_t lds2 = lds1 + (size_t)(2 * kTJ + kBI) * (KP2 + 1) * 4;
   pixcon_pos_kernel<<<dim3(p.nt_i, p.nsplit2), kThreads, lds2, s>>>(chat, ldc, row_label, pcat, ldp, KP2, meta, inv_T,
                                                                     shift_pos, use_prob, p.nsplit1, p.nsplit2, maxA,
-                                                                    negp, maxp, lossp, qsump, Vp);
+                                                                    negp, maxp, lossp, qsump, Vp, Pmat, ldP);
   rc = check_launch(fn);
   if (rc) return rc;
   pixcon_finalize_kernel<<<ceil_div(BHW, kThreads / 64), kThreads, 0, s>>>(row_label, meta, inv_T, p.nsplit1, p.nsplit2,
@@ -513,6 +516,25 @@ int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label,
   if (rc) return rc;
   pixcon_reduce_kernel<<<1, 1024, 0, s>>>(rowloss, meta, loss_out);
   return check_launch(fn);
+}
+
+int ucd_pixcon_loss(const float* chat, int ldc, int N, const uint8_t* row_label, const float* pcat, int ldp, int K,
+                    const void* ch16, const void* p16, int precision, const ucd_pixcon_meta* meta, int BHW,
+                    float temperature, int shift_pos, int use_prob, float* loss_out, float* grad_a, int ldg,
+                    float* row_stats, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  return pixcon_loss_impl("ucd_pixcon_loss", chat, ldc, N, row_label, pcat, ldp, K, ch16, p16, precision, meta, BHW, temperature,
+                          shift_pos, use_prob, nullptr, 0, loss_out, grad_a, ldg, row_stats, workspace, workspace_bytes, stream);
+}
+
+int ucd_pixcon_loss_given_p(const float* chat, int ldc, int N, const uint8_t* row_label, const float* P, int ld_P,
+                            const ucd_pixcon_meta* meta, int max_anchors, float temperature, int shift_pos,
+                            float* loss_out, float* grad_a, int ldg, float* row_stats, void* workspace,
+                            size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_pixcon_loss_given_p";
+  UCD_REQUIRE(!P || ld_P > 0, UCD_EINVAL, "%s: ld_P must be positive", fn);
+  return pixcon_loss_impl(fn, chat, ldc, N, row_label, nullptr, 0, 0, nullptr, nullptr, UCD_PIXCON_F32, meta, max_anchors,
+                          temperature, shift_pos, 0, P, ld_P, loss_out, grad_a, ldg, row_stats, workspace, workspace_bytes,
+                          stream);
 }
 
 }  // extern "C"

@@ -659,14 +659,10 @@ int pixcon16_launch(const _Float16* ch16, const uint8_t* row_label, const _Float
   const int KP16 = use_prob ? (K + 15) / 16 * 16 : 0;
   const float k2 = kLog2e / temperature;
   const int maxA = BHW;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)pixcon16_neg_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)pixcon16_neg_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)pixcon16_pos_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipGetLastError();
-    attr_set = true;
-  }
+  // opt in to more than 64 KiB of dynamic LDS: per call (the attribute is per device; there is no process-wide state here)
+  UCD_TRY_LDS(pixcon16_neg_kernel<true>, 160 * 1024);
+  UCD_TRY_LDS(pixcon16_neg_kernel<false>, 160 * 1024);
+  UCD_TRY_LDS(pixcon16_pos_kernel, 160 * 1024);
   const size_t lds1n = (size_t)3 * kTJ * kPitchH * 2 + 3 * (kTJ + 4) * 4;
   if (k2 <= kFixedShiftMaxK2)
     pixcon16_neg_kernel<true><<<dim3(nt_i, ns), kThreads, lds1n, s>>>(ch16, row_label, meta, k2, ns, maxA, negp, mrunp, maxp, Up);

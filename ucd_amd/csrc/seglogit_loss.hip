@@ -280,14 +280,8 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const int ny = (int)(kTileY * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
   const size_t lds = ((size_t)ny * nx * (2 * Ctot + K) + 8) * sizeof(float);
   UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t ea = hipFuncSetAttribute((const void*)seg_losses_kernel<24>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (ea == hipSuccess)
-      ea = hipFuncSetAttribute((const void*)seg_losses_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    if (ea != hipSuccess) { (void)hipGetLastError(); set_error("%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(ea)); return (int)ea; }
-    attr_set = true;
-  }
+  UCD_TRY_LDS(seg_losses_kernel<24>, 150 * 1024);
+  UCD_TRY_LDS(seg_losses_kernel<0>, 150 * 1024);
   hipError_t e = hipMemsetAsync(d_sem, 0, (size_t)B * h * w * ld_d * sizeof(float), s);
   if (e != hipSuccess) { set_error("%s: %s", fn, hipGetErrorString(e)); return (int)e; }
   const float inv_pix = 1.f / ((float)B * H * W);

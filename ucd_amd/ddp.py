@@ -16,12 +16,22 @@ Here (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL):
 
 The wrapper keeps the ``module.``-prefixed ``state_dict`` keys that the reference's checkpoints have
 (run.py:37,217,222 save and load the DDP-wrapped model).
+
+Drop-in use needs no extra calls: the reference's loop ``optim.zero_grad(); loss.backward(); optim.step()``
+(train.py:104,137-138,149) works unchanged - the first gradient hook of a backward queues an end-of-backward callback
+(``Variable._execution_engine.queue_callback``, the mechanism of torch's own DDP reducer) that completes and waits for the
+buckets, and the wrapper's ``forward`` re-attaches the bucket views that ``optim.zero_grad(set_to_none=True)`` dropped.
+``zero_grad()`` / ``finish_grad_sync()`` remain as the explicit (and idempotent) forms ``ucd_amd.train.Trainer`` uses.
+Gradient accumulation over several backward passes per optimiser step is not supported (it raises).
 """
 from __future__ import annotations
+
+import weakref
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+from torch.optim.optimizer import register_optimizer_step_post_hook
 
 
 def _view_like(buf, p):
@@ -91,6 +101,20 @@ class GradReducer:
             cur_bytes += nb
         if cur:
             self._make_bucket(cur)
+        self._cb_queued = False
+        self._finished = False          # this step's buckets are already reduced (finish() is idempotent)
+        # a finished backward whose gradients were neither consumed by an optimiser step nor cleared: the next backward
+        # would be gradient accumulation, which the bf16 working-copy hand-over and the kernel-written ABN gradients
+        # (both overwrite) cannot express
+        self._dirty = False
+        ref = weakref.ref(self)
+
+        def _after_step(optimizer, args, kwargs):
+            me = ref()
+            if me is not None:
+                me._dirty = False
+        self._step_hook = register_optimizer_step_post_hook(_after_step)
+        self._events = {}
         self._hooks = []
         for p in params:
             holder = self.shadow_of.get(p)
@@ -118,6 +142,8 @@ class GradReducer:
     # -- per step ------------------------------------------------------------------------------
     def zero_grad(self):
         """One memset per bucket instead of one per tensor; keeps the grad views alive."""
+        self._finished = False
+        self._dirty = False
         if self.direct_flat is not None:
             self.direct_flat.zero_()
             off = 0
@@ -140,11 +166,34 @@ class GradReducer:
                     p.grad = _view_like(b.flat[off:off + p.numel()], p)
                 off += p.numel()
 
+    def prepare_step(self):
+        """Called by the wrapper's forward: if the caller cleared the gradients with ``optim.zero_grad()`` (set_to_none:
+        the bucket views are gone) re-attach zeroed views, so that autograd accumulates into the buckets again and the ABN
+        kernels can write their parameter gradients in place."""
+        probe = self.params[0] if self.params else None
+        dropped = probe is not None and probe.grad is None and self.shadow_of.get(probe) is None
+        if not dropped and self.direct_flat is not None:
+            dropped = self._direct_modules[0].bias.grad is None
+        if dropped:
+            self.zero_grad()
+
     def _on_grad(self, p):
         b = self._bucket_of[p]
+        if b.done or b.pending <= 0 or (self._dirty and not self._cb_queued):
+            raise RuntimeError("ucd_amd.ddp: a second backward before optim.step() / zero_grad() - gradient accumulation over "
+                               "several backward passes per optimiser step is not supported")
+        if not self._cb_queued:
+            # end-of-backward callback: finish() without any call from the training loop (apex DDP's allreduce hook)
+            self._cb_queued = True
+            self._finished = False
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         b.pending -= 1
         if b.pending == 0:
             self._complete(b)
+
+    def _end_of_backward(self):
+        self._cb_queued = False
+        self.finish()
 
     def _complete(self, b):
         """All gradients of the bucket exist: widen the bf16 ones into their fp32 slots (one multi-tensor copy),
@@ -152,6 +201,20 @@ class GradReducer:
         if b.done:
             return
         b.done = True
+        # gradients that autograd re-created outside the bucket (the caller dropped the views with set_to_none and no
+        # forward of the wrapper re-attached them): move them in
+        off = 0
+        for p in b.params:
+            n = p.numel()
+            g = p.grad
+            if g is not None and self.shadow_of.get(p) is None:
+                view = _view_like(b.flat[off:off + n], p)
+                if g.data_ptr() != view.data_ptr():
+                    view.copy_(g)
+                    p.grad = view
+            elif g is None and self.shadow_of.get(p) is not None and self.shadow_of[p].grad is not None:
+                p.grad = _view_like(b.flat[off:off + n], p)
+            off += n
         if b.fed:
             dst, src = [], []
             for view32, holder in b.fed:
@@ -165,9 +228,15 @@ class GradReducer:
         if self.world > 1:
             self._launch(b)
 
+    def _event(self, key):
+        ev = self._events.get(key)
+        if ev is None:
+            ev = self._events[key] = torch.cuda.Event()
+        return ev
+
     def _launch(self, b):
         if self.overlap:
-            ev = torch.cuda.Event()
+            ev = self._event(id(b))                              # one event per bucket, reused every step
             ev.record(torch.cuda.current_stream(self.device))    # bucket complete on the compute stream
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
@@ -187,15 +256,32 @@ class GradReducer:
             b.work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
-        """Block the compute stream (not the host) until every bucket of this step is averaged."""
+        """Block the compute stream (not the host) until every bucket of this step is averaged.  Runs from the
+        end-of-backward callback; calling it again before the next backward is a no-op."""
+        if self._finished:
+            return
+        self._finished = True
+        self._dirty = True
         for b in self.buckets:                                  # parameters that received no gradient
             if not b.done:
                 self._complete(b)
+        m0 = self._direct_modules[0] if self.direct_flat is not None else None
+        if m0 is not None and (m0.bias.grad is None or m0.bias.grad.data_ptr() != self.direct_flat.data_ptr()):
+            off = 0                                             # ABN gradients autograd produced outside the flat buffer
+            for m in self._direct_modules:
+                C = m.weight.numel()
+                for p, o in ((m.bias, off), (m.weight, off + C)):
+                    g = p.grad
+                    if g is not None and g.data_ptr() != self.direct_flat.data_ptr() + 4 * o:
+                        self.direct_flat[o:o + C].copy_(g)
+                        p.grad = self.direct_flat[o:o + C]
+                off += 2 * C
         if self.world == 1:
+            self._reset_step()
             return
         if self.direct_flat is not None:                        # kernel-written ABN parameter gradients: one small reduce
             if self.overlap:
-                ev = torch.cuda.Event()
+                ev = self._event("direct")
                 ev.record(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(self.stream):
                     self.stream.wait_event(ev)
@@ -220,6 +306,14 @@ class GradReducer:
         if self.overlap:
             torch.cuda.current_stream(self.device).wait_stream(self.stream)
         self._inflight = []
+        self._reset_step()
+
+    def _reset_step(self):
+        """Per-step bucket state back to 'nothing arrived' (also done by zero_grad): a loop that never calls the reducer's
+        zero_grad (the reference's optim.zero_grad()) must find fresh counters at its next backward."""
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.done = False
 
     def _reduce_flat(self, flat):
         if self.use_avg:
@@ -232,12 +326,15 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self._step_hook.remove()
 
 
 class DistributedDataParallel(nn.Module):
     """``DistributedDataParallel(model, delay_allreduce=True)`` call shape of apex (run.py:204).
     Parameters and buffers are broadcast from rank 0 at construction (apex does the same).
-    Call ``zero_grad()`` before and ``finish_grad_sync()`` after ``backward()``."""
+    The reference's loop works unchanged (``optim.zero_grad(); loss.backward(); optim.step()``): gradient averaging is
+    finished by an end-of-backward callback.  ``zero_grad()`` (one memset per bucket) and ``finish_grad_sync()`` (idempotent)
+    are the explicit forms."""
 
     def __init__(self, module, delay_allreduce=True, bucket_mb=32.0, wire_dtype=None, group=None, overlap=True,
                  bf16_weights=False):
@@ -263,6 +360,8 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         if self.bf16_weights is not None:
             self.bf16_weights.refresh_if_stale()            # after an optimiser step / checkpoint load
+        if self.reducer is not None and self.training and torch.is_grad_enabled():
+            self.reducer.prepare_step()
         return self.module(*args, **kwargs)
 
     def zero_grad(self, set_to_none=False):

@@ -15,8 +15,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libucd_hip.so")
 
 F32, BF16 = 0, 1
-ACT_IDENTITY, ACT_LEAKY_RELU = 0, 1
-ACT_CODES = {"identity": ACT_IDENTITY, "leaky_relu": ACT_LEAKY_RELU}
+ACT_IDENTITY, ACT_LEAKY_RELU, ACT_ELU = 0, 1, 2
+ACT_CODES = {"identity": ACT_IDENTITY, "leaky_relu": ACT_LEAKY_RELU, "elu": ACT_ELU}
+ACT_MASK = 0xFF
+NORM_ABS_GAMMA = 0x100   # flag bit of `act`: gamma~ = |weight| + eps (InPlaceABN / InPlaceABNSync), see include/ucd_hip.h
 PIX_TILE = 128          # kPixTile of csrc/pixcon.h
 PIXCON_LD = 256         # feature rows of the contrast matrix are padded to 256 columns
 PIXCON_F32, PIXCON_F16 = 0, 1
@@ -41,11 +43,11 @@ SIGNATURES = {
     "ucd_last_error": (C.c_char_p, []),
     "ucd_abn_workspace_bytes": (_z, [_i, _i]),
     "ucd_abn_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _z, _p]),
-    "ucd_abn_stats_finalize": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _z, _p]),
-    "ucd_abn_finalize": (_i, [_p, _p, _f, _i, _p, _p, _p, _f, _f, _p, _p, _p, _p]),
-    "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _p]),
+    "ucd_abn_stats_finalize": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p, _z, _p]),
+    "ucd_abn_finalize": (_i, [_p, _p, _f, _i, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p]),
+    "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _i, _p]),
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
-    "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
     "ucd_label_path": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
     "ucd_image_path": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
     "ucd_gemm_load": (_i, [C.c_char_p]),
@@ -67,7 +69,7 @@ SIGNATURES = {
                                         _p, _p, _i, _f, _p, _z, _p]),
     "ucd_abn_sync_stats": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _z, _p]),
     "ucd_abn_sync_forward": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _f, _p]),
-    "ucd_abn_sync_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
+    "ucd_abn_sync_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _p, _z, _p]),
     "ucd_abn_bwd_apply": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p,
                                _f, _i, _i, _f, _p]),
     "ucd_abn_forward": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _f, _f, _i, _p, _p, _i, _f, _p, _z, _p]),
@@ -81,6 +83,7 @@ SIGNATURES = {
     "ucd_pixcon_gather": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p]),
     "ucd_pixcon_loss_workspace_bytes": (_z, [_i, _i, _i]),
     "ucd_pixcon_loss": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _i, _f, _i, _i, _p, _p, _i, _p, _p, _z, _p]),
+    "ucd_pixcon_loss_given_p": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _f, _i, _p, _p, _i, _p, _p, _z, _p]),
     "ucd_pixcon_scatter_grad": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "ucd_seg_losses_workspace_bytes": (_z, [_i, _i, _i]),
     "ucd_seg_losses": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _i, _p, _z, _p]),
@@ -266,15 +269,15 @@ def abn_stats(x, ld, M, Cc, plane_bias, HW, sums, kshift):
 
 
 def abn_stats_finalize(x, ld, M, Cc, plane_bias, HW, sums, kshift, weight, running_mean, running_var, momentum, eps,
-                       mean, invstd, scale):
+                       mean, invstd, scale, flags=0):
     lib = load()
     nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
     ws = workspace(nbytes, x.device)
     with _timed("ucd_abn_stats", M * Cc * x.element_size()):
         _check(lib.ucd_abn_stats_finalize(ptr(x), ld, dtype_code(x), M, Cc, ptr(plane_bias), HW, ptr(sums), ptr(kshift),
                                           ptr(weight), ptr(running_mean), ptr(running_var), float(momentum), float(eps),
-                                          ptr(mean), ptr(invstd), ptr(scale), ptr(ws), nbytes, stream()),
-               "ucd_abn_stats_finalize")
+                                          ptr(mean), ptr(invstd), ptr(scale), int(flags) & NORM_ABS_GAMMA, ptr(ws), nbytes,
+                                          stream()), "ucd_abn_stats_finalize")
 
 
 def abn_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight, bias, running_mean, running_var,
@@ -286,12 +289,12 @@ def abn_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, weight,
     if _timing is not None:      # instrumented bench pass: keep the per-kernel attribution
         if training:
             abn_stats_finalize(x, ld_x, M, Cc, plane_bias, HW, buf[:2 * Cc], buf[2 * Cc:3 * Cc], weight, running_mean,
-                               running_var, momentum, eps, buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:])
+                               running_var, momentum, eps, buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:], act)
             abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, buf[3 * Cc:4 * Cc], buf[5 * Cc:], bias, act, slope)
         else:
             sc = eval_consts[1] if eval_consts is not None else buf[5 * Cc:]
             if eval_consts is None:
-                abn_eval_params(weight, running_var, eps, Cc, buf[4 * Cc:5 * Cc], buf[5 * Cc:])
+                abn_eval_params(weight, running_var, eps, Cc, buf[4 * Cc:5 * Cc], buf[5 * Cc:], act)
             abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, running_mean, sc, bias, act, slope)
         return
     rc = lib.ucd_abn_forward(x.data_ptr(), ld_x, y.data_ptr(), ld_y, ptr(residual), ld_r, BF16 if es == 2 else F32, M, Cc,
@@ -307,7 +310,8 @@ def abn_backward(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane
     lib = load()
     if _timing is not None:
         if training or need_sums:
-            abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, bias, act, slope, sums)
+            abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, bias, act, slope, sums,
+                           weight)
         abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane_bias, HW, mean, invstd, scale, bias,
                       weight, sums, count, 0 if training else 1, act, slope)
         return
@@ -403,26 +407,26 @@ def abn_sync_forward(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, ga
 
 
 def abn_sync_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope, sums,
-                        local_sums):
+                        local_sums, weight=None):
     lib = load()
     nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
     ws = workspace(nbytes, x.device)
     with _timed("ucd_abn_bwd_reduce", M * Cc * x.element_size() * (2 + (y is not None))):
         _check(lib.ucd_abn_sync_bwd_reduce(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, dtype_code(x), M, Cc,
-                                           ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), act,
-                                           float(slope), ptr(sums), ptr(local_sums), ptr(ws), nbytes, stream()),
+                                           ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(weight),
+                                           act, float(slope), ptr(sums), ptr(local_sums), ptr(ws), nbytes, stream()),
                "ucd_abn_sync_bwd_reduce")
 
 
-def abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale):
+def abn_finalize(sums, kshift, count, Cc, weight, running_mean, running_var, momentum, eps, mean, invstd, scale, flags=0):
     _check(load().ucd_abn_finalize(ptr(sums), ptr(kshift), float(count), Cc, ptr(weight), ptr(running_mean),
                                    ptr(running_var), float(momentum), float(eps), ptr(mean), ptr(invstd), ptr(scale),
-                                   stream()), "ucd_abn_finalize")
+                                   int(flags) & NORM_ABS_GAMMA, stream()), "ucd_abn_finalize")
 
 
-def abn_eval_params(weight, running_var, eps, Cc, invstd, scale):
+def abn_eval_params(weight, running_var, eps, Cc, invstd, scale, flags=0):
     _check(load().ucd_abn_eval_params(ptr(weight), ptr(running_var), float(eps), Cc, ptr(invstd), ptr(scale),
-                                      stream()), "ucd_abn_eval_params")
+                                      int(flags) & NORM_ABS_GAMMA, stream()), "ucd_abn_eval_params")
 
 
 def abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, scale, shift, act, slope):
@@ -432,14 +436,15 @@ def abn_apply(x, ld_x, y, ld_y, residual, ld_r, M, Cc, plane_bias, HW, mean, sca
                                     stream()), "ucd_abn_apply")
 
 
-def abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope, sums):
+def abn_bwd_reduce(x, ld_x, dy, ld_dy, y, ld_y, M, Cc, plane_bias, HW, mean, invstd, scale, shift, act, slope, sums,
+                   weight=None):
     lib = load()
     nbytes = lib.ucd_abn_workspace_bytes(M, Cc)
     ws = workspace(nbytes, x.device)
     with _timed("ucd_abn_bwd_reduce", M * Cc * x.element_size() * (2 + (y is not None))):
         _check(lib.ucd_abn_bwd_reduce(ptr(x), ld_x, ptr(dy), ld_dy, ptr(y), ld_y, dtype_code(x), M, Cc,
-                                      ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), act,
-                                      float(slope), ptr(sums), ptr(ws), nbytes, stream()), "ucd_abn_bwd_reduce")
+                                      ptr(plane_bias), HW, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(weight),
+                                      act, float(slope), ptr(sums), ptr(ws), nbytes, stream()), "ucd_abn_bwd_reduce")
 
 
 def abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_y, dx, ld_dx, dz, ld_dz, M, Cc, plane_bias, HW, mean, invstd, scale,
