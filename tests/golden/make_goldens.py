@@ -290,8 +290,105 @@ def gold_cfg0():
          **grads, **upd)
 
 
+def _build_pair(models, modules, segm, classes, seed=42):
+    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+
+    def build(cls):
+        body = models.net_resnet101(norm_act=norm, output_stride=16)
+        head = modules.DeeplabV3(body.out_channels, 256, 256, norm_act=norm, out_stride=16, pooling_size=32)
+        return segm.IncrementalSegmentationModule(body, head, 256, classes=cls)
+
+    student, teacher = build(classes), build(classes[:-1])
+    sd = synth.fill_state_dict(teacher.state_dict(), seed)
+    teacher.load_state_dict(sd)
+    student.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        student.init_new_classifier(torch.device("cpu"))
+    for p in teacher.parameters():
+        p.requires_grad = False
+    teacher.eval(); student.train()
+    return student, teacher
+
+
+STEP_NAMES = ["body.mod1.conv1.weight", "body.mod3.block2.convs.bn2.weight", "body.mod5.block3.convs.conv3.weight",
+              "head.map_convs.2.weight", "head.red_bn.bias", "head.global_pooling_bn.weight"]
+
+
+def _ucd_step(student, teacher, img, labels, old_cl, extra_names):
+    """train.py:95-151 as intended, through the reference's own classes; returns the golden dict."""
+    groups = [{"params": [p for p in m.parameters() if p.requires_grad], "weight_decay": 1e-4}
+              for m in (student.body, student.head, student.cls)]
+    opt = torch.optim.SGD(groups, lr=1e-3, momentum=0.9, nesterov=True)
+    with torch.no_grad():
+        out_old, feat_old = teacher(img)
+    opt.zero_grad()
+    outp, feat = student(img)
+    a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
+                                                     f_o=feat_old["pre_logits"])
+    ce = ref_loss.UnbiasedCrossEntropy(old_cl=old_cl, ignore_index=255, reduction="none")(outp, labels.clone()).mean()
+    con = ref_loss.PixelConLossV2(temperature=0.07)(a, c, la, lc, P)
+    loss = ce + con / 100
+    lkd = 10 * ref_loss.UnbiasedKnowledgeDistillationLoss(alpha=1.0)(outp, out_old)
+    (loss + lkd).backward()
+    names = STEP_NAMES + extra_names
+    params = dict(student.named_parameters())
+    grads = {f"grad_abs::{n}": params[n].grad.double().abs().sum().item() for n in names}
+    grads.update({f"grad_sum::{n}": params[n].grad.double().sum().item() for n in names})
+    opt.step()
+    upd = {f"after_step::{n}": params[n].detach().flatten()[:16].numpy().copy() for n in names}
+    idx = sample_idx(outp.numel(), 256)
+    out = dict(ce=ce.item(), con=con.item(), loss=loss.item(), lkd=lkd.item(), A=a.shape[0], C=c.shape[0],
+               logits_sample=outp.detach().flatten()[idx].numpy(), sample_idx=idx,
+               teacher_logits_sample=out_old.flatten()[sample_idx(out_old.numel(), 256)].numpy(),
+               running_mean_after=student.body.mod1.bn1.running_mean.numpy().copy(), **grads, **upd)
+    out.update(compact("teacher_sem", feat_old["sem"].numpy()))
+    out.update(compact("student_sem", feat["sem"].detach().numpy()))
+    return out
+
+
+def gold_step513():
+    """BASELINE.json configs[1] at its REAL crop: VOC 15-5 step 1 --method UCD on 2 x 513^2 (the per-image shapes of the
+    benchmark; at 513 the stride-16 map is 33 x 33 > --pooling 32, so the teacher takes the sliding-window branch of
+    modules/deeplab.py:77-88 that smaller crops never reach)."""
+    models, modules, segm = import_reference_model()
+    student, teacher = _build_pair(models, modules, segm, [16, 5])
+    img = synth.images(502, 2, 513)
+    labels = synth.seg_labels(502, 2, 513, 513, range(16, 21))
+    out = _ucd_step(student, teacher, img, labels, 16, ["cls.1.weight", "cls.1.bias"])
+    save("ucd_step_513.npz", cfg=np.array([502, 2, 513]), **out)
+
+
+def gold_heads():
+    """BASELINE.json configs[2], a later overlapped step: VOC 15-5s step 3 -> student heads [16, 1, 1, 1], teacher
+    [16, 1, 1] (tasks.py:16-29), new class id 18, 2 x 129^2."""
+    models, modules, segm = import_reference_model()
+    student, teacher = _build_pair(models, modules, segm, [16, 1, 1, 1], seed=44)
+    img = synth.images(503, 2, 129)
+    labels = synth.seg_labels(503, 2, 129, 129, [18])
+    out = _ucd_step(student, teacher, img, labels, 18, ["cls.1.weight", "cls.2.bias", "cls.3.weight", "cls.3.bias"])
+    save("ucd_step_15_5s_step3.npz", cfg=np.array([503, 2, 129]), **out)
+
+
+def gold_aspp_eval():
+    """DeeplabV3 in evaluation mode on maps LARGER than --pooling 32 (modules/deeplab.py:77-88: avg_pool2d(32, stride 1) +
+    replicate pad): 33 x 33 (VOC 513^2) and 48 x 48 (Cityscapes 768^2), plus an even pooling size on an odd map."""
+    models, modules, segm = import_reference_model()
+    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    out = {}
+    for tag, hw, pool in (("33", (33, 33), 32), ("48", (48, 48), 32), ("odd", (21, 35), 8)):
+        head = modules.DeeplabV3(64, 32, 16, norm_act=norm, out_stride=16, pooling_size=pool)
+        head.load_state_dict(synth.fill_state_dict(head.state_dict(), 21))
+        head.eval()
+        x = synth.t_normal(410 + len(tag), (2, 64) + hw, stream=1)
+        with torch.no_grad():
+            y = head(x)
+        out.update(compact(f"eval_{tag}", y.numpy()))
+        out[f"cfg_{tag}"] = np.array([410 + len(tag), 2, 64, hw[0], hw[1], pool])
+    save("aspp_eval.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pixcon", "logit", "v1", "model", "cfg0"]
+    which = sys.argv[1:] or ["pixcon", "logit", "v1", "model", "cfg0", "step513", "heads", "aspp_eval"]
     if "cfg0" in which:
         gold_cfg0()
     if "pixcon" in which:
@@ -302,3 +399,9 @@ if __name__ == "__main__":
         gold_v1_losses()
     if "model" in which:
         gold_model()
+    if "step513" in which:
+        gold_step513()
+    if "heads" in which:
+        gold_heads()
+    if "aspp_eval" in which:
+        gold_aspp_eval()

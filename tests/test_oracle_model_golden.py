@@ -37,15 +37,16 @@ def test_blocks_and_head_match_reference():
     np.testing.assert_allclose(OM.deeplab_head(xh, Ph, False, pooling_size=4).numpy(), g["head_eval"], rtol=1e-5, atol=1e-5)
 
 
-def _student_teacher_params(seed=42):
-    teacher = build_cpu_net([16])
-    student = build_cpu_net([16, 5])
+def _student_teacher_params(seed=42, classes=(16, 5)):
+    classes = list(classes)
+    teacher = build_cpu_net(classes[:-1])
+    student = build_cpu_net(classes)
     sd = synth.fill_state_dict(teacher.state_dict(), seed)
     Pt = OS.make_params(sd, requires_grad=False)
     st = {k: v.clone() for k, v in student.state_dict().items()}
     st.update({k: v.clone() for k, v in sd.items()})
     Ps = OS.make_params(st)
-    OM.init_new_classifier(Ps, 2, 5)
+    OM.init_new_classifier(Ps, len(classes), classes[-1])
     return Ps, Pt
 
 
@@ -115,3 +116,59 @@ def test_config0_voc_19_1_step0_ft_matches_reference():
         if k.startswith("grad_abs::"):
             n = k.split("::")[1]
             assert P[n].grad.double().abs().sum().item() == pytest.approx(float(g[k]), rel=2e-3), n
+
+
+def _check_step_golden(g, r, Ps, rel=1e-4):
+    from conftest import assert_matches_compact
+    assert r["A"] == int(g["A"]) and r["C"] == int(g["C"])
+    for k in ("ce", "con", "loss", "lkd"):
+        assert r[k].item() == pytest.approx(float(g[k]), rel=rel), k
+    np.testing.assert_allclose(r["logits"].detach().flatten()[g["sample_idx"]].numpy(), g["logits_sample"], rtol=1e-3, atol=1e-3)
+    np.testing.assert_allclose(r["logits_old"].flatten()[sample_idx(r["logits_old"].numel(), 256)].numpy(),
+                               g["teacher_logits_sample"], rtol=1e-3, atol=1e-3)
+    (r["loss"] + r["lkd"]).backward()
+    for k in g:
+        if k.startswith("grad_abs::"):
+            n = k.split("::")[1]
+            assert Ps[n].grad.double().abs().sum().item() == pytest.approx(float(g[k]), rel=2e-3), n
+
+
+def test_ucd_step_at_the_benchmark_crop_matches_reference():
+    """configs[1] at 513^2 (2 images): 33 x 33 stride-16 maps, so the teacher's ASPP takes the sliding-window pooling branch
+    (modules/deeplab.py:77-88) that the 129^2 golden never reaches."""
+    g = load_golden("ucd_step_513.npz")
+    Ps, Pt = _student_teacher_params()
+    img = synth.images(502, 2, 513)
+    labels = synth.seg_labels(502, 2, 513, 513, range(16, 21))
+    r = OS.ucd_losses(Ps, Pt, img, labels, [16, 5])
+    _check_step_golden(g, r, Ps)
+
+
+def test_ucd_step_multi_head_15_5s_step3_matches_reference():
+    """configs[2]: a later overlapped step - student heads [16, 1, 1, 1], teacher [16, 1, 1]."""
+    g = load_golden("ucd_step_15_5s_step3.npz")
+    Ps, Pt = _student_teacher_params(seed=44, classes=(16, 1, 1, 1))
+    img = synth.images(503, 2, 129)
+    labels = synth.seg_labels(503, 2, 129, 129, [18])
+    r = OS.ucd_losses(Ps, Pt, img, labels, [16, 1, 1, 1])
+    _check_step_golden(g, r, Ps)
+
+
+def test_aspp_eval_pooling_matches_reference():
+    """DeeplabV3 eval mode on maps larger than the pooling window (33 x 33, 48 x 48, odd map with an even window)."""
+    from functools import partial
+    from conftest import assert_matches_compact
+    g = load_golden("aspp_eval.npz")
+    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    for tag in ("33", "48", "odd"):
+        seed, B, C, H, W, pool = [int(v) for v in g[f"cfg_{tag}"]]
+        head = DeeplabV3(C, 32, 16, norm_act=norm, out_stride=16, pooling_size=pool)
+        Ph = {"head." + k: v for k, v in synth.fill_state_dict(head.state_dict(), 21).items()}
+        x = synth.t_normal(seed, (B, C, H, W), stream=1)
+        y = OM.deeplab_head(x, Ph, False, pooling_size=pool)
+        assert_matches_compact(g, f"eval_{tag}", y.numpy(), rtol=1e-4, atol=1e-4)
+        # the product's module tree on the CPU shim (literal fallback path of ucd_amd.blocks) agrees too
+        head.load_state_dict(synth.fill_state_dict(head.state_dict(), 21))
+        head.eval()
+        with torch.no_grad():
+            assert_matches_compact(g, f"eval_{tag}", head(x).numpy(), rtol=1e-4, atol=1e-4)

@@ -71,6 +71,9 @@ def test_fused_loss_matches_oracle_and_golden(name):
     (2, 256, 16, 14, 256, list(range(14, 20)), 20),      # Cityscapes-like
     (2, 64, 12, 101, 192, list(range(101, 151)), 150),   # ADE: labels beyond int8's 20-clamp (generalised bound)
     (2, 32, 9, 16, 129, [16], 20),
+    (3, 256, 32, 101, 512, list(range(101, 151)), 150),  # BASELINE configs[3]: ADE 100-50 per-rank shape (3 x 512^2, K = 101)
+    (2, 256, 48, 14, 768, list(range(14, 20)), 20),      # BASELINE configs[4]: Cityscapes 13-6 per-rank shape (2 x 768^2)
+    (3, 256, 33, 18, 513, [18], 20),                     # BASELINE configs[2]: VOC 15-5s step 3 per-rank shape (K = 18)
 ])
 def test_prep_and_loss_vs_oracle(B, N, h, K, H, new_ids, max_label):
     from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare, ucd_contrastive_loss

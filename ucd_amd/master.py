@@ -59,7 +59,9 @@ class Bf16Weights:
             me = ref()
             if me is not None:
                 me._dirty = True
-        self._hook = register_optimizer_step_post_hook(_after_step)
+        # frozen copies (the teacher) are not touched by any optimiser: no hook, the version counters (load_state_dict,
+        # copy_) and mark_stale() are what invalidates them - otherwise every student step would re-cast the teacher
+        self._hook = register_optimizer_step_post_hook(_after_step) if trainable else None
         self.refresh_if_stale()
 
     def __del__(self):

@@ -80,8 +80,9 @@ class Trainer:
         self.unce = bool(opts.unce and self.old_classes != 0)
         # fused up-sampling + CE + KD kernel whenever the loss pair is one it implements:
         # (unbiased or plain) CE, optionally with the unbiased KD
+        # (the kernel has no --alpha: utils/loss.py:158 scales the teacher logits by it, so alpha != 1 takes the unfused path)
         self.fuse_logit_losses = (getattr(opts, "fused_logit_losses", True) and device.type == "cuda"
-                                  and (not self.lkd_flag or (opts.unkd and self.unce)))
+                                  and (not self.lkd_flag or (opts.unkd and self.unce and float(opts.alpha) == 1.0)))
         self.amp = getattr(opts, "opt_level", "O0") != "O0"
         # contrastive arithmetic: exact fp32 MFMA with fp32 activations (O0), fp16 operands otherwise
         self.pixcon_precision = getattr(opts, "pixcon_precision", None) or ("f16" if self.amp else "f32")
