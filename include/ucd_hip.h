@@ -384,6 +384,67 @@ int ucd_image_path(const uint8_t* const* src, const int* desc, int B, int S, int
                    float mean_b, float std_r, float std_g, float std_b, int* coeff_ws, uint8_t* tmp, float* out,
                    ucd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * 1x1 convolutions as row-matrix GEMMs on the bf16 matrix cores with the neighbouring ABN work fused (SURVEY.md
+ * section 8-f4).  Replaces the cuDNN 1x1 convolutions of the bottleneck blocks and of the head -
+ * modules/residual.py:57-63 (conv1, conv3), :79-80 (proj_conv), modules/deeplab.py:25,35 (map_convs[0], red_conv) - plus,
+ * fused into them, the inplace_abn passes around them (modules/residual.py:64-73,81-82,90-97; modules/deeplab.py:57,69).
+ *
+ *   y[M, N] = out( in(a)[M, K] . w[N, K]^T )      bf16 operands, fp32 accumulation, bf16 result
+ *
+ *   in(a)    a itself, or (in_scale != NULL) act_in((a - in_mean[k]) * in_scale[k] + in_shift[k]): the ABN apply of the
+ *            layer that PRODUCED a, applied while the tile is staged - that layer's output never exists in memory;
+ *   out_mode 0  y = acc (+ y when accumulate != 0: the identity shortcut's gradient, beta = 1)
+ *            1  y = act_out((acc - out_mean[n]) * out_scale[n] + out_shift[n] + residual[m, n]): this layer's ABN with
+ *               frozen statistics (evaluation mode / --fix_bn), the block's residual add and activation
+ *            2  y = acc and partial[t][0..2][n] = (k, sum (y - k), sum (y - k)^2) over the rows of row tile t, k = the
+ *               tile's first row: input of ucd_conv1x1_stats_finalize (training: the following ABN's statistics pass)
+ *            3  acc is the gradient w.r.t. in'(x) of a layer whose input transform was fused in the forward; with
+ *               x = residual[m, n] (its pre-norm input), z = (x - out_mean) * out_scale + out_shift:
+ *               y = dz = acc * act_out'(z) and partial[t][0..1][n] = (sum dz, sum dz * (x - out_mean) * out_invstd): input
+ *               of ucd_abn_reduce_partials (that ABN's backward reduction)
+ * Shapes: K and N multiples of 64, any M; pointers 16-byte aligned, leading dimensions (elements) multiples of 8.
+ * partial has ucd_conv1x1_row_tiles(M) row tiles.  The input gradient of the layer is the same call on (dY, W^T)
+ * (ucd_transpose_bf16 builds W^T); the weight gradient is ucd_conv1x1_wgrad. */
+typedef struct ucd_conv1x1_desc {
+  const void* a;  int lda;
+  const void* w;  int ldw;
+  void* y;        int ldy;
+  int M, N, K;
+  const float* in_mean;  const float* in_scale;  const float* in_shift;  int in_act;  float in_slope;
+  int out_mode;
+  const float* out_mean;  const float* out_scale;  const float* out_shift;  const float* out_invstd;
+  const void* residual;  int ldr;
+  int out_act;  float out_slope;
+  float* partial;
+  int accumulate;
+} ucd_conv1x1_desc;
+
+int ucd_conv1x1_row_tiles(int M);
+int ucd_conv1x1(const ucd_conv1x1_desc* desc, ucd_stream_t stream);
+
+/* out_mode 2 partials -> batch statistics of the [M, C] product -> buf = [sums(2C) | kshift(C) | mean | invstd | scale]
+ * (the layout ucd_abn_forward leaves for the backward) and the running statistics, like ucd_abn_stats_finalize; with
+ * pack != NULL it writes this rank's [mean_r | M2_r] instead (SyncBN: all-gather, then ucd_abn_sync_forward). */
+int ucd_conv1x1_stats_finalize(const float* partial, int M, int C, const float* weight, float* running_mean,
+                               float* running_var, float momentum, float eps, float* buf, float* pack, int flags,
+                               ucd_stream_t stream);
+
+/* sums[0:C] / sums[C:2C] = sum over the `tiles` rows of partial[tiles][2][C] (fixed order); sums_copy (optional) receives
+ * the same; with UCD_NORM_ABS_GAMMA in flags the second row is multiplied by sign(weight) (see ucd_abn_bwd_reduce). */
+int ucd_abn_reduce_partials(const float* partial, int tiles, int C, float* sums, float* sums_copy, const float* weight,
+                            int flags, ucd_stream_t stream);
+
+/* dw[N, K] (bf16) = dy[M, N]^T . in(a)[M, K] with the forward's input transform re-applied to a (N, K multiples of 128).
+ * workspace: ucd_conv1x1_wgrad_workspace_bytes(M, N, K) bytes of fp32 split-M partials, combined in a fixed order. */
+size_t ucd_conv1x1_wgrad_workspace_bytes(int M, int N, int K);
+int ucd_conv1x1_wgrad(const void* dy, int ld_dy, const void* a, int lda, int M, int N, int K,
+                      const float* in_mean, const float* in_scale, const float* in_shift, int in_act, float in_slope,
+                      void* dw, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* dst[cols, rows] = src[rows, cols]^T (bf16): the [K, N] weight of the input-gradient product. */
+int ucd_transpose_bf16(const void* src, int rows, int cols, void* dst, ucd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

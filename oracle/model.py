@@ -8,9 +8,9 @@ reference's ``state_dict`` key names - of
   * ``IncrementalSegmentationModule._network/forward/att_map/init_new_classifier``
                                                                   segmentation_module.py:86-136
   * the norm/activation layer: inplace_abn.{ABN, InPlaceABN, InPlaceABNSync} (third-party wheel,
-    source not under /root/reference -> parity unpinned by the reference) restated as
-    ``F.batch_norm`` (biased batch variance, eps 1e-5, momentum 0.1) followed by
-    ``leaky_relu(0.01)`` or identity.
+    source not under /root/reference -> parity unpinned by the reference) restated as batch norm
+    (biased batch variance, eps 1e-5, momentum 0.1) with the in-place variants' ``|weight| + eps`` scale
+    (``--norm_act iabn_sync``, the reference's default) followed by ``leaky_relu(0.01)`` or identity.
 Being functional (no nn.Module tree) it shares no code with the product's modules and doubles as a
 check that the product's parameter names are the reference's.  Pinned by tests/golden/model_*.npz.
 """
@@ -25,9 +25,14 @@ SLOPE = 0.01
 STRUCTURE_101 = (3, 4, 23, 3)
 
 
+ABS_GAMMA = True      # the network is built with --norm_act iabn_sync (InPlaceABNSync): gamma~ = |gamma| + eps, oracle/abn.py
+
+
 def abn(x, P, name, training, activation="leaky_relu", slope=SLOPE):
-    """BatchNorm (batch statistics + running-stat update when ``training``) then the activation."""
-    y = F.batch_norm(x, P[name + ".running_mean"], P[name + ".running_var"], P[name + ".weight"],
+    """Batch norm (batch statistics + running-stat update when ``training``) with the in-place variants' ``|weight| + eps``
+    scale, then the activation (oracle/abn.py holds the layer's full restatement)."""
+    w = P[name + ".weight"]
+    y = F.batch_norm(x, P[name + ".running_mean"], P[name + ".running_var"], w.abs() + EPS if ABS_GAMMA else w,
                      P[name + ".bias"], training, MOMENTUM, EPS)
     if activation == "leaky_relu":
         return F.leaky_relu(y, slope)

@@ -8,7 +8,8 @@ Import recipe: utils/loss.py and utils/loss_new.py load b
 torch only; models/ + modules/ import with sys.path=/root/reference (models first); the third-party
 wheels the reference needs but this image lacks (inplace_abn, torchvision, apex, wandb, cv2) are
 replaced by import-time stand-ins *in this process only* - inplace_abn.ABN becomes
-BatchNorm2d + leaky_relu, its documented semantics.
+BatchNorm2d + leaky_relu, inplace_abn.InPlaceABN / InPlaceABNSync the same with the wheel's published
+``|weight| + eps`` scale (the model-level goldens use the latter: --norm_act iabn_sync is the reference's default).
 """
 import importlib.util
 import os
@@ -58,9 +59,23 @@ class ShimABN(nn.BatchNorm2d):
         return y
 
 
+class ShimInPlaceABN(ShimABN):
+    """inplace_abn.InPlaceABN / InPlaceABNSync stand-in: the in-place kernels of the wheel normalise with
+    ``|weight| + eps`` (its published forward), everything else as ShimABN.  This is what ``--norm_act iabn_sync`` (the
+    reference's default, argparser.py:132) instantiates, so the model-level goldens are captured with it."""
+
+    def forward(self, x):
+        y = F.batch_norm(x, self.running_mean, self.running_var, self.weight.abs() + self.eps, self.bias,
+                         self.training, self.momentum, self.eps)
+        if self.activation == "leaky_relu":
+            return F.leaky_relu(y, self.activation_param)
+        return y
+
+
 def import_reference_model():
     shim = types.ModuleType("inplace_abn")
-    shim.ABN = shim.InPlaceABN = shim.InPlaceABNSync = ShimABN
+    shim.ABN = ShimABN
+    shim.InPlaceABN = shim.InPlaceABNSync = ShimInPlaceABN
     sys.modules["inplace_abn"] = shim
     tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
     tvf = types.ModuleType("torchvision.transforms.functional"); tvf.normalize = lambda *a, **k: None
@@ -166,7 +181,7 @@ def gold_v1_losses():
 # ---------------------------------------------------------------------------------------------
 def gold_model():
     models, modules, segm = import_reference_model()
-    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    norm = partial(ShimInPlaceABN, activation="leaky_relu", activation_param=0.01)
 
     # (a) one projection bottleneck + one identity bottleneck, train and eval
     blk = modules.ResidualBlock(32, (16, 16, 64), norm_act=norm, stride=2, dilation=1)
@@ -264,7 +279,7 @@ def gold_cfg0():
     images, single-process CPU fp32, through the reference's own model classes (train.py:108,116 with model_old None;
     run.py:175-186 optimiser with the step-0 learning rate 0.01)."""
     models, modules, segm = import_reference_model()
-    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    norm = partial(ShimInPlaceABN, activation="leaky_relu", activation_param=0.01)
     body = models.net_resnet101(norm_act=norm, output_stride=16)
     head = modules.DeeplabV3(body.out_channels, 256, 256, norm_act=norm, out_stride=16, pooling_size=32)
     model = segm.IncrementalSegmentationModule(body, head, 256, classes=[20])
@@ -291,7 +306,7 @@ def gold_cfg0():
 
 
 def _build_pair(models, modules, segm, classes, seed=42):
-    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    norm = partial(ShimInPlaceABN, activation="leaky_relu", activation_param=0.01)
 
     def build(cls):
         body = models.net_resnet101(norm_act=norm, output_stride=16)
@@ -373,7 +388,7 @@ def gold_aspp_eval():
     """DeeplabV3 in evaluation mode on maps LARGER than --pooling 32 (modules/deeplab.py:77-88: avg_pool2d(32, stride 1) +
     replicate pad): 33 x 33 (VOC 513^2) and 48 x 48 (Cityscapes 768^2), plus an even pooling size on an odd map."""
     models, modules, segm = import_reference_model()
-    norm = partial(ShimABN, activation="leaky_relu", activation_param=0.01)
+    norm = partial(ShimInPlaceABN, activation="leaky_relu", activation_param=0.01)
     out = {}
     for tag, hw, pool in (("33", (33, 33), 32), ("48", (48, 48), 32), ("odd", (21, 35), 8)):
         head = modules.DeeplabV3(64, 32, 16, norm_act=norm, out_stride=16, pooling_size=pool)

@@ -441,8 +441,8 @@ def test_elu_activation(dtype, with_res):
     st = synth.fill_state_dict(m.state_dict(), seed=5)
     m.load_state_dict(st)
     w, b = st["weight"].clone().requires_grad_(True), st["bias"].clone().requires_grad_(True)
-    xr = x.float().requires_grad_(True)
-    rr = r.float().requires_grad_(True)
+    xr = x.float().clone().requires_grad_(True)
+    rr = r.float().clone().requires_grad_(True)
     yr = _ref(xr, w, b, st["running_mean"].clone(), st["running_var"].clone(), True, "identity" if with_res else "elu", 0.9,
               abs_gamma=True)
     if with_res:

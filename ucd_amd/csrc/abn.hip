@@ -15,6 +15,7 @@
 // block is TX channel-groups wide (TX <= 64) and TY = 256/TX rows tall; blockIdx.x walks channel
 // groups, blockIdx.y owns a contiguous band of rows.  Per-channel parameters sit in registers.
 #include "common.h"
+#include "abn_finalize.h"
 
 namespace ucd {
 namespace {
@@ -157,48 +158,6 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
 // loop is latency-bound: a partial row is only 2C floats), fixed combination order (deterministic).
 // With FINALIZE the same block turns the two sums into the normalisation constants (one launch less per
 // layer than a separate finalize kernel).
-struct FinalizeArgs {
-  const float* kshift;
-  const float* weight;
-  float* running_mean;
-  float* running_var;
-  float* mean;
-  float* invstd;
-  float* scale;
-  float count, momentum, eps;
-  float* pack;   // PACK mode: [mean_r | M2_r] of this rank for the cross-rank combination
-  int abs_gamma; // scale = (|weight| + eps) * invstd (InPlaceABN / InPlaceABNSync) instead of weight * invstd
-};
-
-__device__ __forceinline__ void finalize_moments(int c, float mean, float m2, const FinalizeArgs& f) {
-  const float var = fmaxf(m2 / f.count, 0.f);
-  const float invstd = 1.f / sqrtf(var + f.eps);
-  if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
-  if (f.running_var) {
-    const float unbiased = f.count > 1.f ? var * (f.count / (f.count - 1.f)) : var;
-    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
-  }
-  f.mean[c] = mean;
-  f.invstd[c] = invstd;
-  f.scale[c] = (f.weight ? gamma_eff(f.weight[c], f.eps, f.abs_gamma) : 1.f) * invstd;
-}
-
-__device__ __forceinline__ void finalize_channel(int c, float s, float ss, const FinalizeArgs& f) {
-  const float inv_n = 1.f / f.count;
-  const float d = s * inv_n;                       // mean - k
-  const float mean = (f.kshift ? f.kshift[c] : 0.f) + d;
-  const float var = fmaxf((ss - s * d) * inv_n, 0.f);
-  const float invstd = 1.f / sqrtf(var + f.eps);
-  if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * mean;
-  if (f.running_var) {
-    const float unbiased = f.count > 1.f ? var * (f.count / (f.count - 1.f)) : var;
-    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
-  }
-  f.mean[c] = mean;
-  f.invstd[c] = invstd;
-  f.scale[c] = (f.weight ? gamma_eff(f.weight[c], f.eps, f.abs_gamma) : 1.f) * invstd;
-}
-
 // MODE 0: sums only (and an optional second copy), 1: + finalize, 2: + pack [mean_r | M2_r] for the SyncBN gather
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int C,
@@ -779,6 +738,15 @@ int ucd_abn_bwd_reduce(const void* x, int ld_x, const void* dy, int ld_dy, const
                        void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
   return bwd_reduce_impl("ucd_abn_bwd_reduce", x, ld_x, dy, ld_dy, y, ld_y, dtype, M, C, plane_bias, HW, mean, invstd, scale,
                          shift, weight, act, slope, sums, nullptr, workspace, workspace_bytes, stream);
+}
+
+int ucd_abn_reduce_partials(const float* partial, int tiles, int C, float* sums, float* sums_copy, const float* weight,
+                            int flags, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_reduce_partials";
+  UCD_REQUIRE(partial && sums && tiles > 0 && C > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, (hipStream_t)stream>>>(partial, tiles, C, sums, FinalizeArgs{}, sums_copy,
+                                                                            (flags & UCD_NORM_ABS_GAMMA) ? weight : nullptr);
+  return check_launch(fn);
 }
 
 // ---- SyncBN (one process per GPU): the three library calls around the two collectives of a layer ----

@@ -1,0 +1,608 @@
+// 1x1 convolutions of the UCD network as row-matrix GEMMs on the bf16 matrix cores, with the ABN work that surrounds
+// them fused in (reference call sites modules/residual.py:57-73 conv1 / conv3 / proj_conv,
+// modules/deeplab.py:24-37,56-58 map_convs[0] / red_conv).
+//
+// On channels-last activations a 1x1 convolution IS the GEMM  Y[M, N] = A[M, K] . W[N, K]^T  with M = B*H*W pixels,
+// K = C_in, N = C_out: both operands are K-contiguous, which is exactly the operand layout of
+// v_mfma_f32_32x32x16_bf16 (lane l holds 8 consecutive k of row / column l & 31).  At the network's shapes these
+// products are HBM-bound (M = 26 136 ... 399 384 rows, K and N 64 ... 2048), so what matters is that the activation
+// matrix is streamed ONCE and that the elementwise passes around the product never make their own trip to HBM:
+//
+//   input side   a' = act((a - mean_k) * scale_k + shift_k) applied while the A tile is staged into LDS: the ABN apply
+//                of the PRODUCER layer (bn2 in front of conv3) never materialises;
+//   output side  (1) evaluation / frozen statistics: y = act((acc - mean_n) * scale_n + shift_n + residual) - the ABN
+//                    apply of THIS layer, the residual add and the block activation in the epilogue (the teacher runs
+//                    its bottleneck 1x1 layers as one kernel each);
+//                (2) training: y = bf16(acc) plus per-tile shifted sums (k, sum(y - k), sum(y - k)^2) per output channel
+//                    - the statistics pass of the following ABN costs no read of y;
+//                (3) backward of a fused input transform: the product is d a' (gradient w.r.t. the transformed input),
+//                    the epilogue turns it into dz = d a' * act'(z(x)) and accumulates sum dz, sum dz * xhat per
+//                    channel - the bwd_reduce pass of that ABN costs no read either;
+//                (0) plain, optionally accumulating into y (the identity shortcut's gradient, beta = 1).
+//   The input gradient of the layer is the same kernel on (dY, W^T); the weight gradient is conv1x1_wgrad below.
+//
+// Tiling: a workgroup of 4 waves owns a 128 x BN tile (BN = 128, or 64 for the 64-channel layers), each wave a
+// 64 x BN/2 sub-tile as 2 x (BN/64) accumulators of 32 x 32; K is walked in steps of 64 through two LDS buffers, the
+// next step's global loads in flight under the current step's MFMAs (register staging: the input transform and the
+// row mask of the last tile need the values in registers anyway).  LDS rows are padded to 144 bytes, which makes the
+// ds_read_b128 fragment reads conflict-free for every 16-lane group.  Two workgroups are resident per CU.  The output
+// tile goes through LDS (fp32) so that global stores, residual loads and the per-channel reductions are row-contiguous
+// 16-byte accesses.  blockIdx -> tile: the column tiles of one row strip sit on the same XCD (ids congruent mod 8 share
+// an L2), so a strip of A is fetched from HBM once.
+#include "common.h"
+#include "abn_finalize.h"
+
+namespace ucd {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __hip_bfloat16 bf16;
+
+constexpr int kThreads = 256;
+constexpr int kBM = 128;
+constexpr int kBK = 64;
+constexpr int kPitch = kBK + 8;        // bf16 elements per LDS row (144 bytes)
+
+struct Args {
+  const bf16* A; int lda;
+  const bf16* W; int ldw;
+  bf16* Y; int ldy;
+  int M, N, K;
+  const float *in_mean, *in_scale, *in_shift; int in_act; float in_slope;
+  const float *out_mean, *out_scale, *out_shift, *out_invstd;
+  const bf16* R; int ldr;
+  int out_act; float out_slope;
+  float* partial;
+  int accumulate;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float act_rt(float z, int act, float slope) {      // identity arrives as leaky_relu(1)
+  if (act == UCD_ACT_ELU) return z > 0.f ? z : slope * expm1f(z);
+  return z > 0.f ? z : z * slope;
+}
+__device__ __forceinline__ float act_grad_rt(float z, int act, float slope) {
+  if (act == UCD_ACT_ELU) return z > 0.f ? 1.f : slope * __expf(z);
+  return z > 0.f ? 1.f : slope;
+}
+
+// OUT: 0 plain (+accumulate), 1 affine + residual + activation, 2 plain + statistics partials, 3 activation backward + sums
+template <int BN, bool PRO, int OUT>
+__global__ __launch_bounds__(kThreads, 2) void conv1x1_kernel(Args p) {
+  constexpr int WN = BN / 2;           // columns per wave
+  constexpr int TN = WN / 32;          // 32-wide accumulator tiles per wave along N
+  constexpr int NB = BN * 8 / kThreads;  // 16-byte chunks of the W tile per thread (4 or 2)
+  constexpr int CP = BN + 4;           // fp32 pitch of the output tile in LDS
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16* As = reinterpret_cast<bf16*>(smem);            // [2][kBM][kPitch]
+  bf16* Bs = As + 2 * kBM * kPitch;                    // [2][BN][kPitch]
+  float* Cs = reinterpret_cast<float*>(smem);          // [kBM][CP] after the main loop
+
+  // tile of this workgroup: column tiles of one strip on the same XCD
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
+  if (tm >= p.tiles_m) return;
+  const int m0 = tm * kBM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ks = tid & 7;              // 16-byte slot of this thread inside a 64-wide K step
+  const int srow = tid >> 3;           // first staged row (then +32 per chunk)
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  uint4 ra[4], rb[NB];
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + srow + 32 * i;
+      ra[i] = row < p.M ? *reinterpret_cast<const uint4*>(p.A + (size_t)row * p.lda + k0 + ks * 8) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      rb[i] = *reinterpret_cast<const uint4*>(p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + k0 + ks * 8);
+  };
+  auto commit = [&](int buf, int k0) {
+    bf16* as = As + buf * kBM * kPitch;
+    bf16* bs = Bs + buf * BN * kPitch;
+    if (PRO) {
+      float mu[8], sc[8], sh[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + ks * 8 + e;
+        mu[e] = p.in_mean[k]; sc[e] = p.in_scale[k]; sh[e] = p.in_shift ? p.in_shift[k] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Vec<bf16> v, o;
+        v.raw = ra[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, act_rt((v.get(e) - mu[e]) * sc[e] + sh[e], p.in_act, p.in_slope));
+        *reinterpret_cast<uint4*>(as + (srow + 32 * i) * kPitch + ks * 8) = o.raw;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(as + (srow + 32 * i) * kPitch + ks * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(bs + (srow + 32 * i) * kPitch + ks * 8) = rb[i];
+  };
+
+  const int nk = p.K / kBK;
+  fetch(0);
+  commit(0, 0);
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const int cur = kb & 1;
+    if (kb + 1 < nk) fetch((kb + 1) * kBK);
+    const bf16* as = As + cur * kBM * kPitch + (wm * 64 + (lane & 31)) * kPitch + 8 * (lane >> 5);
+    const bf16* bs = Bs + cur * BN * kPitch + (wn * WN + (lane & 31)) * kPitch + 8 * (lane >> 5);
+#pragma unroll
+    for (int kk = 0; kk < kBK / 16; ++kk) {
+      bf16x8 af[2], bfr[TN];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(as + a * 32 * kPitch + kk * 16);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(bs + b * 32 * kPitch + kk * 16);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    if (kb + 1 < nk) commit(cur ^ 1, (kb + 1) * kBK);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32, [row][col]) -> row-contiguous 16-byte global accesses -------------------
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        Cs[row * CP + wn * WN + b * 32 + (lane & 31)] = acc[a][b][r];
+      }
+  __syncthreads();
+
+  constexpr int CPR = BN / 8;                       // 8-column chunks per row
+  constexpr int RPT = kBM * CPR / kThreads;         // rows per thread (8 for BN = 128, 4 for BN = 64)
+  constexpr int RSTEP = kThreads / CPR;             // row stride between a thread's chunks
+  const int c8 = tid % CPR, r0 = tid / CPR;
+  const int ncol = n0 + c8 * 8;
+  float em[8], es[8], eb[8], ei[8];
+  if (OUT == 1 || OUT == 3) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      em[e] = p.out_mean ? p.out_mean[ncol + e] : 0.f;
+      es[e] = p.out_scale ? p.out_scale[ncol + e] : 1.f;
+      eb[e] = p.out_shift ? p.out_shift[ncol + e] : 0.f;
+      ei[e] = (OUT == 3) ? p.out_invstd[ncol + e] : 0.f;
+    }
+  }
+  float kshift[8], s1[8], s2[8];
+  if (OUT == 2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      // shift = this tile's first row (rounded like the stored value): sums of small numbers, no cancellation
+      kshift[e] = __bfloat162float(__float2bfloat16(Cs[c8 * 8 + e]));
+      s1[e] = 0.f; s2[e] = 0.f;
+    }
+  }
+  if (OUT == 3) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    const int row = r0 + RSTEP * i;
+    const int grow = m0 + row;
+    if (grow >= p.M) continue;
+    const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8);
+    const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    Vec<bf16> o;
+    bf16* yp = p.Y + (size_t)grow * p.ldy + ncol;
+    if (OUT == 0) {
+      if (p.accumulate) {
+        Vec<bf16> old;
+        old.load(yp);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += old.get(e);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+    } else if (OUT == 1) {
+      Vec<bf16> rv;
+      if (p.R) rv.load(p.R + (size_t)grow * p.ldr + ncol);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float z = (v[e] - em[e]) * es[e] + eb[e];
+        if (p.R) z += rv.get(e);
+        o.set(e, act_rt(z, p.out_act, p.out_slope));
+      }
+    } else if (OUT == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o.set(e, v[e]);
+        const float d = o.get(e) - kshift[e];
+        s1[e] += d;
+        s2[e] += d * d;
+      }
+    } else {  // OUT == 3: v = d a', x = the fused layer's pre-norm input
+      Vec<bf16> xv;
+      xv.load(p.R + (size_t)grow * p.ldr + ncol);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xc = xv.get(e) - em[e];
+        const float dz = v[e] * act_grad_rt(xc * es[e] + eb[e], p.out_act, p.out_slope);
+        o.set(e, dz);
+        const float dzr = o.get(e);          // the stored (rounded) value is what the apply pass will read
+        s1[e] += dzr;
+        s2[e] += dzr * (xc * ei[e]);
+      }
+    }
+    o.store(yp);
+  }
+  if (OUT == 2 || OUT == 3) {
+    // reduce over the RSTEP threads that share a column chunk: through LDS (the output tile is consumed)
+    __syncthreads();
+    float* red = Cs;                                  // [RSTEP][2][BN]
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[(r0 * 2 + 0) * BN + c8 * 8 + e] = s1[e];
+      red[(r0 * 2 + 1) * BN + c8 * 8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
+      float t = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < RSTEP; ++q) t += red[(q * 2 + which) * BN + col];
+      if (OUT == 2) {
+        float* dst = p.partial + (size_t)tm * 3 * p.N + n0 + col;
+        dst[(1 + which) * p.N] = t;
+      } else {
+        p.partial[(size_t)tm * 2 * p.N + which * p.N + n0 + col] = t;
+      }
+    }
+    if (OUT == 2 && r0 == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) p.partial[(size_t)tm * 3 * p.N + ncol + e] = kshift[e];
+    }
+  }
+}
+
+// Per-tile shifted sums (k_t, s1_t, s2_t) -> sums about the common shift K = k_0 -> the usual finalize.
+//   sum (y - K) = s1_t + c_t (k_t - K),   sum (y - K)^2 = s2_t + 2 (k_t - K) s1_t + c_t (k_t - K)^2   (exact identities)
+// A block owns 8 channels x 32 tile-lanes (fixed combination order: deterministic).  MODE 1 finalises, MODE 2 packs
+// (mean_r, M2_r) for the SyncBN all-gather.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void tile_stats_reduce_kernel(const float* __restrict__ partial, int tiles, int M, int C,
+                                                                    float* __restrict__ sums, float* __restrict__ kout,
+                                                                    FinalizeArgs fin) {
+  __shared__ float lds[2][32][9];
+  const int ch = threadIdx.x & 7, tl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + ch;
+  float S1 = 0.f, S2 = 0.f, K = 0.f;
+  if (c < C) {
+    K = partial[c];
+    for (int t = tl; t < tiles; t += 32) {
+      const float* pt = partial + (size_t)t * 3 * C + c;
+      const float cnt = (float)min(kBM, M - t * kBM);
+      const float dk = pt[0] - K, a = pt[C], b = pt[2 * C];
+      S1 += a + cnt * dk;
+      S2 += b + 2.f * dk * a + cnt * dk * dk;
+    }
+  }
+  lds[0][tl][ch] = S1;
+  lds[1][tl][ch] = S2;
+  __syncthreads();
+  if (tl == 0 && c < C) {
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { t1 += lds[0][i][ch]; t2 += lds[1][i][ch]; }
+    sums[c] = t1;
+    sums[C + c] = t2;
+    kout[c] = K;
+    if (MODE == 1) {
+      fin.kshift = kout;
+      finalize_channel(c, t1, t2, fin);
+    } else {
+      const float d = t1 / fin.count;
+      fin.pack[c] = K + d;
+      fin.pack[C + c] = t2 - t1 * d;
+    }
+  }
+}
+
+// ---- weight gradient: dW[N, K] = dY[M, N]^T . A'[M, K] ------------------------------------------------------------------
+// The reduction runs over the M = B*H*W rows, the slow dimension of BOTH operands, so the MFMA fragments (8 consecutive
+// reduction indices per lane) are fetched with ds_read_b64_tr_b16 from row-major [m][n] / [m][k] LDS tiles (hardware
+// transpose: a 16-lane group reads a 4-row x 16-column block, lane i receives column i).  Both operands go through the
+// same read pattern, so the permutation of the reduction index inside a step is the same on both sides.
+// Grid: (row chunks, N/128, K/128); every workgroup writes an fp32 [128 x 128] partial of its row chunk, summed by
+// wgrad_reduce_kernel (fixed order) into the bf16 weight gradient.  The input transform of the forward (PRO) is
+// re-applied to A here, so the transformed activation never exists in memory.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <bool PRO>
+__global__ __launch_bounds__(kThreads, 2) void conv1x1_wgrad_kernel(const bf16* __restrict__ dY, int ldy,
+                                                                   const bf16* __restrict__ A, int lda, int M, int N, int K,
+                                                                   const float* __restrict__ in_mean,
+                                                                   const float* __restrict__ in_scale,
+                                                                   const float* __restrict__ in_shift, int in_act,
+                                                                   float in_slope, int rows_per_chunk,
+                                                                   float* __restrict__ partial) {
+  constexpr int BT = 128;              // output tile: 128 (n) x 128 (k)
+  constexpr int BMS = 32;              // reduction rows per step
+  constexpr int P = BT + 8;            // bf16 pitch of the [m][n] / [m][k] LDS tiles (272 bytes)
+  __shared__ __attribute__((aligned(16))) bf16 Ys[2][BMS][P];
+  __shared__ __attribute__((aligned(16))) bf16 Xs[2][BMS][P];
+  const int n0 = blockIdx.y * BT, k0 = blockIdx.z * BT;
+  const int mb = blockIdx.x * rows_per_chunk, me = min(M, mb + rows_per_chunk);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;             // wave tile: 64 (n) x 64 (k)
+  const int srow = tid >> 4, scol = (tid & 15) * 8;     // staging: 16 rows x 16 chunks per pass, 2 passes
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float mu[8], sc[8], sh[8];
+  if (PRO) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu[e] = in_mean[k0 + scol + e]; sc[e] = in_scale[k0 + scol + e]; sh[e] = in_shift ? in_shift[k0 + scol + e] : 0.f;
+    }
+  }
+  uint4 ry[2], rx[2];
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+  auto fetch = [&](int m) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = m + srow + 16 * i;
+      const bool ok = row < me;
+      ry[i] = ok ? *reinterpret_cast<const uint4*>(dY + (size_t)row * ldy + n0 + scol) : zero4;
+      rx[i] = ok ? *reinterpret_cast<const uint4*>(A + (size_t)row * lda + k0 + scol) : zero4;
+    }
+  };
+  auto commit = [&](int buf, int m) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(&Ys[buf][srow + 16 * i][scol]) = ry[i];
+      if (PRO) {
+        Vec<bf16> v, o;
+        v.raw = rx[i];
+        const bool ok = m + srow + 16 * i < me;        // masked rows must stay zero after the transform
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, ok ? act_rt((v.get(e) - mu[e]) * sc[e] + sh[e], in_act, in_slope) : 0.f);
+        *reinterpret_cast<uint4*>(&Xs[buf][srow + 16 * i][scol]) = o.raw;
+      } else {
+        *reinterpret_cast<uint4*>(&Xs[buf][srow + 16 * i][scol]) = rx[i];
+      }
+    }
+  };
+  // transposed fragment: 8 reduction rows (two 4-row blocks) of column `col` for this lane
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  auto frag = [&](const bf16 (*tile)[P], int mstep, int col0) -> bf16x8 {
+    typedef __attribute__((address_space(3))) bf16x4* lptr;
+    const bf16* a0 = &tile[mstep + 4 * h + q][col0 + 16 * g + 4 * pp];
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)a0);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lptr)(a0 + 8 * P));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  };
+
+  const int nsteps = (me - mb + BMS - 1) / BMS;
+  if (nsteps > 0) {
+    fetch(mb);
+    commit(0, mb);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < nsteps) fetch(mb + (s + 1) * BMS);
+#pragma unroll
+    for (int ms = 0; ms < BMS; ms += 16) {
+      bf16x8 fy[2], fx[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fy[a] = frag(Ys[cur], ms, wn * 64 + a * 32);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fx[b] = frag(Xs[cur], ms, wk * 64 + b * 32);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) commit(cur ^ 1, mb + (s + 1) * BMS);
+    __syncthreads();
+  }
+  // partial[chunk][n][k] fp32: lanes 0..31 of a register write 32 consecutive k (128 bytes)
+  float* dst = partial + ((size_t)blockIdx.x * N + n0) * K + k0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dst[(size_t)n * K + wk * 64 + b * 32 + (lane & 31)] = acc[a][b][r];
+      }
+}
+
+__global__ __launch_bounds__(kThreads) void wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, size_t total,
+                                                               bf16* __restrict__ dW) {
+  const size_t i = ((size_t)blockIdx.x * kThreads + threadIdx.x) * 8;
+  if (i >= total) return;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < chunks; ++c) {
+    const float4 a = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i);
+    const float4 b = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i + 4);
+    s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w; s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+  }
+  Vec<bf16> o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.set(e, s[e]);
+  o.store(dW + i);
+}
+
+// [R, C] bf16 -> [C, R] (the weight of the input-gradient product): 32 x 32 tiles through LDS
+__global__ __launch_bounds__(kThreads) void transpose_bf16_kernel(const uint16_t* __restrict__ src, int R, int C,
+                                                                 uint16_t* __restrict__ dst) {
+  __shared__ uint16_t t[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  for (int i = y; i < 32; i += 8)
+    if (r0 + i < R && c0 + x < C) t[i][x] = src[(size_t)(r0 + i) * C + c0 + x];
+  __syncthreads();
+  for (int i = y; i < 32; i += 8)
+    if (c0 + i < C && r0 + x < R) dst[(size_t)(c0 + i) * R + r0 + x] = t[x][i];
+}
+
+int pick_wgrad_chunks(int M, int N, int K) {
+  // enough workgroups for two per CU, chunks of whole 32-row steps
+  const int tiles = (N / 128) * (K / 128);
+  int chunks = (512 + tiles - 1) / tiles;
+  const int max_chunks = (M + 255) / 256;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  return chunks;
+}
+
+}  // namespace
+}  // namespace ucd
+
+using namespace ucd;
+
+extern "C" {
+
+int ucd_conv1x1_row_tiles(int M) { return ceil_div(M, kBM); }
+
+int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
+  static const char* fn = "ucd_conv1x1";
+  UCD_REQUIRE(d && d->a && d->w && d->y, UCD_EINVAL, "%s: NULL operand", fn);
+  UCD_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, UCD_EINVAL, "%s: empty product", fn);
+  UCD_REQUIRE(d->K % kBK == 0 && d->N % 64 == 0, UCD_EUNSUPPORTED, "%s: K (%d) and N (%d) must be multiples of 64", fn, d->K, d->N);
+  UCD_REQUIRE(aligned16(d->a) && aligned16(d->w) && aligned16(d->y) && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldy % 8 == 0 &&
+                  d->lda >= d->K && d->ldw >= d->K && d->ldy >= d->N,
+              UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
+  UCD_REQUIRE(d->out_mode >= 0 && d->out_mode <= 3, UCD_EINVAL, "%s: unknown out_mode %d", fn, d->out_mode);
+  UCD_REQUIRE(d->out_mode != 2 && d->out_mode != 3 ? true : d->partial != nullptr, UCD_EINVAL, "%s: partial is NULL", fn);
+  UCD_REQUIRE(d->out_mode != 3 || (d->residual && d->out_invstd && d->out_mean && d->out_scale), UCD_EINVAL,
+              "%s: out_mode 3 needs x (residual), mean, scale, invstd", fn);
+  UCD_REQUIRE(!d->residual || (aligned16(d->residual) && d->ldr % 8 == 0 && d->ldr >= d->N), UCD_EALIGN,
+              "%s: residual must be 16-byte aligned", fn);
+  UCD_REQUIRE(!d->in_scale || d->in_mean, UCD_EINVAL, "%s: in_scale without in_mean", fn);
+  Args a;
+  a.A = (const bf16*)d->a; a.lda = d->lda; a.W = (const bf16*)d->w; a.ldw = d->ldw; a.Y = (bf16*)d->y; a.ldy = d->ldy;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.in_mean = d->in_mean; a.in_scale = d->in_scale; a.in_shift = d->in_shift;
+  a.in_act = d->in_act & UCD_ACT_MASK; a.in_slope = a.in_act == UCD_ACT_IDENTITY ? 1.f : d->in_slope;
+  a.out_mean = d->out_mean; a.out_scale = d->out_scale; a.out_shift = d->out_shift; a.out_invstd = d->out_invstd;
+  a.R = (const bf16*)d->residual; a.ldr = d->ldr;
+  a.out_act = d->out_act & UCD_ACT_MASK; a.out_slope = a.out_act == UCD_ACT_IDENTITY ? 1.f : d->out_slope;
+  a.partial = d->partial; a.accumulate = d->accumulate;
+  const int BN = d->N % 128 == 0 ? 128 : 64;
+  a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
+  const int grid = ceil_div(a.tiles_m, 8) * 8 * a.tiles_n;
+  const size_t lds_main = (size_t)2 * (kBM + BN) * kPitch * 2, lds_out = (size_t)kBM * (BN + 4) * 4;
+  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
+  hipStream_t s = (hipStream_t)stream;
+  const bool pro = d->in_scale != nullptr;
+#define UCD_C1_LAUNCH(BNV, PROV, OUTV)                                          \
+  {                                                                             \
+    UCD_TRY_LDS((conv1x1_kernel<BNV, PROV, OUTV>), 96 * 1024);                  \
+    conv1x1_kernel<BNV, PROV, OUTV><<<grid, kThreads, lds, s>>>(a);             \
+  }
+#define UCD_C1_OUT(BNV, PROV)                                                   \
+  switch (d->out_mode) {                                                        \
+    case 0: UCD_C1_LAUNCH(BNV, PROV, 0) break;                                  \
+    case 1: UCD_C1_LAUNCH(BNV, PROV, 1) break;                                  \
+    case 2: UCD_C1_LAUNCH(BNV, PROV, 2) break;                                  \
+    default: UCD_C1_LAUNCH(BNV, PROV, 3) break;                                 \
+  }
+  if (BN == 128) {
+    if (pro) { UCD_C1_OUT(128, true) } else { UCD_C1_OUT(128, false) }
+  } else {
+    if (pro) { UCD_C1_OUT(64, true) } else { UCD_C1_OUT(64, false) }
+  }
+#undef UCD_C1_OUT
+#undef UCD_C1_LAUNCH
+  return check_launch(fn);
+}
+
+int ucd_conv1x1_stats_finalize(const float* partial, int M, int C, const float* weight, float* running_mean,
+                               float* running_var, float momentum, float eps, float* buf, float* pack, int flags,
+                               ucd_stream_t stream) {
+  static const char* fn = "ucd_conv1x1_stats_finalize";
+  UCD_REQUIRE(partial && buf && M > 0 && C > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  const int tiles = ceil_div(M, kBM);
+  float *sums = buf, *kshift = buf + 2 * C, *mean = buf + 3 * C, *invstd = buf + 4 * C, *scale = buf + 5 * C;
+  FinalizeArgs fin{kshift, weight, running_mean, running_var, mean, invstd, scale, (float)M, momentum, eps, pack,
+                   (flags & UCD_NORM_ABS_GAMMA) != 0};
+  hipStream_t s = (hipStream_t)stream;
+  if (pack)
+    tile_stats_reduce_kernel<2><<<ceil_div(C, 8), kThreads, 0, s>>>(partial, tiles, M, C, sums, kshift, fin);
+  else
+    tile_stats_reduce_kernel<1><<<ceil_div(C, 8), kThreads, 0, s>>>(partial, tiles, M, C, sums, kshift, fin);
+  return check_launch(fn);
+}
+
+size_t ucd_conv1x1_wgrad_workspace_bytes(int M, int N, int K) {
+  if (N % 128 || K % 128) return 0;
+  return (size_t)pick_wgrad_chunks(M, N, K) * N * K * sizeof(float);
+}
+
+int ucd_conv1x1_wgrad(const void* dy, int ld_dy, const void* a, int lda, int M, int N, int K, const float* in_mean,
+                      const float* in_scale, const float* in_shift, int in_act, float in_slope, void* dw,
+                      void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_conv1x1_wgrad";
+  UCD_REQUIRE(dy && a && dw && workspace, UCD_EINVAL, "%s: NULL argument", fn);
+  UCD_REQUIRE(M > 0 && N % 128 == 0 && K % 128 == 0, UCD_EUNSUPPORTED, "%s: N (%d) and K (%d) must be multiples of 128", fn, N, K);
+  UCD_REQUIRE(aligned16(dy) && aligned16(a) && aligned16(dw) && ld_dy % 8 == 0 && lda % 8 == 0, UCD_EALIGN,
+              "%s: operands must be 16-byte aligned", fn);
+  const int chunks = pick_wgrad_chunks(M, N, K);
+  UCD_REQUIRE(workspace_bytes >= (size_t)chunks * N * K * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
+  int rows = ceil_div(M, chunks);
+  rows = ceil_div(rows, 32) * 32;
+  const int grid_x = ceil_div(M, rows);
+  hipStream_t s = (hipStream_t)stream;
+  const int act = in_act & UCD_ACT_MASK;
+  const float slope = act == UCD_ACT_IDENTITY ? 1.f : in_slope;
+  dim3 grid(grid_x, N / 128, K / 128);
+  if (in_scale)
+    conv1x1_wgrad_kernel<true><<<grid, kThreads, 0, s>>>((const bf16*)dy, ld_dy, (const bf16*)a, lda, M, N, K, in_mean, in_scale,
+                                                         in_shift, act, slope, rows, (float*)workspace);
+  else
+    conv1x1_wgrad_kernel<false><<<grid, kThreads, 0, s>>>((const bf16*)dy, ld_dy, (const bf16*)a, lda, M, N, K, nullptr, nullptr,
+                                                          nullptr, act, slope, rows, (float*)workspace);
+  int rc = check_launch(fn);
+  if (rc) return rc;
+  const size_t total = (size_t)N * K;
+  wgrad_reduce_kernel<<<(unsigned)((total / 8 + kThreads - 1) / kThreads), kThreads, 0, s>>>((const float*)workspace, grid_x, total,
+                                                                                         (bf16*)dw);
+  return check_launch(fn);
+}
+
+int ucd_transpose_bf16(const void* src, int rows, int cols, void* dst, ucd_stream_t stream) {
+  static const char* fn = "ucd_transpose_bf16";
+  UCD_REQUIRE(src && dst && rows > 0 && cols > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  transpose_bf16_kernel<<<dim3(ceil_div(cols, 32), ceil_div(rows, 32)), kThreads, 0, (hipStream_t)stream>>>(
+      (const uint16_t*)src, rows, cols, (uint16_t*)dst);
+  return check_launch(fn);
+}
+
+}  // extern "C"

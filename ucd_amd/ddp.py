@@ -272,7 +272,11 @@ class GradReducer:
                 C = m.weight.numel()
                 for p, o in ((m.bias, off), (m.weight, off + C)):
                     g = p.grad
-                    if g is not None and g.data_ptr() != self.direct_flat.data_ptr() + 4 * o:
+                    if g is None:
+                        # cleared between the forward (which handed the kernels this slice's address) and the backward
+                        # (which wrote into it): hand the view back
+                        p.grad = self.direct_flat[o:o + C]
+                    elif g.data_ptr() != self.direct_flat.data_ptr() + 4 * o:
                         self.direct_flat[o:o + C].copy_(g)
                         p.grad = self.direct_flat[o:o + C]
                 off += 2 * C

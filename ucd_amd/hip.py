@@ -36,6 +36,18 @@ class PixconMeta(C.Structure):
 
 META_BYTES = C.sizeof(PixconMeta)
 
+
+class Conv1x1Desc(C.Structure):
+    """Mirror of ``ucd_conv1x1_desc`` (include/ucd_hip.h)."""
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int), ("w", C.c_void_p), ("ldw", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("in_mean", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p), ("in_act", C.c_int),
+                ("in_slope", C.c_float), ("out_mode", C.c_int),
+                ("out_mean", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p), ("out_invstd", C.c_void_p),
+                ("residual", C.c_void_p), ("ldr", C.c_int), ("out_act", C.c_int), ("out_slope", C.c_float),
+                ("partial", C.c_void_p), ("accumulate", C.c_int)]
+
+
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 # name -> (restype, argtypes); must list every symbol of include/ucd_hip.h (checked by the CPU tests)
 SIGNATURES = {
@@ -78,6 +90,13 @@ SIGNATURES = {
     "ucd_plane_sum": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p]),
     "ucd_attmap_workspace_bytes": (_z, [_i, _i]),
     "ucd_attmap": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "ucd_conv1x1_row_tiles": (_i, [_i]),
+    "ucd_conv1x1": (_i, [C.POINTER(Conv1x1Desc), _p]),
+    "ucd_conv1x1_stats_finalize": (_i, [_p, _i, _i, _p, _p, _p, _f, _f, _p, _p, _i, _p]),
+    "ucd_abn_reduce_partials": (_i, [_p, _i, _i, _p, _p, _p, _i, _p]),
+    "ucd_conv1x1_wgrad_workspace_bytes": (_z, [_i, _i, _i]),
+    "ucd_conv1x1_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
     "ucd_pixcon_prep_workspace_bytes": (_z, [_i, _i]),
     "ucd_pixcon_prep": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "ucd_pixcon_gather": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p]),
@@ -468,3 +487,55 @@ def attmap(x, ld_x, y, ld_y, B, HW, Cc):
     ws = workspace(nbytes, x.device, "attmap")
     _check(lib.ucd_attmap(ptr(x), ld_x, ptr(y), ld_y, dtype_code(x), B, HW, Cc, ptr(ws), nbytes, stream()),
            "ucd_attmap")
+
+
+# ---------------------------------------------------------------------------------------------
+# 1x1 convolutions as fused GEMMs (csrc/conv1x1.hip)
+# ---------------------------------------------------------------------------------------------
+def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, partial=None, accumulate=False):
+    """y[M, N] = out(in(a)[M, K] . w[N, K]^T).  ``in_norm`` = (mean, scale, shift, act, slope) of the producer's ABN or None;
+    ``out_norm`` = (mean, scale, shift, invstd, act, slope) for out_mode 1 / 3.  All 2-D bf16 row matrices."""
+    lib = load()
+    d = Conv1x1Desc()
+    M, K = a.shape
+    N = w.shape[0]
+    d.a, d.lda, d.w, d.ldw, d.y, d.ldy = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0)
+    d.M, d.N, d.K = M, N, K
+    if in_norm is not None:
+        mean, scale, shift, act, slope = in_norm
+        d.in_mean, d.in_scale, d.in_shift, d.in_act, d.in_slope = ptr(mean), ptr(scale), ptr(shift), act & ACT_MASK, slope
+    d.out_mode = out_mode
+    if out_norm is not None:
+        mean, scale, shift, invstd, act, slope = out_norm
+        d.out_mean, d.out_scale, d.out_shift, d.out_invstd = ptr(mean), ptr(scale), ptr(shift), ptr(invstd)
+        d.out_act, d.out_slope = act & ACT_MASK, slope
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    d.partial = ptr(partial)
+    d.accumulate = 1 if accumulate else 0
+    work = 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)))
+    with _timed("ucd_conv1x1", work):
+        _check(lib.ucd_conv1x1(C.byref(d), stream()), "ucd_conv1x1")
+    return y
+
+
+def conv1x1_wgrad(dy, a, dw, in_norm=None):
+    """dw[N, K] = dy[M, N]^T . in(a)[M, K] (bf16)."""
+    lib = load()
+    M, N = dy.shape
+    K = a.shape[1]
+    nbytes = lib.ucd_conv1x1_wgrad_workspace_bytes(M, N, K)
+    ws = workspace(nbytes, dy.device, "wgrad")
+    mean = scale = shift = None
+    act, slope = ACT_IDENTITY, 1.0
+    if in_norm is not None:
+        mean, scale, shift, act, slope = in_norm
+    with _timed("ucd_conv1x1_wgrad", 2 * (M * N + M * K)):
+        _check(lib.ucd_conv1x1_wgrad(ptr(dy), dy.stride(0), ptr(a), a.stride(0), M, N, K, ptr(mean), ptr(scale), ptr(shift),
+                                     act & ACT_MASK, float(slope), ptr(dw), ptr(ws), nbytes, stream()), "ucd_conv1x1_wgrad")
+    return dw
+
+
+def transpose_bf16(src, dst):
+    _check(load().ucd_transpose_bf16(ptr(src), src.shape[0], src.shape[1], ptr(dst), stream()), "ucd_transpose_bf16")
+    return dst
