@@ -403,6 +403,8 @@ int ucd_image_path(const uint8_t* const* src, const int* desc, int B, int S, int
  *               x = residual[m, n] (its pre-norm input), z = (x - out_mean) * out_scale + out_shift:
  *               y = dz = acc * act_out'(z) and partial[t][0..1][n] = (sum dz, sum dz * (x - out_mean) * out_invstd): input
  *               of ucd_abn_reduce_partials (that ABN's backward reduction)
+ * act_in / act_out: UCD_ACT_LEAKY_RELU or UCD_ACT_IDENTITY (elu layers keep the separate ucd_abn_* kernels); modes 1 and 3
+ * need out_mean, out_scale and out_shift (pass zeros / ones for a missing term).
  * Shapes: K and N multiples of 64, any M; pointers 16-byte aligned, leading dimensions (elements) multiples of 8.
  * partial has ucd_conv1x1_row_tiles(M) row tiles.  The input gradient of the layer is the same call on (dY, W^T)
  * (ucd_transpose_bf16 builds W^T); the weight gradient is ucd_conv1x1_wgrad. */

@@ -1,0 +1,158 @@
+"""GPU: the fused 1x1-convolution GEMM (csrc/conv1x1.hip) through the C ABI - every mode against an fp32
+product of the same bf16 operands on the device (hipBLASLt / MIOpen are the A/B reference here, never a fallback), and the
+module paths built on it against the layer-by-layer path and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from ucd_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mk(M, K, N, seed):
+    g = torch.Generator(DEV).manual_seed(seed)
+    a = (torch.randn(M, K, device=DEV, generator=g) * 1.3 + 0.2).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * (2.0 / K) ** 0.5).bfloat16()
+    r = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    vk = [torch.randn(K, device=DEV, generator=g) * 0.3, torch.rand(K, device=DEV, generator=g) + 0.5,
+          torch.randn(K, device=DEV, generator=g) * 0.2]
+    vn = [torch.randn(N, device=DEV, generator=g) * 0.3, torch.rand(N, device=DEV, generator=g) + 0.5,
+          torch.randn(N, device=DEV, generator=g) * 0.2, torch.rand(N, device=DEV, generator=g) + 0.5]
+    return a, w, r, vk, vn
+
+
+def _rel(x, ref):
+    return ((x.float() - ref).norm() / ref.norm()).item()
+
+
+SHAPES = [(300, 64, 64), (1000, 128, 256), (2178, 256, 128), (4356, 512, 1024), (777, 64, 256), (129, 1024, 192), (128, 64, 320)]
+
+
+@pytest.mark.parametrize("M,K,N", SHAPES)
+def test_conv1x1_modes_against_fp32_product(M, K, N):
+    """bf16 rounding of the stored result is the only error: 2^-9 relative per element, ~1.7e-3 in L2."""
+    from ucd_amd import hip
+    a, w, r, (im, isc, ish), (om, osc, osh, oinv) = _mk(M, K, N, 3 + M)
+    af, wf = a.float(), w.float()
+    ref = af @ wf.t()
+    y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.conv1x1(a, w, y)
+    assert _rel(y, ref) < 3e-3
+    # exact product check with small integers (catches any fragment / swizzle / tile-mapping slip: every output is exact)
+    ai = torch.randint(-3, 4, (M, K), device=DEV).bfloat16()
+    wi = torch.randint(-2, 3, (N, K), device=DEV).bfloat16()
+    yi = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    hip.conv1x1(ai, wi, yi)
+    exact = ai.float() @ wi.float().t()
+    assert torch.equal(yi.float(), exact.bfloat16().float())
+    # accumulate (beta = 1)
+    y2 = r.clone()
+    hip.conv1x1(a, w, y2, accumulate=True)
+    assert _rel(y2, ref + r.float()) < 3e-3
+    # input transform + affine + residual + activation
+    ap = F.leaky_relu((af - im) * isc + ish, 0.01).bfloat16().float()
+    hip.conv1x1(a, w, y, in_norm=(im, isc, ish, hip.ACT_LEAKY_RELU, 0.01), out_mode=1,
+                out_norm=(om, osc, osh, None, hip.ACT_LEAKY_RELU, 0.01), residual=r)
+    ref3 = F.leaky_relu((ap @ wf.t() - om) * osc + osh + r.float(), 0.01)
+    assert _rel(y, ref3) < 3e-3
+    # identity activations, no residual
+    hip.conv1x1(a, w, y, out_mode=1, out_norm=(om, osc, osh, None, hip.ACT_IDENTITY, 0.0))
+    assert _rel(y, (ref - om) * osc + osh) < 3e-3
+    # statistics epilogue + finalize (|gamma| + eps scale, running statistics)
+    tiles = hip.load().ucd_conv1x1_row_tiles(M)
+    part = torch.full((tiles, 3, N), float("nan"), device=DEV)
+    hip.conv1x1(a, w, y, out_mode=2, partial=part)
+    buf = torch.zeros(6 * N, device=DEV)
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    gamma = torch.rand(N, device=DEV) - 0.3
+    hip._check(hip.load().ucd_conv1x1_stats_finalize(hip.ptr(part), M, N, hip.ptr(gamma), hip.ptr(rm), hip.ptr(rv), 0.1, 1e-5,
+                                                     hip.ptr(buf), None, hip.NORM_ABS_GAMMA, hip.stream()), "finalize")
+    yf = y.float()                                   # statistics are those of the STORED tensor
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    torch.testing.assert_close(buf[3 * N:4 * N], mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(buf[4 * N:5 * N], 1 / torch.sqrt(var + 1e-5), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(buf[5 * N:], (gamma.abs() + 1e-5) / torch.sqrt(var + 1e-5), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(rm, 0.1 * mean, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(rv, 0.9 + 0.1 * var * M / (M - 1), rtol=1e-4, atol=1e-6)
+    # SyncBN packing: (mean_r, M2_r)
+    pack = torch.zeros(2 * N, device=DEV)
+    hip._check(hip.load().ucd_conv1x1_stats_finalize(hip.ptr(part), M, N, None, None, None, 0.1, 1e-5, hip.ptr(buf), hip.ptr(pack),
+                                                     0, hip.stream()), "finalize")
+    torch.testing.assert_close(pack[:N], mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(pack[N:], var * M, rtol=1e-3, atol=1e-3)
+    # activation backward + sums
+    part2 = torch.full((tiles, 2, N), float("nan"), device=DEV)
+    hip.conv1x1(a, w, y, out_mode=3, out_norm=(om, osc, osh, oinv, hip.ACT_LEAKY_RELU, 0.01), residual=r, partial=part2)
+    z = (r.float() - om) * osc + osh
+    assert _rel(y, ref * torch.where(z > 0, 1.0, 0.01)) < 3e-3
+    sums = torch.zeros(2 * N, device=DEV)
+    sgn = torch.where(gamma < 0, -1.0, 1.0)
+    hip._check(hip.load().ucd_abn_reduce_partials(hip.ptr(part2), tiles, N, hip.ptr(sums), None, hip.ptr(gamma),
+                                                  hip.NORM_ABS_GAMMA, hip.stream()), "reduce")
+    dz = y.float()
+    torch.testing.assert_close(sums[:N], dz.sum(0), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(sums[N:], sgn * (dz * (r.float() - om) * oinv).sum(0), rtol=1e-3, atol=1e-2)
+    # transposed weight and (shapes it supports) the weight gradient
+    wt = torch.empty(K, N, device=DEV, dtype=torch.bfloat16)
+    hip.transpose_bf16(w, wt)
+    assert torch.equal(wt, w.t().contiguous())
+    if N % 128 == 0 and K % 128 == 0:
+        dw = torch.empty(N, K, device=DEV, dtype=torch.bfloat16)
+        hip.conv1x1_wgrad(r, a, dw)
+        assert _rel(dw, r.float().t() @ af) < 3e-3
+        hip.conv1x1_wgrad(r, a, dw, in_norm=(im, isc, ish, hip.ACT_LEAKY_RELU, 0.01))
+        assert _rel(dw, r.float().t() @ ap) < 3e-3
+
+
+def test_conv1x1_argument_errors_and_slice_output():
+    from ucd_amd import hip
+    a, w, r, _, (om, osc, osh, _) = _mk(256, 64, 64, 1)
+    y = torch.empty(256, 64, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):            # K not a multiple of 64
+        hip.conv1x1(a[:, :32].contiguous(), w[:, :32].contiguous(), y)
+    with pytest.raises(RuntimeError):            # elu is not a fused activation
+        hip.conv1x1(a, w, y, out_mode=1, out_norm=(om, osc, osh, None, hip.ACT_ELU, 1.0))
+    # output into a channel slice of a wider buffer (the ASPP concatenation), input a channel slice too
+    wide = torch.zeros(256, 256, device=DEV, dtype=torch.bfloat16)
+    awide = torch.zeros(256, 192, device=DEV, dtype=torch.bfloat16)
+    awide[:, 64:128] = a
+    hip.conv1x1(awide[:, 64:128], w, wide[:, 128:192])
+    ref = a.float() @ w.float().t()
+    assert _rel(wide[:, 128:192], ref) < 3e-3
+    assert not wide[:, :128].any() and not wide[:, 192:].any()
+
+
+@pytest.mark.parametrize("stride,dil,cin", [(1, 1, 256), (2, 1, 128), (1, 2, 256)])
+def test_residual_block_eval_fused_equals_layer_by_layer(stride, dil, cin):
+    """The frozen-statistics forward of a bottleneck (the teacher): conv1 + bn1 and conv3 + bn3 + shortcut + activation as
+    one GEMM each, against the same module with the fusion switched off (MIOpen / hipBLASLt + separate ABN kernels) and
+    against the fp32 run of the module."""
+    from functools import partial
+    from ucd_amd.abn import InPlaceABNSync
+    from ucd_amd.blocks import ResidualBlock
+    norm = partial(InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    blk = ResidualBlock(cin, (64, 64, 256), norm_act=norm, stride=stride, dilation=dil)
+    blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+    blk = blk.to(DEV).to(memory_format=torch.channels_last).eval()
+    x = synth.t_normal(9, (3, cin, 17, 19), stream=1).to(DEV).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref32 = blk(x.clone())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            xb = x.bfloat16()
+            assert blk._eval_fusable(xb)
+            fused = blk(xb.clone())
+            os.environ["UCD_FUSED_CONV1X1"] = "0"
+            try:
+                assert not blk._eval_fusable(xb)
+                plain = blk(xb.clone())
+            finally:
+                del os.environ["UCD_FUSED_CONV1X1"]
+    assert fused.dtype == torch.bfloat16 and fused.shape == ref32.shape
+    e_f, e_p = _rel(fused, ref32), _rel(plain, ref32)
+    assert e_f < 1e-2 and e_f < 1.5 * e_p + 1e-3, (e_f, e_p)       # no worse than the unfused bf16 path

@@ -114,10 +114,15 @@ def timing(M, K, N):
     t_lib = bench(lambda: hip.gemm_bf16(0, a, w, y)) if hip.gemm_available() else float("nan")
     t_plain = bench(lambda: hip.conv1x1(a, w, y))
     t_stats = bench(lambda: hip.conv1x1(a, w, y, out_mode=2, partial=part))
+    t_pro = bench(lambda: hip.conv1x1(a, w, y, in_norm=(v, v, v, 1, 0.01)))
+    t_aff = bench(lambda: hip.conv1x1(a, w, y, out_mode=1, out_norm=(v, v, v, None, 1, 0.01)))
+    t_affr = bench(lambda: hip.conv1x1(a, w, y, out_mode=1, out_norm=(v, v, v, None, 1, 0.01), residual=res))
+    part2 = torch.zeros(tiles, 2, N, device=dev)
+    t_bwd = bench(lambda: hip.conv1x1(a, w, y, out_mode=3, out_norm=(v, v, v, v, 1, 0.01), residual=res, partial=part2))
     t_full = bench(lambda: hip.conv1x1(a, w, y, in_norm=(v, v, v, 1, 0.01), out_mode=1, out_norm=(v, v, v, None, 1, 0.01), residual=res))
     byt = 2 * (M * K + M * N + N * K)
     line = (f"M={M:6d} K={K:4d} N={N:4d}  hipBLASLt {t_lib:7.1f} us | own plain {t_plain:7.1f} us ({byt / t_plain / 1e6:5.2f} TB/s, "
-            f"{2 * M * K * N / t_plain / 1e6:6.1f} TF/s)  +stats {t_stats:7.1f}  pro+affine+res {t_full:7.1f}")
+            f"{2 * M * K * N / t_plain / 1e6:6.1f} TF/s)  +stats {t_stats:6.1f} pro {t_pro:6.1f} aff {t_aff:6.1f} aff+res {t_affr:6.1f} bwdact {t_bwd:6.1f} pro+aff+res {t_full:6.1f}")
     if N % 128 == 0 and K % 128 == 0:
         dw = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
         t_w = bench(lambda: hip.conv1x1_wgrad(res, a, dw))

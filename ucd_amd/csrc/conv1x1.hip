@@ -42,7 +42,6 @@ typedef __hip_bfloat16 bf16;
 constexpr int kThreads = 256;
 constexpr int kBM = 128;
 constexpr int kBK = 64;
-constexpr int kPitch = kBK + 8;        // bf16 elements per LDS row (144 bytes)
 
 struct Args {
   const bf16* A; int lda;
@@ -56,28 +55,39 @@ struct Args {
   float* partial;
   int accumulate;
   int tiles_m, tiles_n;
+  int param_off;     // byte offset of the input-transform constants in LDS
 };
 
-__device__ __forceinline__ float act_rt(float z, int act, float slope) {      // identity arrives as leaky_relu(1)
-  if (act == UCD_ACT_ELU) return z > 0.f ? z : slope * expm1f(z);
-  return z > 0.f ? z : z * slope;
-}
-__device__ __forceinline__ float act_grad_rt(float z, int act, float slope) {
-  if (act == UCD_ACT_ELU) return z > 0.f ? 1.f : slope * __expf(z);
-  return z > 0.f ? 1.f : slope;
-}
+// The fused transforms take leaky_relu(slope) only; identity arrives as slope = 1 (elu layers keep the separate ABN
+// kernels: a per-element expm1 makes every fused loop a chain of exec-masked branches, measured 2x on the epilogue).
+__device__ __forceinline__ float act_rt(float z, float slope) { return z > 0.f ? z : z * slope; }
+__device__ __forceinline__ float act_grad_rt(float z, float slope) { return z > 0.f ? 1.f : slope; }
+
+// LDS image of a [rows][64] bf16 operand tile: 128-byte rows, the 16-byte slot s of row r stored at slot
+// s ^ ((r >> 1) & 7).  Two rows share a 256-byte bank row; with this XOR the 16 lanes of every ds_read_b128 group
+// (rows 0-3,12-15,20-27 / 4-11,16-19,28-31 of a 32-row fragment) hit 16 different slots: conflict-free without padding,
+// which is what lets the tile be filled by global_load_lds (lane-linear destination, swizzle on the SOURCE address).
+__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 // OUT: 0 plain (+accumulate), 1 affine + residual + activation, 2 plain + statistics partials, 3 activation backward + sums
+//
+// Structure: one LDS stage per workgroup and FOUR workgroups per CU (<= 128 VGPRs, 34 KB of LDS): a K step is
+// {fill the stage: global_load_lds for W (and for A when it needs no transform), registers + transform for A otherwise;
+// wait; barrier; 16 MFMAs per wave; barrier}, and the memory latency of one workgroup's fill is covered by the MFMAs of
+// the three others - 128 KB of loads in flight per CU with no software pipeline for the compiler to undo.
 template <int BN, bool PRO, int OUT>
-__global__ __launch_bounds__(kThreads, 2) void conv1x1_kernel(Args p) {
+__global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) void conv1x1_kernel(Args p) {
   constexpr int WN = BN / 2;           // columns per wave
   constexpr int TN = WN / 32;          // 32-wide accumulator tiles per wave along N
-  constexpr int NB = BN * 8 / kThreads;  // 16-byte chunks of the W tile per thread (4 or 2)
-  constexpr int CP = BN + 4;           // fp32 pitch of the output tile in LDS
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16* As = reinterpret_cast<bf16*>(smem);            // [2][kBM][kPitch]
-  bf16* Bs = As + 2 * kBM * kPitch;                    // [2][BN][kPitch]
-  float* Cs = reinterpret_cast<float*>(smem);          // [kBM][CP] after the main loop
+  constexpr int CP = BN + 4;           // fp32 pitch of the (half) output tile in LDS
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* As = smem;                            // [128][64] bf16, swizzled
+  unsigned char* Bs = smem + kBM * 128;                // [BN][64]
+  float* Cs = reinterpret_cast<float*>(smem);          // [64][CP] per epilogue half
+  float* Ps = reinterpret_cast<float*>(smem + p.param_off);   // PRO: [3][K] input-transform constants, loaded once
 
   // tile of this workgroup: column tiles of one strip on the same XCD
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -86,8 +96,6 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_kernel(Args p) {
   const int m0 = tm * kBM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ks = tid & 7;              // 16-byte slot of this thread inside a 64-wide K step
-  const int srow = tid >> 3;           // first staged row (then +32 per chunk)
 
   f32x16 acc[2][TN];
 #pragma unroll
@@ -97,83 +105,104 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_kernel(Args p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  uint4 ra[4], rb[NB];
-  const uint4 zero4 = {0u, 0u, 0u, 0u};
-  auto fetch = [&](int k0) {
+  // ---- staging addresses -------------------------------------------------------------------------------------------
+  // LDS-DMA: wave-instruction c covers tile rows 8c .. 8c+7 (1 KiB); lane l lands on (row 8c + l/8, slot l%8) and
+  // therefore FETCHES logical slot (l%8) ^ ((row >> 1) & 7) of that row.  Rows past M are clamped (never stored).
+  constexpr int CA = 4, CB = BN / 32;                  // chunks per wave: A 16 chunks, B BN/8 chunks, 4 waves
+  const bf16* ga[CA];
+  const bf16* gb[CB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = m0 + srow + 32 * i;
-      ra[i] = row < p.M ? *reinterpret_cast<const uint4*>(p.A + (size_t)row * p.lda + k0 + ks * 8) : zero4;
+  for (int i = 0; i < CA; ++i) {
+    const int row = 8 * (wave * CA + i) + (lane >> 3);
+    ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < CB; ++i) {
+    const int row = 8 * (wave * CB + i) + (lane >> 3);
+    gb[i] = p.W + (size_t)(n0 + row) * p.ldw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+  }
+  // register path of A (PRO): thread -> 16-byte slot ks of rows srow + 32 i
+  const int ks = tid & 7, srow = tid >> 3;
+  const bf16* arow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) arow[i] = p.A + (size_t)min(m0 + srow + 32 * i, p.M - 1) * p.lda + ks * 8;
+
+  if (PRO) {
+    for (int k = tid; k < p.K; k += kThreads) {
+      Ps[k] = p.in_mean[k];
+      Ps[p.K + k] = p.in_scale[k];
+      Ps[2 * p.K + k] = p.in_shift ? p.in_shift[k] : 0.f;
     }
+    // visible after the first barrier of the K loop (the A commit that reads them comes after the global loads)
+    __syncthreads();
+  }
+  const unsigned char* afrag = As + 0;                 // fragment bases resolved per read (swizzled)
+  const int fr = lane & 31, fh = lane >> 5;
+  const int nk = p.K / kBK;
+  uint4 ra[4];
+  if (PRO) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      rb[i] = *reinterpret_cast<const uint4*>(p.W + (size_t)(n0 + srow + 32 * i) * p.ldw + k0 + ks * 8);
-  };
-  auto commit = [&](int buf, int k0) {
-    bf16* as = As + buf * kBM * kPitch;
-    bf16* bs = Bs + buf * BN * kPitch;
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i]);
+  }
+  for (int kb = 0; kb < nk; ++kb) {
+    const int k0 = kb * kBK;
+    if (kb) __syncthreads();                           // the previous step's fragment reads are done
     if (PRO) {
-      float mu[8], sc[8], sh[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = k0 + ks * 8 + e;
-        mu[e] = p.in_mean[k]; sc[e] = p.in_scale[k]; sh[e] = p.in_shift ? p.in_shift[k] : 0.f;
+      for (int i = 0; i < CB; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + k0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
+      float mu[8], sc[8], sh[8];
+      {
+        const float* pk = Ps + k0 + ks * 8;
+        const float4 a0 = *reinterpret_cast<const float4*>(pk), a1 = *reinterpret_cast<const float4*>(pk + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(pk + p.K), b1 = *reinterpret_cast<const float4*>(pk + p.K + 4);
+        const float4 c0 = *reinterpret_cast<const float4*>(pk + 2 * p.K), c1 = *reinterpret_cast<const float4*>(pk + 2 * p.K + 4);
+        mu[0] = a0.x; mu[1] = a0.y; mu[2] = a0.z; mu[3] = a0.w; mu[4] = a1.x; mu[5] = a1.y; mu[6] = a1.z; mu[7] = a1.w;
+        sc[0] = b0.x; sc[1] = b0.y; sc[2] = b0.z; sc[3] = b0.w; sc[4] = b1.x; sc[5] = b1.y; sc[6] = b1.z; sc[7] = b1.w;
+        sh[0] = c0.x; sh[1] = c0.y; sh[2] = c0.z; sh[3] = c0.w; sh[4] = c1.x; sh[5] = c1.y; sh[6] = c1.z; sh[7] = c1.w;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         Vec<bf16> v, o;
         v.raw = ra[i];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, act_rt((v.get(e) - mu[e]) * sc[e] + sh[e], p.in_act, p.in_slope));
-        *reinterpret_cast<uint4*>(as + (srow + 32 * i) * kPitch + ks * 8) = o.raw;
+        for (int e = 0; e < 8; ++e) o.set(e, act_rt((v.get(e) - mu[e]) * sc[e] + sh[e], p.in_slope));
+        *reinterpret_cast<uint4*>(As + swz(srow + 32 * i, ks)) = o.raw;
       }
+      // the NEXT step's A rows go out now (always: past the end the last step is re-read and never used) and land under
+      // this step's MFMAs; the counted wait below covers the W tile only (the 4 youngest loads stay in flight)
+      const int kn = min(k0 + kBK, p.K - kBK);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i] + kn);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(as + (srow + 32 * i) * kPitch + ks * 8) = ra[i];
-    }
+      for (int i = 0; i < CA; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + k0), (lptr_t)(As + (wave * CA + i) * 1024), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(bs + (srow + 32 * i) * kPitch + ks * 8) = rb[i];
-  };
-
-  const int nk = p.K / kBK;
-  fetch(0);
-  commit(0, 0);
-  __syncthreads();
-  for (int kb = 0; kb < nk; ++kb) {
-    const int cur = kb & 1;
-    if (kb + 1 < nk) fetch((kb + 1) * kBK);
-    const bf16* as = As + cur * kBM * kPitch + (wm * 64 + (lane & 31)) * kPitch + 8 * (lane >> 5);
-    const bf16* bs = Bs + cur * BN * kPitch + (wn * WN + (lane & 31)) * kPitch + 8 * (lane >> 5);
+      for (int i = 0; i < CB; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + k0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
+    }
+    if (!PRO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of the A tile have landed
+    __builtin_amdgcn_s_barrier();                      // raw barrier: __syncthreads() would drain the A prefetch too
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       bf16x8 af[2], bfr[TN];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(as + a * 32 * kPitch + kk * 16);
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(afrag + swz(wm * 64 + a * 32 + fr, 2 * kk + fh));
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(bs + b * 32 * kPitch + kk * 16);
+      for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(Bs + swz(wn * WN + b * 32 + fr, 2 * kk + fh));
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     }
-    if (kb + 1 < nk) commit(cur ^ 1, (kb + 1) * kBK);
-    __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> LDS (fp32, [row][col]) -> row-contiguous 16-byte global accesses -------------------
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        Cs[row * CP + wn * WN + b * 32 + (lane & 31)] = acc[a][b][r];
-      }
-  __syncthreads();
-
+  // ---- epilogue: accumulators -> LDS (fp32, [row][col], 64 rows at a time) -> row-contiguous 16-byte global accesses --
   constexpr int CPR = BN / 8;                       // 8-column chunks per row
-  constexpr int RPT = kBM * CPR / kThreads;         // rows per thread (8 for BN = 128, 4 for BN = 64)
+  constexpr int RPT = 64 * CPR / kThreads;          // rows per thread and half (4 for BN = 128, 2 for BN = 64)
   constexpr int RSTEP = kThreads / CPR;             // row stride between a thread's chunks
   const int c8 = tid % CPR, r0 = tid / CPR;
   const int ncol = n0 + c8 * 8;
@@ -181,75 +210,90 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_kernel(Args p) {
   if (OUT == 1 || OUT == 3) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      em[e] = p.out_mean ? p.out_mean[ncol + e] : 0.f;
-      es[e] = p.out_scale ? p.out_scale[ncol + e] : 1.f;
-      eb[e] = p.out_shift ? p.out_shift[ncol + e] : 0.f;
+      em[e] = p.out_mean[ncol + e];
+      es[e] = p.out_scale[ncol + e];
+      eb[e] = p.out_shift[ncol + e];
       ei[e] = (OUT == 3) ? p.out_invstd[ncol + e] : 0.f;
     }
   }
   float kshift[8], s1[8], s2[8];
-  if (OUT == 2) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      // shift = this tile's first row (rounded like the stored value): sums of small numbers, no cancellation
-      kshift[e] = __bfloat162float(__float2bfloat16(Cs[c8 * 8 + e]));
-      s1[e] = 0.f; s2[e] = 0.f;
+  for (int e = 0; e < 8; ++e) { kshift[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
+  const bool has_side = (OUT == 0 && p.accumulate) || (OUT == 1 && p.R != nullptr) || OUT == 3;
+  const bf16* sp = OUT == 0 ? p.Y : p.R;
+  const int lds_ = OUT == 0 ? p.ldy : p.ldr;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    // side input (residual / old y / x) of this half's rows: requested before the LDS round trip, rows past M clamped
+    uint4 side[RPT];
+    if (has_side) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i)
+        side[i] = *reinterpret_cast<const uint4*>(sp + (size_t)min(m0 + half * 64 + r0 + RSTEP * i, p.M - 1) * lds_ + ncol);
     }
-  }
-  if (OUT == 3) {
+    __syncthreads();                                  // main loop reads / previous half's reads are done
+    if (wm == half) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-  }
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    const int row = r0 + RSTEP * i;
-    const int grow = m0 + row;
-    if (grow >= p.M) continue;
-    const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8);
-    const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8 + 4);
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    Vec<bf16> o;
-    bf16* yp = p.Y + (size_t)grow * p.ldy + ncol;
-    if (OUT == 0) {
-      if (p.accumulate) {
-        Vec<bf16> old;
-        old.load(yp);
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += old.get(e);
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o.set(e, v[e]);
-    } else if (OUT == 1) {
-      Vec<bf16> rv;
-      if (p.R) rv.load(p.R + (size_t)grow * p.ldr + ncol);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float z = (v[e] - em[e]) * es[e] + eb[e];
-        if (p.R) z += rv.get(e);
-        o.set(e, act_rt(z, p.out_act, p.out_slope));
-      }
-    } else if (OUT == 2) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        o.set(e, v[e]);
-        const float d = o.get(e) - kshift[e];
-        s1[e] += d;
-        s2[e] += d * d;
-      }
-    } else {  // OUT == 3: v = d a', x = the fused layer's pre-norm input
-      Vec<bf16> xv;
-      xv.load(p.R + (size_t)grow * p.ldr + ncol);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xc = xv.get(e) - em[e];
-        const float dz = v[e] * act_grad_rt(xc * es[e] + eb[e], p.out_act, p.out_slope);
-        o.set(e, dz);
-        const float dzr = o.get(e);          // the stored (rounded) value is what the apply pass will read
-        s1[e] += dzr;
-        s2[e] += dzr * (xc * ei[e]);
-      }
+          for (int r = 0; r < 16; ++r) {
+            const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            Cs[row * CP + wn * WN + b * 32 + (lane & 31)] = acc[a][b][r];
+          }
     }
-    o.store(yp);
+    __syncthreads();
+    if (OUT == 2 && half == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)   // shift = the tile's first row (rounded like the stored value): sums of small numbers
+        kshift[e] = __bfloat162float(__float2bfloat16(Cs[c8 * 8 + e]));
+    }
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+      const int row = r0 + RSTEP * i;
+      const int grow = m0 + half * 64 + row;
+      const bool live = grow < p.M;
+      const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8);
+      const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8 + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      Vec<bf16> o, sv;
+      sv.raw = side[i];
+      if (OUT == 0) {
+        if (p.accumulate) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += sv.get(e);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
+      } else if (OUT == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = (v[e] - em[e]) * es[e] + eb[e];
+          if (p.R) z += sv.get(e);
+          o.set(e, act_rt(z, p.out_slope));
+        }
+      } else if (OUT == 2) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o.set(e, v[e]);
+          const float d = live ? o.get(e) - kshift[e] : 0.f;
+          s1[e] += d;
+          s2[e] += d * d;
+        }
+      } else {  // OUT == 3: v = d a', x = the fused layer's pre-norm input
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xc = sv.get(e) - em[e];
+          const float dz = v[e] * act_grad_rt(xc * es[e] + eb[e], p.out_slope);
+          o.set(e, dz);
+          const float dzr = live ? o.get(e) : 0.f;   // the stored (rounded) value is what the apply pass will read
+          s1[e] += dzr;
+          s2[e] += dzr * (xc * ei[e]);
+        }
+      }
+      if (live) o.store(p.Y + (size_t)grow * p.ldy + ncol);
+    }
   }
   if (OUT == 2 || OUT == 3) {
     // reduce over the RSTEP threads that share a column chunk: through LDS (the output tile is consumed)
@@ -334,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void tile_stats_reduce_kernel(const float
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 template <bool PRO>
-__global__ __launch_bounds__(kThreads, 2) void conv1x1_wgrad_kernel(const bf16* __restrict__ dY, int ldy,
+__global__ __launch_bounds__(kThreads, 3) void conv1x1_wgrad_kernel(const bf16* __restrict__ dY, int ldy,
                                                                    const bf16* __restrict__ A, int lda, int M, int N, int K,
                                                                    const float* __restrict__ in_mean,
                                                                    const float* __restrict__ in_scale,
@@ -344,8 +388,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_wgrad_kernel(const bf16* 
   constexpr int BT = 128;              // output tile: 128 (n) x 128 (k)
   constexpr int BMS = 32;              // reduction rows per step
   constexpr int P = BT + 8;            // bf16 pitch of the [m][n] / [m][k] LDS tiles (272 bytes)
-  __shared__ __attribute__((aligned(16))) bf16 Ys[2][BMS][P];
-  __shared__ __attribute__((aligned(16))) bf16 Xs[2][BMS][P];
+  __shared__ __attribute__((aligned(16))) bf16 Ys[1][BMS][P];
+  __shared__ __attribute__((aligned(16))) bf16 Xs[1][BMS][P];
   const int n0 = blockIdx.y * BT, k0 = blockIdx.z * BT;
   const int mb = blockIdx.x * rows_per_chunk, me = min(M, mb + rows_per_chunk);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -366,28 +410,30 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_wgrad_kernel(const bf16* 
       mu[e] = in_mean[k0 + scol + e]; sc[e] = in_scale[k0 + scol + e]; sh[e] = in_shift ? in_shift[k0 + scol + e] : 0.f;
     }
   }
-  uint4 ry[2], rx[2];
-  const uint4 zero4 = {0u, 0u, 0u, 0u};
-  auto fetch = [&](int m) {
+  // rows past the chunk end are clamped (no branch around a load) and zeroed with a mask at commit time: they would
+  // otherwise enter the reduction
+  uint4 ry0[2], rx0[2];
+  auto fetch = [&](uint4 (&ry)[2], uint4 (&rx)[2], int m) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = m + srow + 16 * i;
-      const bool ok = row < me;
-      ry[i] = ok ? *reinterpret_cast<const uint4*>(dY + (size_t)row * ldy + n0 + scol) : zero4;
-      rx[i] = ok ? *reinterpret_cast<const uint4*>(A + (size_t)row * lda + k0 + scol) : zero4;
+      const int row = min(m + srow + 16 * i, me - 1);
+      ry[i] = *reinterpret_cast<const uint4*>(dY + (size_t)row * ldy + n0 + scol);
+      rx[i] = *reinterpret_cast<const uint4*>(A + (size_t)row * lda + k0 + scol);
     }
   };
-  auto commit = [&](int buf, int m) {
+  auto commit = [&](const uint4 (&ry)[2], const uint4 (&rx)[2], int buf, int m) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(&Ys[buf][srow + 16 * i][scol]) = ry[i];
+      const unsigned keep = (m + srow + 16 * i < me) ? 0xFFFFFFFFu : 0u;
+      uint4 y4 = ry[i];
+      y4.x &= keep; y4.y &= keep; y4.z &= keep; y4.w &= keep;
+      *reinterpret_cast<uint4*>(&Ys[buf][srow + 16 * i][scol]) = y4;
       if (PRO) {
         Vec<bf16> v, o;
         v.raw = rx[i];
-        const bool ok = m + srow + 16 * i < me;        // masked rows must stay zero after the transform
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, ok ? act_rt((v.get(e) - mu[e]) * sc[e] + sh[e], in_act, in_slope) : 0.f);
-        *reinterpret_cast<uint4*>(&Xs[buf][srow + 16 * i][scol]) = o.raw;
+        for (int e = 0; e < 8; ++e) o.set(e, act_rt((v.get(e) - mu[e]) * sc[e] + sh[e], in_slope));
+        *reinterpret_cast<uint4*>(&Xs[buf][srow + 16 * i][scol]) = o.raw;     // dY is zero on the masked rows
       } else {
         *reinterpret_cast<uint4*>(&Xs[buf][srow + 16 * i][scol]) = rx[i];
       }
@@ -406,15 +452,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_wgrad_kernel(const bf16* 
     return r;
   };
 
-  const int nsteps = (me - mb + BMS - 1) / BMS;
-  if (nsteps > 0) {
-    fetch(mb);
-    commit(0, mb);
-  }
-  __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < nsteps) fetch(mb + (s + 1) * BMS);
+  auto compute = [&](int cur) {
 #pragma unroll
     for (int ms = 0; ms < BMS; ms += 16) {
       bf16x8 fy[2], fx[2];
@@ -427,8 +465,15 @@ __global__ __launch_bounds__(kThreads, 2) void conv1x1_wgrad_kernel(const bf16* 
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a], fx[b], acc[a][b], 0, 0, 0);
     }
-    if (s + 1 < nsteps) commit(cur ^ 1, mb + (s + 1) * BMS);
+  };
+  const int nsteps = (me - mb + BMS - 1) / BMS;
+  // one LDS stage, three to four workgroups per CU: the loads of one workgroup land under the MFMAs of the others
+  for (int s = 0; s < nsteps; ++s) {
+    fetch(ry0, rx0, mb + s * BMS);
+    if (s) __syncthreads();                      // the previous step's fragment reads are done
+    commit(ry0, rx0, 0, mb + s * BMS);
     __syncthreads();
+    compute(0);
   }
   // partial[chunk][n][k] fp32: lanes 0..31 of a register write 32 consecutive k (128 bytes)
   float* dst = partial + ((size_t)blockIdx.x * N + n0) * K + k0;
@@ -501,8 +546,11 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
   UCD_REQUIRE(d->out_mode >= 0 && d->out_mode <= 3, UCD_EINVAL, "%s: unknown out_mode %d", fn, d->out_mode);
   UCD_REQUIRE(d->out_mode != 2 && d->out_mode != 3 ? true : d->partial != nullptr, UCD_EINVAL, "%s: partial is NULL", fn);
-  UCD_REQUIRE(d->out_mode != 3 || (d->residual && d->out_invstd && d->out_mean && d->out_scale), UCD_EINVAL,
-              "%s: out_mode 3 needs x (residual), mean, scale, invstd", fn);
+  UCD_REQUIRE((d->out_mode != 1 && d->out_mode != 3) || (d->out_mean && d->out_scale && d->out_shift), UCD_EINVAL,
+              "%s: out_mode %d needs out_mean, out_scale and out_shift", fn, d->out_mode);
+  UCD_REQUIRE(d->out_mode != 3 || (d->residual && d->out_invstd), UCD_EINVAL, "%s: out_mode 3 needs x (residual) and invstd", fn);
+  UCD_REQUIRE((d->in_act & UCD_ACT_MASK) != UCD_ACT_ELU && (d->out_act & UCD_ACT_MASK) != UCD_ACT_ELU, UCD_EUNSUPPORTED,
+              "%s: the fused transforms take leaky_relu / identity (elu layers use the separate ABN kernels)", fn);
   UCD_REQUIRE(!d->residual || (aligned16(d->residual) && d->ldr % 8 == 0 && d->ldr >= d->N), UCD_EALIGN,
               "%s: residual must be 16-byte aligned", fn);
   UCD_REQUIRE(!d->in_scale || d->in_mean, UCD_EINVAL, "%s: in_scale without in_mean", fn);
@@ -518,13 +566,17 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   const int BN = d->N % 128 == 0 ? 128 : 64;
   a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
   const int grid = ceil_div(a.tiles_m, 8) * 8 * a.tiles_n;
-  const size_t lds_main = (size_t)2 * (kBM + BN) * kPitch * 2, lds_out = (size_t)kBM * (BN + 4) * 4;
-  const size_t lds = lds_main > lds_out ? lds_main : lds_out;
-  hipStream_t s = (hipStream_t)stream;
+  const size_t lds_main = (size_t)(kBM + BN) * 128, lds_out = (size_t)64 * (BN + 4) * 4;
+  size_t lds = lds_main > lds_out ? lds_main : lds_out;
+  const size_t lds_red = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;       // statistics reduction scratch
+  if (lds_red > lds) lds = lds_red;
   const bool pro = d->in_scale != nullptr;
+  a.param_off = (int)align_up(lds, 16);
+  if (pro) lds = a.param_off + (size_t)3 * d->K * sizeof(float);
+  UCD_REQUIRE(lds <= 64 * 1024, UCD_EUNSUPPORTED, "%s: K = %d is too wide for the fused input transform", fn, d->K);
+  hipStream_t s = (hipStream_t)stream;
 #define UCD_C1_LAUNCH(BNV, PROV, OUTV)                                          \
   {                                                                             \
-    UCD_TRY_LDS((conv1x1_kernel<BNV, PROV, OUTV>), 96 * 1024);                  \
     conv1x1_kernel<BNV, PROV, OUTV><<<grid, kThreads, lds, s>>>(a);             \
   }
 #define UCD_C1_OUT(BNV, PROV)                                                   \
@@ -581,6 +633,7 @@ int ucd_conv1x1_wgrad(const void* dy, int ld_dy, const void* a, int lda, int M, 
   const int grid_x = ceil_div(M, rows);
   hipStream_t s = (hipStream_t)stream;
   const int act = in_act & UCD_ACT_MASK;
+  UCD_REQUIRE(act != UCD_ACT_ELU, UCD_EUNSUPPORTED, "%s: the fused input transform takes leaky_relu / identity", fn);
   const float slope = act == UCD_ACT_IDENTITY ? 1.f : in_slope;
   dim3 grid(grid_x, N / 128, K / 128);
   if (in_scale)
