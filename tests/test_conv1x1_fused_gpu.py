@@ -156,3 +156,45 @@ def test_residual_block_eval_fused_equals_layer_by_layer(stride, dil, cin):
     assert fused.dtype == torch.bfloat16 and fused.shape == ref32.shape
     e_f, e_p = _rel(fused, ref32), _rel(plain, ref32)
     assert e_f < 1e-2 and e_f < 1.5 * e_p + 1e-3, (e_f, e_p)       # no worse than the unfused bf16 path
+
+
+@pytest.mark.parametrize("cin,chans,with_ddp", [(1024, (256, 256, 1024), False), (512, (256, 256, 1024), False),
+                                                (1024, (256, 256, 1024), True)])
+def test_residual_block_training_fused_node_equals_module_path(cin, chans, with_ddp):
+    """Training forward + backward of a wide bottleneck with every 1x1 convolution + ABN as one node (statistics in the GEMM
+    epilogue, C++ autograd) against the same block run module by module (library GEMM + separate statistics kernels):
+    same outputs, input / parameter gradients and running statistics up to bf16 rounding of the intermediate maps."""
+    from functools import partial
+    from ucd_amd import abn
+    from ucd_amd.blocks import ResidualBlock
+    from ucd_amd.ddp import DistributedDataParallel
+    assert abn._abn_node() is not None and hasattr(abn._abn_node(), "conv_abn_train")
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    x0 = synth.t_normal(9, (4, cin, 15, 13), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(10, (4, chans[2], 15, 13), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        blk = ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=1)
+        blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+        blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
+        mod = DistributedDataParallel(blk, bf16_weights=True) if with_ddp else blk
+        if not fused:
+            os.environ["UCD_FUSED_CONV1X1"] = "0"
+        try:
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = mod(x * 1.0)
+            y.backward(dy)
+            if with_ddp:
+                mod.finish_grad_sync()
+        finally:
+            os.environ.pop("UCD_FUSED_CONV1X1", None)
+        grads = {n: p.grad.float().clone() for n, p in blk.named_parameters()}
+        outs.append((y.detach().float(), x.grad.float(), grads, blk.convs.bn3.running_var.clone(), blk.convs.bn1.running_mean.clone()))
+    (yf, gxf, gf, rvf, rmf), (yp, gxp, gp, rvp, rmp) = outs
+    assert _rel(yf, yp) < 1e-2
+    assert _rel(gxf, gxp) < 3e-2
+    torch.testing.assert_close(rvf, rvp, rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(rmf, rmp, rtol=1e-3, atol=1e-4)
+    for n in gf:
+        assert _rel(gf[n], gp[n]) < 5e-2, n

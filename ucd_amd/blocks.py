@@ -253,6 +253,49 @@ def _is_fused_abn(m) -> bool:
     return getattr(m, "ucd_fused_abn", False)
 
 
+def _own_gemm_with_stats(K, N):
+    """Forward kernel choice of a conv + training-ABN pair, from tools/conv1x1_probe.py on MI355X (M = 26 136): the fused GEMM
+    with the statistics epilogue costs its plain time + 1-4 us; the tuned library GEMM needs a statistics pass over its
+    output on top (11-30 us).  The library only stays ahead where the product is large on both sides (2048 -> 512: 44 + 16
+    against 72 us; 1024 -> 2048: 101 + 30 against 134)."""
+    return not (K * N >= (1 << 20) and K >= 1024)
+
+
+def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_param=None, with_skip=False):
+    """``bn(conv(x) [, residual])`` of a wide 1x1 convolution and a training-mode HIP ABN as ONE autograd node
+    (csrc/abn_node.cpp::ConvABNTrainNode): the ABN's batch statistics come out of the GEMM's epilogue.  Returns None when the
+    pair is not eligible (the caller then runs the modules one after the other), else ``y`` or ``(y, shortcut alias of x)``."""
+    if os.environ.get("UCD_FUSED_CONV1X1", "1") == "0":
+        return None
+    if not (isinstance(conv, Conv1x1) and conv.as_gemm and conv.bias is None and conv.weight.requires_grad and _is_fused_abn(bn)
+            and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
+            and x.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
+        return None
+    node = _gemm_node()
+    if node is None or not hasattr(node, "conv_abn_train") or not node.dense_channels_last(x):
+        return None
+    if residual is not None and not (residual.dtype == x.dtype and node.dense_channels_last(residual)):
+        return None
+    from . import abn as _abn
+    from . import hip
+    group = bn._group()
+    world = _abn._group_size(group)
+    sync = group is not False and (world > 1 or (_abn._FORCE_SYNC and torch.distributed.is_initialized()))
+    comm = _abn.direct_comm(group) if sync else None
+    if sync and comm is None:
+        return None
+    w16 = conv.working_weight()
+    if w16 is None:
+        w16 = conv.weight.to(x.dtype)
+    act = _abn._act_code(bn.activation if activation is None else activation) | (hip.NORM_ABS_GAMMA if bn._abs_gamma else 0)
+    slope = bn.activation_param if activation_param is None else activation_param
+    bn.__dict__.pop("_eval_cache", None)
+    out = node.conv_abn_train(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
+                              slope, comm.handle if comm is not None else 0, world, _hip_stream(), bn._direct_grad_ptr(),
+                              bool(with_skip), _own_gemm_with_stats(conv.in_channels, conv.out_channels))
+    return (out[0], out[1]) if with_skip else out[0]
+
+
 def _apply_act(x, activation, param):
     if activation == "leaky_relu":
         return F.leaky_relu(x, negative_slope=param, inplace=True)
@@ -376,11 +419,26 @@ class ResidualBlock(nn.Module):
         if not self.training and not torch.is_grad_enabled() and self._eval_fusable(x):
             return self._forward_eval_fused(x)
         if hasattr(self, "proj_conv"):
-            residual = self.proj_bn(self.proj_conv(x))
+            residual = _conv_abn_train(self.proj_conv, self.proj_bn, x) if self.training else None
+            if residual is None:
+                residual = self.proj_bn(self.proj_conv(x))
         else:
             residual = x
         act, slope = self.convs.bn1.activation, self.convs.bn1.activation_param
         last = getattr(self.convs, self._last_bn)
+        if (self.training and _is_fused_abn(last) and last.activation == "identity" and self._last_bn == "bn3"
+                and "dropout" not in self.convs._modules and x.is_cuda and x.dtype == torch.bfloat16):
+            # wide bottleneck in training: every 1x1 convolution and its ABN are one node (statistics in the GEMM epilogue)
+            c = self.convs
+            skip = residual is x and x.requires_grad
+            first = _conv_abn_train(c.conv1, c.bn1, x, with_skip=skip)
+            if first is not None:
+                h1, res = first if skip else (first, residual)
+                h2 = c.bn2(c.conv2(h1))
+                out = _conv_abn_train(c.conv3, c.bn3, h2, residual=res, activation=act, activation_param=slope)
+                if out is None:
+                    out = c.bn3(c.conv3(h2), residual=res, activation=act, activation_param=slope)
+                return out
         if _is_fused_abn(last) and last.activation == "identity" and act in ("leaky_relu", "identity"):
             # fused epilogue: act(bn(conv_out) + residual) in one HBM pass
             h, first = x, None

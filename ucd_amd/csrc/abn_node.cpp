@@ -11,6 +11,7 @@
 // The reference reaches the same work through inplace_abn's autograd Functions (segmentation_module.py:15-20).
 #include <torch/extension.h>
 
+#include <cstring>
 #include <map>
 #include <mutex>
 
@@ -324,6 +325,197 @@ class StrideOneConvNode : public torch::autograd::Function<StrideOneConvNode> {
 
 at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d) { return StrideOneConvNode::apply(x, w, d); }
 
+// ---- 1x1 convolution + training-mode ABN as ONE node ------------------------------------------------------
+// forward   z = x . w^T with the statistics of z accumulated in the GEMM's epilogue (ucd_conv1x1 out_mode 2: no statistics
+//           pass over z) -> finalize (or the SyncBN exchange) -> y = act(norm(z) [+ residual])
+//           (for the shapes where the tuned library GEMM is faster than the fused kernel by more than the statistics pass
+//           costs, `fused` is 0: library GEMM + ucd_abn_forward - the same arithmetic)
+// backward  ABN backward (d z, d residual, parameter gradients) -> d x = d z . w (+ the shortcut's gradient, beta = 1)
+//           -> d w = d z^T . x as batched split-M products
+// with_skip: x is also the block's identity shortcut; the node returns (y, alias of x) so that x has one consumer and the
+// shortcut's gradient is folded into the input-gradient product (Gemm1x1SkipNode's trick).
+// Reference: conv1 -> bn1, conv3 -> bn3 (+ shortcut, activation), proj_conv -> proj_bn of modules/residual.py:57-97.
+class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
+ public:
+  static variable_list forward(AutogradContext* ctx, at::Tensor x, at::Tensor w4, at::Tensor weight, at::Tensor bias,
+                               c10::optional<at::Tensor> residual_, at::Tensor running_mean, at::Tensor running_var,
+                               double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
+                               int64_t stream, int64_t param_grad, bool with_skip, bool fused) {
+    TORCH_CHECK(dense_channels_last(x) && x.scalar_type() == at::kBFloat16, "ucd conv+abn node: x must be dense channels-last bf16");
+    TORCH_CHECK(w4.dim() == 4 && w4.scalar_type() == at::kBFloat16 && w4.size(1) == x.size(1) && w4.size(2) == 1 &&
+                    w4.size(3) == 1 && w4.is_contiguous(),
+                "ucd conv+abn node: weight [Co, Ci, 1, 1] bf16 expected");
+    at::Tensor residual = residual_.has_value() ? *residual_ : at::Tensor();
+    const bool has_res = residual.defined();
+    const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0);
+    const int64_t HW = H * W, M = B * HW;
+    if (has_res)
+      TORCH_CHECK(dense_channels_last(residual) && residual.size(1) == N && residual.size(0) == B && residual.size(2) == H &&
+                      residual.size(3) == W && residual.scalar_type() == at::kBFloat16,
+                  "ucd conv+abn node: residual must match the output");
+    const bool sync = comm != 0;
+    auto opts = x.options().memory_format(at::MemoryFormat::ChannelsLast);
+    at::Tensor z = at::empty({B, N, H, W}, opts), y = at::empty({B, N, H, W}, opts);
+    at::Tensor buf = at::empty({(sync ? 8 + 2 * world : 6) * N}, x.options().dtype(at::kFloat));
+    float* b = buf.data_ptr<float>();
+    const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)N);
+    const void* resp = has_res ? residual.data_ptr() : nullptr;
+    if (fused) {
+      const int tiles = ucd_conv1x1_row_tiles((int)M);
+      size_t need = (size_t)tiles * 3 * N * sizeof(float);
+      float* partial = (float*)workspace(x, need > ws_bytes ? need : ws_bytes, stream);
+      ucd_conv1x1_desc d;
+      memset(&d, 0, sizeof(d));
+      d.a = x.data_ptr(); d.lda = (int)K; d.w = w4.data_ptr(); d.ldw = (int)K; d.y = z.data_ptr(); d.ldy = (int)N;
+      d.M = (int)M; d.N = (int)N; d.K = (int)K; d.out_mode = 2; d.partial = partial;
+      check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
+      if (!sync) {
+        check(ucd_conv1x1_stats_finalize(partial, (int)M, (int)N, fptr(weight), running_mean.data_ptr<float>(),
+                                         running_var.data_ptr<float>(), (float)momentum, (float)eps, b, nullptr, (int)act,
+                                         (ucd_stream_t)stream),
+              "ucd_conv1x1_stats_finalize");
+        check(ucd_abn_apply(z.data_ptr(), (int)N, y.data_ptr(), (int)N, resp, has_res ? (int)N : 0, UCD_BF16, (int)M, (int)N, nullptr,
+                            (int)HW, b + 3 * N, b + 5 * N, fptr(bias), (int)act, (float)slope, (ucd_stream_t)stream),
+              "ucd_abn_apply");
+      } else {
+        float *pack = b + 6 * N, *gathered = b + 8 * N;
+        check(ucd_conv1x1_stats_finalize(partial, (int)M, (int)N, nullptr, nullptr, nullptr, (float)momentum, (float)eps, b, pack, 0,
+                                         (ucd_stream_t)stream),
+              "ucd_conv1x1_stats_finalize");
+        check(ucd_comm_all_gather((ucd_comm_t)comm, pack, gathered, (size_t)2 * N, (ucd_stream_t)stream), "ucd_comm_all_gather");
+        check(ucd_abn_sync_forward(z.data_ptr(), (int)N, y.data_ptr(), (int)N, resp, has_res ? (int)N : 0, UCD_BF16, (int)M, (int)N,
+                                   nullptr, (int)HW, gathered, (int)world, fptr(weight), fptr(bias), running_mean.data_ptr<float>(),
+                                   running_var.data_ptr<float>(), (float)momentum, (float)eps, b, (int)act, (float)slope,
+                                   (ucd_stream_t)stream),
+              "ucd_abn_sync_forward");
+      }
+    } else {
+      const size_t wsb = ucd_gemm_workspace_bytes();
+      check(ucd_gemm_bf16(0, (int)M, (int)N, (int)K, x.data_ptr(), (int)K, w4.data_ptr(), (int)K, z.data_ptr(), (int)N,
+                          workspace(x, wsb, stream, 1), wsb, 1, (ucd_stream_t)stream),
+            "ucd_gemm_bf16");
+      void* ws = workspace(x, ws_bytes, stream);
+      if (sync)
+        check(ucd_abn_sync_forward_comm((ucd_comm_t)comm, (int)world, z.data_ptr(), (int)N, y.data_ptr(), (int)N, resp,
+                                        has_res ? (int)N : 0, UCD_BF16, (int)M, (int)N, nullptr, (int)HW, fptr(weight), fptr(bias),
+                                        running_mean.data_ptr<float>(), running_var.data_ptr<float>(), (float)momentum, (float)eps, b,
+                                        (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+              "ucd_abn_sync_forward_comm");
+      else
+        check(ucd_abn_forward(z.data_ptr(), (int)N, y.data_ptr(), (int)N, resp, has_res ? (int)N : 0, UCD_BF16, (int)M, (int)N, nullptr,
+                              (int)HW, fptr(weight), fptr(bias), running_mean.data_ptr<float>(), running_var.data_ptr<float>(),
+                              (float)momentum, (float)eps, 1, b, nullptr, (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+              "ucd_abn_forward");
+    }
+    const bool needs_y = has_res && (act & UCD_ACT_MASK) != UCD_ACT_IDENTITY;
+    ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf});
+    ctx->saved_data["act"] = act;
+    ctx->saved_data["slope"] = slope;
+    ctx->saved_data["comm"] = comm;
+    ctx->saved_data["world"] = world;
+    ctx->saved_data["stream"] = stream;
+    ctx->saved_data["has_res"] = has_res;
+    ctx->saved_data["param_grad"] = param_grad;
+    ctx->saved_data["with_skip"] = with_skip;
+    if (with_skip) return {y, x};
+    return {y};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    auto saved = ctx->get_saved_variables();
+    at::Tensor x = saved[0], w4 = saved[1], z = saved[2], y = saved[3], weight = saved[4], bias = saved[5], buf = saved[6];
+    const int64_t act = ctx->saved_data["act"].toInt(), comm = ctx->saved_data["comm"].toInt();
+    const int64_t world = ctx->saved_data["world"].toInt(), stream = ctx->saved_data["stream"].toInt();
+    const double slope = ctx->saved_data["slope"].toDouble();
+    const bool has_res = ctx->saved_data["has_res"].toBool(), with_skip = ctx->saved_data["with_skip"].toBool();
+    float* param_grad = reinterpret_cast<float*>(ctx->saved_data["param_grad"].toInt());
+    const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0), HW = H * W, M = B * HW;
+    at::Tensor dy = grads[0];
+    at::Tensor dskip = with_skip ? grads[1] : at::Tensor();
+    at::Tensor none;
+    at::Tensor dx, dw, dweight, dbias, dres;
+    at::Tensor dz;   // gradient w.r.t. the convolution output z
+    if (dy.defined()) {
+      if (dy.scalar_type() != at::kBFloat16) dy = dy.to(at::kBFloat16);
+      if (!dense_channels_last(dy)) dy = dy.contiguous(at::MemoryFormat::ChannelsLast);
+      dz = at::empty_like(z);
+      if (has_res) dres = at::empty_like(z);
+      const bool sync = comm != 0;
+      at::Tensor sums;
+      if (sync || !param_grad) sums = at::empty({(sync && !param_grad ? 4 : 2) * N}, x.options().dtype(at::kFloat));
+      float* b = buf.data_ptr<float>();
+      const float *mean = b + 3 * N, *invstd = b + 4 * N, *scale = b + 5 * N;
+      const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)N);
+      void* ws = workspace(x, ws_bytes, stream);
+      const void* yp = y.defined() ? y.data_ptr() : nullptr;
+      if (sync) {
+        check(ucd_abn_sync_backward_comm((ucd_comm_t)comm, (int)world, z.data_ptr(), (int)N, dy.data_ptr(), (int)N, yp, yp ? (int)N : 0,
+                                         dz.data_ptr(), (int)N, has_res ? dres.data_ptr() : nullptr, has_res ? (int)N : 0, UCD_BF16,
+                                         (int)M, (int)N, nullptr, (int)HW, mean, invstd, scale, fptr(bias), fptr(weight),
+                                         sums.data_ptr<float>(), param_grad ? param_grad : sums.data_ptr<float>() + 2 * N, (int)act,
+                                         (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+              "ucd_abn_sync_backward_comm");
+        if (!param_grad) { dbias = sums.narrow(0, 2 * N, N); dweight = sums.narrow(0, 3 * N, N); }
+      } else {
+        check(ucd_abn_backward(z.data_ptr(), (int)N, dy.data_ptr(), (int)N, yp, yp ? (int)N : 0, dz.data_ptr(), (int)N,
+                               has_res ? dres.data_ptr() : nullptr, has_res ? (int)N : 0, UCD_BF16, (int)M, (int)N, nullptr, (int)HW,
+                               mean, invstd, scale, fptr(bias), fptr(weight), param_grad ? param_grad : sums.data_ptr<float>(),
+                               (float)M, 1, 1, (int)act, (float)slope, ws, ws_bytes, (ucd_stream_t)stream),
+              "ucd_abn_backward");
+        if (!param_grad) { dbias = sums.narrow(0, 0, N); dweight = sums.narrow(0, N, N); }
+      }
+    }
+    const size_t wsb = ucd_gemm_workspace_bytes();
+    void* gws = workspace(x, wsb, stream, 1);
+    if (ctx->needs_input_grad(0)) {
+      const bool fold = dskip.defined() && dz.defined() && dskip.scalar_type() == at::kBFloat16;
+      if (fold) {
+        if (!dense_channels_last(dskip)) dskip = dskip.contiguous(at::MemoryFormat::ChannelsLast);
+        if (!ucd_gemm_has_plan(1, (int)M, (int)K, (int)N, (int)N, (int)K, (int)K)) {   // tune once, into scratch
+          at::Tensor scratch = at::empty_like(x);
+          check(ucd_gemm_bf16(1, (int)M, (int)K, (int)N, dz.data_ptr(), (int)N, w4.data_ptr(), (int)K, scratch.data_ptr(), (int)K,
+                              gws, wsb, 1, (ucd_stream_t)stream),
+                "ucd_gemm_bf16");
+        }
+        check(ucd_gemm_bf16_acc(1, (int)M, (int)K, (int)N, dz.data_ptr(), (int)N, w4.data_ptr(), (int)K, dskip.data_ptr(), (int)K, gws,
+                                wsb, (ucd_stream_t)stream),
+              "ucd_gemm_bf16_acc");
+        dx = dskip;
+      } else if (dz.defined()) {
+        dx = at::empty_like(x);
+        check(ucd_gemm_bf16(1, (int)M, (int)K, (int)N, dz.data_ptr(), (int)N, w4.data_ptr(), (int)K, dx.data_ptr(), (int)K, gws, wsb, 1,
+                            (ucd_stream_t)stream),
+              "ucd_gemm_bf16");
+        if (dskip.defined()) dx = dx + dskip;
+      } else {
+        dx = dskip;
+      }
+    }
+    if (ctx->needs_input_grad(1) && dz.defined()) {
+      at::Tensor dz2 = dz.permute({0, 2, 3, 1}).reshape({M, N}), x2 = x.permute({0, 2, 3, 1}).reshape({M, K});
+      const int64_t S = wgrad_split(M);
+      if (S > 1) {
+        dw = at::bmm(dz2.view({S, M / S, N}).transpose(1, 2), x2.view({S, M / S, K})).sum(0);
+      } else {
+        dw = at::empty({N, K}, x.options().memory_format(c10::nullopt));
+        check(ucd_gemm_bf16(2, (int)N, (int)K, (int)M, dz2.data_ptr(), (int)N, x2.data_ptr(), (int)K, dw.data_ptr(), (int)K, gws, wsb, 1,
+                            (ucd_stream_t)stream),
+              "ucd_gemm_bf16");
+      }
+      dw = dw.as_strided(w4.sizes(), w4.strides());
+    }
+    return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none};
+  }
+};
+
+std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor weight, at::Tensor bias,
+                                       c10::optional<at::Tensor> residual, at::Tensor running_mean, at::Tensor running_var,
+                                       double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
+                                       int64_t stream, int64_t param_grad, bool with_skip, bool fused) {
+  return ConvABNTrainNode::apply(x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world,
+                                 stream, param_grad, with_skip, fused);
+}
+
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,
                      at::Tensor running_mean, at::Tensor running_var, double momentum, double eps, int64_t act, double slope,
                      int64_t comm, int64_t world, int64_t stream, int64_t param_grad) {
@@ -340,4 +532,5 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("conv_stride1", &conv_stride1, "stride-1 conv (3x3 pad=dilation, or 1x1) with the input gradient on the forward solver");
   m.def("gemm1x1_skip", &gemm1x1_skip, "(rows x w^T, rows): first 1x1 conv of an identity-shortcut block with the shortcut");
   m.def("gemm1x1", &gemm1x1, "rows[M, Ci] x w[Co, Ci, 1, 1]^T with autograd in C++ (call ucd_gemm_load first)");
+  m.def("conv_abn_train", &conv_abn_train, "1x1 convolution + training-mode ABN (+ residual) as one node, statistics in the GEMM epilogue");
 }
