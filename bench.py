@@ -140,7 +140,21 @@ def cpu_baseline(args, classes):
         (r["loss"] + r["lkd"]).backward()
         opt.step()
         dt = time.time() - t0
-    return {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+    # the contrastive prep + loss alone (forward + backward) at the per-rank shape of the 8-GPU configs
+    # (3 images, 33 x 33 maps, K = 16: A ~ 2.4k anchors x C ~ 4.5k contrast rows), same host threads
+    from oracle import contrastive as OC
+    f_n, f_o, l_po, lab3 = synth.contrastive_case(7, 3, 256, 33, 33, 16, args.crop, args.crop, new_ids)
+    tc = None
+    for _ in range(2):
+        x = f_n.clone().requires_grad_(True)
+        t0 = time.time()
+        prep = OC.pre_contrastive_pixel(x, lab3, l_po, f_o)
+        OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07).backward()
+        tc = time.time() - t0
+    A3, C3 = prep["a"].shape[0], prep["c"].shape[0]
+    contrastive = {"seconds": tc, "A": A3, "C": C3, "K": 16, "gflops_algorithmic": A3 * C3 * (4 * 256 + 2 * 16) / tc / 1e9,
+                   "sample": "pre_contrastive_pixel + PixelConLossV2 forward + backward, 3 images 33x33 maps (cfg3 per-rank shape)"}
+    return {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "contrastive": contrastive,
             "sample": f"1 full UCD step after 1 warm-up step (teacher fwd + student fwd/bwd + CE + contrastive + KD + SGD), {B} images "
                       f"{args.crop}x{args.crop}, fp32 PyTorch-CPU oracle, {dt:.1f} s",
             "loss": float((r["loss"] + r["lkd"]).detach())}

@@ -231,6 +231,13 @@ int ucd_abn_sync_backward_comm(ucd_comm_t comm, int world, const void* x, int ld
 int ucd_plane_sum(const void* x, int ld_x, int dtype, int B, int HW, int C, float alpha,
                   float* out /* [B, C] */, ucd_stream_t stream);
 
+/* Sliding-window mean with stride 1 and no padding: out[b, oy, ox, c] = mean of the ph x pw window of x at (oy, ox);
+ * out is [B, H-ph+1, W-pw+1, C] channels-last.  Replaces F.avg_pool2d(x, (ph, pw), stride=1) of the image-pooling branch in
+ * evaluation mode (modules/deeplab.py:77-83; the teacher at 513^2 and 768^2, --pooling 32) with one read of the map. */
+size_t ucd_window_mean_workspace_bytes(int B, int H, int W, int C, int ph);
+int ucd_window_mean(const void* x, int ld_x, int dtype, int B, int H, int W, int C, int ph, int pw, void* out, int ld_out,
+                    void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
 /* Spatial attention map (segmentation_module.py:86-94): a[b,p] = sum_c x^2, normalised per image by
  * its Frobenius norm; y = a * x.  workspace: B*HW + B floats. */
 size_t ucd_attmap_workspace_bytes(int B, int HW);
@@ -443,6 +450,14 @@ size_t ucd_conv1x1_wgrad_workspace_bytes(int M, int N, int K);
 int ucd_conv1x1_wgrad(const void* dy, int ld_dy, const void* a, int lda, int M, int N, int K,
                       const float* in_mean, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                       void* dw, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
+/* The weights of the input-gradient convolutions of ALL stride-1 layers in one launch: for table entry e = {src offset,
+ * dst offset, Co, Ci, KH*KW} (elements into the flat bf16 buffers; 4-D weights in channels-last memory order
+ * [out][kh][kw][in]), dst_e = src_e.flip(2, 3).transpose(0, 1) in the same memory order.  blocks [n_blocks][4] (device,
+ * int32) = {entry, spatial tap, out-channel tile of 32, in-channel tile of 32}, entries [n][5] (device, int64).  Replaces the
+ * per-layer flip + copy of the "input gradient on the forward solver" trick (ucd_amd/blocks.py::_StrideOneConvFn). */
+int ucd_flip_weights_batched(const void* src_flat, void* dst_flat, const int* blocks, int n_blocks, const long long* entries,
+                             ucd_stream_t stream);
 
 /* dst[cols, rows] = src[rows, cols]^T (bf16): the [K, N] weight of the input-gradient product. */
 int ucd_transpose_bf16(const void* src, int rows, int cols, void* dst, ucd_stream_t stream);

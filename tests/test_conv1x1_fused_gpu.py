@@ -198,3 +198,54 @@ def test_residual_block_training_fused_node_equals_module_path(cin, chans, with_
     torch.testing.assert_close(rmf, rmp, rtol=1e-3, atol=1e-4)
     for n in gf:
         assert _rel(gf[n], gp[n]) < 5e-2, n
+
+
+def test_cached_flipped_weights_equal_flip_transpose():
+    """ucd_flip_weights_batched (one launch for every stride-1 layer, refreshed with the bf16 working copies) against
+    w.flip(2, 3).transpose(0, 1) per layer, before and after an optimiser step; and the step with the cached copies gives the
+    same input gradients as the per-call flip."""
+    from functools import partial
+    from ucd_amd import abn
+    from ucd_amd.blocks import Conv1x1, Conv3x3, ResidualBlock
+    from ucd_amd.master import Bf16Weights
+    norm = partial(abn.InPlaceABN, activation="leaky_relu", activation_param=0.01)
+    net = torch.nn.Sequential(ResidualBlock(64, (64, 64, 256), norm_act=norm, stride=1, dilation=1),
+                              ResidualBlock(256, (128, 128, 256), norm_act=norm, stride=1, dilation=2))
+    net.load_state_dict(synth.fill_state_dict(net.state_dict(), 3))
+    net = net.to(DEV).to(memory_format=torch.channels_last).train()
+    bw = Bf16Weights(net)
+    mods = [m for m in net.modules() if isinstance(m, (Conv3x3, Conv1x1)) and m._w16_flip is not None]
+    assert len(mods) >= 5
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+
+    def check():
+        bw.refresh_if_stale()
+        for m in mods:
+            ref = m._w16.detach().flip(2, 3).transpose(0, 1)
+            assert m._w16_flip.shape == ref.shape and torch.equal(m._w16_flip, ref)
+            assert m._w16_flip.is_contiguous(memory_format=torch.channels_last)
+    check()
+    x = synth.t_normal(4, (24, 64, 21, 19), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    grads = []
+    for cached in (True, False):
+        xi = x.clone().requires_grad_(True)
+        if not cached:
+            saved = [(m, m._w16_flip) for m in mods]
+            for m in mods:
+                m._w16_flip = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            net(xi).float().square().mean().backward()
+        grads.append(xi.grad.float().clone())
+        if not cached:
+            for m, f in saved:
+                m._w16_flip = f
+        for p in net.parameters():
+            p.grad = None
+        for m in net.modules():
+            if getattr(m, "_w16", None) is not None:
+                m._w16.grad = None
+    assert _rel(grads[0], grads[1]) < 2e-2          # same solvers, same values: only MIOpen's own run-to-run noise
+    for p in net.parameters():
+        p.grad = torch.randn_like(p) * 0.01
+    opt.step()
+    check()

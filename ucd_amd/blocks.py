@@ -110,6 +110,7 @@ class Conv2d(nn.Conv2d):
     ``state_dict`` keys and the fp32 behaviour are those of ``nn.Conv2d``."""
 
     _w16 = None
+    _w16_flip = None        # w16.flip(2, 3).transpose(0, 1) kept by ucd_amd.master.Bf16Weights (refreshed with the working copy)
 
     def working_weight(self):
         w = self._w16
@@ -141,8 +142,9 @@ class _StrideOneConvFn(torch.autograd.Function):
     (256->64 at 129^2 / 512->128 at 65^2 / 256->128 at 129^2)."""
 
     @staticmethod
-    def forward(ctx, x, w, d):
+    def forward(ctx, x, w, d, wt=None):
         ctx.d = d
+        ctx.wt = wt          # w.flip(2, 3).transpose(0, 1), channels-last, when the caller keeps it cached (ucd_amd/master.py)
         ctx.save_for_backward(x, w)
         return F.conv2d(x, w, None, 1, d * (w.shape[2] // 2), d)
 
@@ -153,21 +155,24 @@ class _StrideOneConvFn(torch.autograd.Function):
         pad = d * (w.shape[2] // 2)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = w.transpose(0, 1) if w.shape[2] == 1 else w.flip(2, 3).transpose(0, 1)
-            dx = F.conv2d(dy, wt.contiguous(memory_format=torch.channels_last), None, 1, pad, d)
+            wt = ctx.wt
+            if wt is None:
+                wt = (w.transpose(0, 1) if w.shape[2] == 1 else w.flip(2, 3).transpose(0, 1)).contiguous(
+                    memory_format=torch.channels_last)
+            dx = F.conv2d(dy, wt, None, 1, pad, d)
         if ctx.needs_input_grad[1]:
             dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [pad, pad], [d, d], False, [0, 0], 1,
                                                      [False, True, False])[1]
-        return dx, dw, None
+        return dx, dw, None, None
 
 
-def _stride_one_conv(x, w, d):
+def _stride_one_conv(x, w, d, wt=None):
     """The C++ autograd node when built (no Python in the backward), else the Python Function: same ATen calls."""
     from . import abn
     node = abn._abn_node()
     if node is not None and hasattr(node, "conv_stride1"):
-        return node.conv_stride1(x, w, d)
-    return _StrideOneConvFn.apply(x, w, d)
+        return node.conv_stride1(x, w, d, wt)
+    return _StrideOneConvFn.apply(x, w, d, wt)
 
 
 class Conv3x3(Conv2d):
@@ -180,8 +185,8 @@ class Conv3x3(Conv2d):
                 and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
             w = self.working_weight()
             if w is None:
-                w = self.weight.to(x.dtype)
-            return _stride_one_conv(x, w, self.dilation[0])
+                return _stride_one_conv(x, self.weight.to(x.dtype), self.dilation[0])
+            return _stride_one_conv(x, w, self.dilation[0], self._w16_flip)
         return super().forward(x)
 
 
@@ -205,7 +210,9 @@ class Conv1x1(Conv2d):
                     and self.weight.requires_grad and x.shape[0] * x.shape[2] * x.shape[3] >= 8192
                     and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
                 w = self.working_weight()
-                return _stride_one_conv(x, w if w is not None else self.weight.to(x.dtype), 1)   # narrow layer: MIOpen
+                if w is None:
+                    return _stride_one_conv(x, self.weight.to(x.dtype), 1)
+                return _stride_one_conv(x, w, 1, self._w16_flip)                                  # narrow layer: MIOpen
             return super().forward(x)
         B, C, H, W = x.shape
         rows = x.permute(0, 2, 3, 1)                      # a view of a channels-last tensor
@@ -521,6 +528,10 @@ class DeeplabV3(nn.Module):
         pw = min(try_index(self.pooling_size, 1), x.shape[3])
         pad = ((pw - 1) // 2, (pw - 1) // 2 + (1 - pw % 2),
                (ph - 1) // 2, (ph - 1) // 2 + (1 - ph % 2))
+        if (x.is_cuda and _is_fused_abn(self.red_bn) and not torch.is_grad_enabled()
+                and x.shape[1] % (8 if x.dtype == torch.bfloat16 else 4) == 0 and x.dtype in (torch.bfloat16, torch.float32)):
+            from . import hip
+            return hip.window_mean(x, ph, pw), pad                # separable running sums: one read of the map
         return F.avg_pool2d(x, (ph, pw), stride=1), pad
 
     def forward(self, x):

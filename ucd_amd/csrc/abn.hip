@@ -499,6 +499,71 @@ __global__ __launch_bounds__(kBlock) void plane_sum_kernel(const T* __restrict__
   }
 }
 
+// ---- sliding-window mean (the image-pooling branch of DeeplabV3 in evaluation mode, modules/deeplab.py:77-83) --------
+// out[b, oy, ox, c] = mean over the ph x pw window at (oy, ox), stride 1, no padding (avg_pool2d's "valid" output); the
+// replicate padding back to the input size is the caller's (it commutes with the pointwise layers that follow).
+// Separable running sums: pass 1 walks every column down (one thread per (b, x, 8/4-channel vector): add the entering row,
+// drop the leaving one), pass 2 walks the rows of the intermediate across.  One read of the map instead of ph*pw.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void window_vsum_kernel(const T* __restrict__ x, int ld_x, int B, int H, int W, int C,
+                                                            int ph, float* __restrict__ tmp) {
+  constexpr int VEC = Vec<T>::N;
+  const int CG = C / VEC, OH = H - ph + 1;
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (size_t)B * W * CG) return;
+  const int cg = idx % CG, xx = (idx / CG) % W, b = idx / ((size_t)CG * W);
+  const T* col = x + ((size_t)b * H * W + xx) * ld_x + (size_t)cg * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  for (int y = 0; y < H; ++y) {
+    Vec<T> v;
+    v.load(col + (size_t)y * W * ld_x);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += v.get(i);
+    if (y >= ph) {
+      Vec<T> o;
+      o.load(col + (size_t)(y - ph) * W * ld_x);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] -= o.get(i);
+    }
+    if (y >= ph - 1) {
+      float* dst = tmp + (((size_t)b * OH + (y - ph + 1)) * W + xx) * C + (size_t)cg * VEC;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) dst[i] = acc[i];
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void window_hsum_kernel(const float* __restrict__ tmp, int B, int OH, int W, int C, int pw,
+                                                            float scale, T* __restrict__ out, int ld_o) {
+  constexpr int VEC = Vec<T>::N;
+  const int CG = C / VEC, OW = W - pw + 1;
+  const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+  if (idx >= (size_t)B * OH * CG) return;
+  const int cg = idx % CG;
+  const size_t line = idx / CG;                      // (b, oy)
+  const float* row = tmp + line * W * C + (size_t)cg * VEC;
+  float acc[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+  for (int xx = 0; xx < W; ++xx) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) acc[i] += row[(size_t)xx * C + i];
+    if (xx >= pw) {
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] -= row[(size_t)(xx - pw) * C + i];
+    }
+    if (xx >= pw - 1) {
+      Vec<T> o;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) o.set(i, acc[i] * scale);
+      o.store(out + (line * OW + (xx - pw + 1)) * ld_o + (size_t)cg * VEC);
+    }
+  }
+}
+
 // ---- attention map (segmentation_module.py:86-94) -----------------------------------------------
 // pass 1: a[p] = sum_c x[p,c]^2 (one wave per pixel row), pass 2: per-image sum of a^2, pass 3: y = x*a/||a||
 template <typename T>
@@ -901,6 +966,40 @@ int ucd_plane_sum(const void* x, int ld_x, int dtype, int B, int HW, int C, floa
     Geom g = make_geom<4>(HW, C, 1, 1);
     plane_sum_kernel<float><<<dim3(g.gx, B), kBlock, kBlock * 4 * 4, s>>>((const float*)x, ld_x, HW, C, alpha, g.TX,
                                                                          g.TY, out);
+  }
+  return check_launch(fn);
+}
+
+size_t ucd_window_mean_workspace_bytes(int B, int H, int W, int C, int ph) {
+  return (size_t)B * (size_t)(H - ph + 1) * W * C * sizeof(float);
+}
+
+int ucd_window_mean(const void* x, int ld_x, int dtype, int B, int H, int W, int C, int ph, int pw, void* out, int ld_out,
+                    void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_window_mean";
+  UCD_TRY(check_common(fn, dtype, B * H * W, C, UCD_ACT_IDENTITY));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, dtype, C, false));
+  UCD_TRY(check_act_tensor(fn, "out", out, ld_out, dtype, C, false));
+  UCD_REQUIRE(ph >= 1 && pw >= 1 && ph <= H && pw <= W, UCD_EINVAL, "%s: window %dx%d does not fit the %dx%d map", fn, ph, pw, H, W);
+  UCD_REQUIRE(workspace && workspace_bytes >= ucd_window_mean_workspace_bytes(B, H, W, C, ph), UCD_EWORKSPACE,
+              "%s: workspace too small", fn);
+  hipStream_t s = (hipStream_t)stream;
+  const int OH = H - ph + 1;
+  const float scale = 1.f / ((float)ph * (float)pw);
+  float* tmp = (float*)workspace;
+  if (dtype == UCD_BF16) {
+    const size_t n1 = (size_t)B * W * (C / 8), n2 = (size_t)B * OH * (C / 8);
+    window_vsum_kernel<__hip_bfloat16><<<(unsigned)((n1 + kBlock - 1) / kBlock), kBlock, 0, s>>>((const __hip_bfloat16*)x, ld_x, B, H, W,
+                                                                                             C, ph, tmp);
+    UCD_TRY(check_launch(fn));
+    window_hsum_kernel<__hip_bfloat16><<<(unsigned)((n2 + kBlock - 1) / kBlock), kBlock, 0, s>>>(tmp, B, OH, W, C, pw, scale,
+                                                                                             (__hip_bfloat16*)out, ld_out);
+  } else {
+    const size_t n1 = (size_t)B * W * (C / 4), n2 = (size_t)B * OH * (C / 4);
+    window_vsum_kernel<float><<<(unsigned)((n1 + kBlock - 1) / kBlock), kBlock, 0, s>>>((const float*)x, ld_x, B, H, W, C, ph, tmp);
+    UCD_TRY(check_launch(fn));
+    window_hsum_kernel<float><<<(unsigned)((n2 + kBlock - 1) / kBlock), kBlock, 0, s>>>(tmp, B, OH, W, C, pw, scale, (float*)out,
+                                                                                    ld_out);
   }
   return check_launch(fn);
 }

@@ -299,31 +299,36 @@ std::vector<at::Tensor> gemm1x1_skip(at::Tensor rows, at::Tensor w4, int64_t str
 // the Python twin.
 class StrideOneConvNode : public torch::autograd::Function<StrideOneConvNode> {
  public:
-  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor w, int64_t d) {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt_) {
     const int64_t pad = d * (w.size(2) / 2);
-    ctx->save_for_backward({x, w});
+    // wt = w.flip(2, 3).transpose(0, 1) in channels-last order when the caller keeps it cached (ucd_amd/master.py: one
+    // batched kernel per optimiser step instead of a flip + copy per layer and step)
+    ctx->save_for_backward({x, w, wt_.has_value() ? *wt_ : at::Tensor()});
     ctx->saved_data["d"] = d;
     return at::conv2d(x, w, {}, {1, 1}, {pad, pad}, {d, d}, 1);
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     auto saved = ctx->get_saved_variables();
-    at::Tensor x = saved[0], w = saved[1], dy = grads[0];
+    at::Tensor x = saved[0], w = saved[1], wt = saved[2], dy = grads[0];
     const int64_t d = ctx->saved_data["d"].toInt(), pad = d * (w.size(2) / 2);
     at::Tensor dx, dw;
     if (ctx->needs_input_grad(0)) {
-      at::Tensor wt = w.size(2) == 1 ? w.transpose(0, 1) : w.flip({2, 3}).transpose(0, 1);
-      dx = at::conv2d(dy, wt.contiguous(at::MemoryFormat::ChannelsLast), {}, {1, 1}, {pad, pad}, {d, d}, 1);
+      if (!wt.defined())
+        wt = (w.size(2) == 1 ? w.transpose(0, 1) : w.flip({2, 3}).transpose(0, 1)).contiguous(at::MemoryFormat::ChannelsLast);
+      dx = at::conv2d(dy, wt, {}, {1, 1}, {pad, pad}, {d, d}, 1);
     }
     if (ctx->needs_input_grad(1)) {
       dw = std::get<1>(at::convolution_backward(dy, x, w, c10::nullopt, {1, 1}, {pad, pad}, {d, d}, false, {0, 0}, 1,
                                                 {false, true, false}));
     }
-    return {dx, dw, at::Tensor()};
+    return {dx, dw, at::Tensor(), at::Tensor()};
   }
 };
 
-at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d) { return StrideOneConvNode::apply(x, w, d); }
+at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt) {
+  return StrideOneConvNode::apply(x, w, d, wt);
+}
 
 // ---- 1x1 convolution + training-mode ABN as ONE node ------------------------------------------------------
 // forward   z = x . w^T with the statistics of z accumulated in the GEMM's epilogue (ucd_conv1x1 out_mode 2: no statistics

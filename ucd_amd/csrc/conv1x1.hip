@@ -517,6 +517,30 @@ __global__ __launch_bounds__(kThreads) void transpose_bf16_kernel(const uint16_t
     if (c0 + i < C && r0 + x < R) dst[(size_t)(c0 + i) * R + r0 + x] = t[x][i];
 }
 
+// Batched "weight of the input-gradient convolution": for every layer e of a table,
+//   dst_e[ci][kh][kw][co] = src_e[co][KH-1-kh][KW-1-kw][ci]       (both channels-last 4-D weights: [out][kh][kw][in] in memory)
+// i.e. w.flip(2, 3).transpose(0, 1) of all stride-1 convolutions in ONE launch (the per-layer flip + copy pairs were ~70
+// launches per step).  blocks[b] = {entry, spatial index, co tile, ci tile}; entries[e] = {src offset, dst offset, Co, Ci, KH*KW}
+// (offsets in elements into the flat bf16 buffers).
+__global__ __launch_bounds__(kThreads) void flip_weights_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst,
+                                                               const int4* __restrict__ blocks,
+                                                               const long long* __restrict__ entries) {
+  __shared__ uint16_t t[32][33];
+  const int4 bk = blocks[blockIdx.x];
+  const long long* e = entries + (size_t)bk.x * 5;
+  const long long so = e[0], dofs = e[1];
+  const int Co = (int)e[2], Ci = (int)e[3], S = (int)e[4];
+  const int sp = bk.y, co0 = bk.z * 32, ci0 = bk.w * 32;
+  const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+  const uint16_t* sp_src = src + so + (size_t)(S - 1 - sp) * Ci;       // flipped spatial tap
+  for (int i = y; i < 32; i += 8)
+    if (co0 + i < Co && ci0 + x < Ci) t[i][x] = sp_src[(size_t)(co0 + i) * S * Ci + ci0 + x];
+  __syncthreads();
+  uint16_t* sp_dst = dst + dofs + (size_t)sp * Co;
+  for (int i = y; i < 32; i += 8)
+    if (ci0 + i < Ci && co0 + x < Co) sp_dst[(size_t)(ci0 + i) * S * Co + co0 + x] = t[x][i];
+}
+
 int pick_wgrad_chunks(int M, int N, int K) {
   // enough workgroups for two per CU, chunks of whole 32-row steps
   const int tiles = (N / 128) * (K / 128);
@@ -647,6 +671,15 @@ int ucd_conv1x1_wgrad(const void* dy, int ld_dy, const void* a, int lda, int M, 
   const size_t total = (size_t)N * K;
   wgrad_reduce_kernel<<<(unsigned)((total / 8 + kThreads - 1) / kThreads), kThreads, 0, s>>>((const float*)workspace, grid_x, total,
                                                                                          (bf16*)dw);
+  return check_launch(fn);
+}
+
+int ucd_flip_weights_batched(const void* src_flat, void* dst_flat, const int* blocks, int n_blocks, const long long* entries,
+                             ucd_stream_t stream) {
+  static const char* fn = "ucd_flip_weights_batched";
+  UCD_REQUIRE(src_flat && dst_flat && blocks && entries && n_blocks > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  flip_weights_kernel<<<n_blocks, kThreads, 0, (hipStream_t)stream>>>((const uint16_t*)src_flat, (uint16_t*)dst_flat,
+                                                                      (const int4*)blocks, entries);
   return check_launch(fn);
 }
 

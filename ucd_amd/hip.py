@@ -88,6 +88,8 @@ SIGNATURES = {
     "ucd_abn_backward": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _p, _f, _i, _i,
                               _i, _f, _p, _z, _p]),
     "ucd_plane_sum": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _p]),
+    "ucd_window_mean_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "ucd_window_mean": (_i, [_p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _z, _p]),
     "ucd_attmap_workspace_bytes": (_z, [_i, _i]),
     "ucd_attmap": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "ucd_conv1x1_row_tiles": (_i, [_i]),
@@ -97,6 +99,7 @@ SIGNATURES = {
     "ucd_conv1x1_wgrad_workspace_bytes": (_z, [_i, _i, _i]),
     "ucd_conv1x1_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
+    "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
     "ucd_pixcon_prep_workspace_bytes": (_z, [_i, _i]),
     "ucd_pixcon_prep": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "ucd_pixcon_gather": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p]),
@@ -539,3 +542,19 @@ def conv1x1_wgrad(dy, a, dw, in_norm=None):
 def transpose_bf16(src, dst):
     _check(load().ucd_transpose_bf16(ptr(src), src.shape[0], src.shape[1], ptr(dst), stream()), "ucd_transpose_bf16")
     return dst
+
+
+def window_mean(x, ph, pw):
+    """F.avg_pool2d(x, (ph, pw), stride=1) of a channels-last map (ucd_window_mean)."""
+    lib = load()
+    xv, M, Cc, HW, ld = rows_view(x)
+    B, _, H, W = xv.shape
+    out = torch.empty((B, Cc, H - ph + 1, W - pw + 1), dtype=xv.dtype, device=xv.device, memory_format=torch.channels_last)
+    if out.shape[2] == 1 or out.shape[3] == 1 or B == 1:      # ambiguous channels_last strides: make the rows explicit
+        out = torch.empty((B, H - ph + 1, W - pw + 1, Cc), dtype=xv.dtype, device=xv.device).permute(0, 3, 1, 2)
+    nbytes = lib.ucd_window_mean_workspace_bytes(B, H, W, Cc, ph)
+    ws = workspace(nbytes, xv.device, "winmean")
+    with _timed("ucd_window_mean", B * H * W * Cc * xv.element_size()):
+        _check(lib.ucd_window_mean(ptr(xv), ld, dtype_code(xv), B, H, W, Cc, ph, pw, ptr(out), Cc, ptr(ws), nbytes, stream()),
+               "ucd_window_mean")
+    return out

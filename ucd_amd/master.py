@@ -49,6 +49,7 @@ class Bf16Weights:
                 m._w16 = s
                 self.shadow_of[w] = s
                 off += n
+        self._build_flip_table()
         self._seen = None
         self._dirty = True
         # fused optimisers update the weights without bumping their version counters, so any optimiser step marks
@@ -69,6 +70,50 @@ class Bf16Weights:
         if hook is not None:
             hook.remove()
 
+    def _build_flip_table(self):
+        """Flipped + transposed bf16 copies of the stride-1 weights whose input gradient runs on the FORWARD solver
+        (``blocks._StrideOneConvFn``: dx = conv2d(dy, w.flip(2, 3).transpose(0, 1))): one flat buffer, refreshed together with
+        the working copies by ONE batched kernel (``ucd_flip_weights_batched``) instead of a flip + copy per layer and step."""
+        from .blocks import Conv1x1, Conv3x3
+        self.flat16_flip = None
+        if not self.trainable:
+            return
+        mods = [m for m in self.convs if isinstance(m, (Conv3x3, Conv1x1)) and m.weight.requires_grad and m.bias is None
+                and m.stride == (1, 1) and m.groups == 1 and not (isinstance(m, Conv1x1) and m.as_gemm)
+                and m.weight.is_contiguous(memory_format=torch.channels_last)]
+        if not mods:
+            return
+        dev = self.flat16.device
+        entries, blocks, off = [], [], 0
+        base = self.flat16.data_ptr()
+        for e, m in enumerate(mods):
+            co, ci, kh, kw = m.weight.shape
+            src_off = (m._w16.data_ptr() - base) // 2
+            entries.append([src_off, off, co, ci, kh * kw])
+            for sp in range(kh * kw):
+                for a in range((co + 31) // 32):
+                    for b in range((ci + 31) // 32):
+                        blocks.append([e, sp, a, b])
+            off += co * ci * kh * kw
+        self.flat16_flip = torch.empty(off, dtype=torch.bfloat16, device=dev)
+        self._flip_entries = torch.tensor(entries, dtype=torch.int64, device=dev)
+        self._flip_blocks = torch.tensor(blocks, dtype=torch.int32, device=dev)
+        off = 0
+        for m in mods:
+            co, ci, kh, kw = m.weight.shape
+            n = co * ci * kh * kw
+            # [ci, co, kh, kw] tensor in channels-last memory order ([ci][kh][kw][co])
+            m._w16_flip = self.flat16_flip[off:off + n].view(ci, kh, kw, co).permute(0, 3, 1, 2)
+            off += n
+
+    def _refresh_flips(self):
+        if self.flat16_flip is None:
+            return
+        from . import hip
+        hip._check(hip.load().ucd_flip_weights_batched(self.flat16.data_ptr(), self.flat16_flip.data_ptr(),
+                                                       self._flip_blocks.data_ptr(), self._flip_blocks.shape[0],
+                                                       self._flip_entries.data_ptr(), hip.stream()), "ucd_flip_weights_batched")
+
     def mark_stale(self):
         self._dirty = True
 
@@ -82,5 +127,6 @@ class Bf16Weights:
         if self._dirty or v != self._seen:
             with torch.no_grad():
                 self.flat16.copy_(self.flat32)
+                self._refresh_flips()
             self._seen = v
             self._dirty = False
