@@ -2,7 +2,7 @@
 //
 // The kernels live behind the C ABI (include/ucd_hip.h); what this file replaces is the Python wrapper around them on
 // the student's 106 training-mode layers: a Python autograd.Function costs ~38 us forward and ~33 us backward of host
-// time per layer (tools/host_profile2.py), which is what bounds the step once a GPU holds 3-6 images (4-8 GPU runs).
+// time per layer (tools/host_profile.py), which is what bounds the step once a GPU holds 3-6 images (4-8 GPU runs).
 // Here the forward is one pybind call (~8 us) and the backward never enters Python.  It mirrors
 // ucd_amd/abn.py::_ABNFunction for the case it is used for - batch statistics, dense channels-last input, optional
 // fused residual, optional SyncBN through the library-owned RCCL communicator - and the Python class stays the
