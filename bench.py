@@ -47,6 +47,7 @@ def parse():
     # test hooks: run the N > 1 code path with several ranks on ONE GPU (RCCL refuses that; gloo carries CUDA tensors)
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
     p.add_argument("--device", type=int, default=None, help=argparse.SUPPRESS)
+    p.add_argument("--check_lockstep", action="store_true", help=argparse.SUPPRESS)   # test hook: ranks compare weights / statistics
     return p.parse_args()
 
 
@@ -201,6 +202,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     last = {k: float(v) for k, v in trainer.last.items()}
+    lockstep = None
+    if args.check_lockstep and world > 1:
+        # data parallelism keeps every replica identical: after the timed steps all ranks must hold the same parameters AND
+        # the same running statistics (SyncBN), bit for bit (gradients are averaged before the update, statistics are
+        # combined from the same gathered table on every rank)
+        net = trainer.model.module if hasattr(trainer.model, "module") else trainer.model
+        sig = torch.stack([t.detach().double().sum() for t in list(net.parameters()) + list(net.buffers())
+                           if t.is_floating_point()])
+        gathered = [torch.zeros_like(sig) for _ in range(world)]
+        dist.all_gather(gathered, sig)
+        lockstep = all(torch.equal(g, gathered[0]) for g in gathered)
 
     roof, kernels = None, None
     if not args.no_kernel_timing:
@@ -260,6 +272,8 @@ def main():
                        "contrastive_dtype": trainer.pixcon_precision},
             "losses": last, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
         }
+        if lockstep is not None:
+            out["lockstep"] = bool(lockstep)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -210,3 +210,24 @@ def test_bench_multi_rank_path_two_ranks_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
     assert all(np.isfinite(v) for v in d["losses"].values())
+
+
+def test_bench_four_ranks_one_gpu_stay_in_lockstep(tmp_path):
+    """The N > 1 path at world size 4 (four ranks share the one GPU, gloo carries the tensors): sharded batch, bucketed
+    gradient averaging under the backward, per-layer SyncBN exchange, end-of-backward finish - and after the steps every
+    rank holds bit-identical parameters and running statistics."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4",
+                        "--master-addr", "127.0.0.1", "--master-port", "29727", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "4", "--steps", "2", "--warmup", "3", "--global_batch", "8", "--crop", "129",
+                        "--backend", "gloo", "--device", "0", "--no_miopen_find", "--no_cpu_baseline", "--no_kernel_timing",
+                        "--check_lockstep"],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["config"]["parallelism"] == "dp4" and d["value"] > 0
+    assert d["lockstep"] is True
+    assert all(np.isfinite(v) for v in d["losses"].values())

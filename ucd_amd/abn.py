@@ -88,10 +88,26 @@ def _abn_node():
 
 
 def _all_gather_stats(pack, world, group):
-    """[world, 2C] table of every rank's (mean_r | M2_r) - the one forward collective of a SyncBN layer."""
+    """[world, 2C] table of every rank's (mean_r | M2_r) - the one forward collective of a SyncBN layer: on the
+    library-owned RCCL communicator (compute stream, no dispatcher) when there is one, else through torch.distributed."""
     flat = torch.empty(world * pack.numel(), dtype=torch.float32, device=pack.device)
-    dist.all_gather_into_tensor(flat, pack, group=group if group is not None else None)
+    comm = direct_comm(group) if pack.is_cuda else None
+    if comm is not None:
+        hip._check(hip.load().ucd_comm_all_gather(comm.handle, hip.ptr(pack), hip.ptr(flat), pack.numel(), hip.stream()),
+                   "ucd_comm_all_gather")
+    else:
+        dist.all_gather_into_tensor(flat, pack, group=group if group is not None else None)
     return flat
+
+
+def _all_reduce_sums(sums, group):
+    """In-place sum over the ranks of a backward's [sum dz | sum dz*xhat] vector (same routing as the gather)."""
+    comm = direct_comm(group) if sums.is_cuda else None
+    if comm is not None:
+        hip._check(hip.load().ucd_comm_all_reduce_sum(comm.handle, hip.ptr(sums), sums.numel(), hip.stream()),
+                   "ucd_comm_all_reduce_sum")
+    else:
+        dist.all_reduce(sums, group=group if group is not None else None)
 
 
 class _ABNFunction(torch.autograd.Function):
@@ -185,7 +201,7 @@ class _ABNFunction(torch.autograd.Function):
             dbias = dweight = None
             if need_param_grad:
                 dbias, dweight = local[:Cc], local[Cc:]
-            dist.all_reduce(sums, group=group if group is not None else None)
+            _all_reduce_sums(sums, group)
             hip.abn_bwd_apply(x, ld_x, dy, ld_dy, y, ld_yy, dx, Cc, dz, Cc if has_res else 0, M, Cc, plane_bias, HW, mean,
                               invstd, scale, shift, weight, sums, count, 0, act, slope)
         dpb = None
@@ -292,7 +308,7 @@ class _ABNBranchesFunction(torch.autograd.Function):
             dbias = torch.cat([sums[2 * o:2 * o + c] for c, o in zip(chans, offs)])
             dweight = torch.cat([sums[2 * o + c:2 * (o + c)] for c, o in zip(chans, offs)])
         if training and world > 1:
-            dist.all_reduce(sums, group=group if group is not None else None)
+            _all_reduce_sums(sums, group)
         dxs = []
         for x, c, o, ld in zip(xs, chans, offs, lds):
             sl = slice(o, o + c)
