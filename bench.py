@@ -20,6 +20,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def _seed_miopen_user_db():
+    """MIOpen's solver search (torch.backends.cudnn.benchmark) takes ~1 minute of the warm-up on a fresh box.  Its results
+    for this workload's convolutions, captured on an MI355X, are committed under ucd_amd/tuning/miopen (text find-db of the
+    same MIOpen build); seeding a private user-db directory with them turns every search into a lookup.  A different MIOpen
+    build or GPU simply ignores the files (they are keyed by build and architecture) and searches as before."""
+    if os.environ.get("MIOPEN_USER_DB_PATH") or os.environ.get("UCD_NO_MIOPEN_SEED"):
+        return
+    src = os.path.join(ROOT, "ucd_amd", "tuning", "miopen")
+    if not os.path.isdir(src):
+        return
+    import shutil
+    import tempfile
+    dst = tempfile.mkdtemp(prefix="ucd_miopen_db_")
+    for name in os.listdir(src):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+
+
+_seed_miopen_user_db()          # before torch / MIOpen load
+
 import torch
 import torch.distributed as dist
 
