@@ -107,12 +107,13 @@ def build(args, device, per_rank_batch, rank):
 def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
     """Second, instrumented pass (not part of `value`): HIP events around every libucd_hip call on the
     stream it is launched on, plus the algorithmic bytes / flops of each call."""
-    from ucd_amd import abn, hip
-    # attribution mode: every library call visible and alone on the stream - no C++ node, no teacher graph, no
-    # teacher/student overlap (the timed region above ran with all three)
-    saved = (abn._node_mod, trainer.graph_teacher, trainer._side)
+    from ucd_amd import abn, blocks, hip
+    # attribution mode: every library call visible and alone on the stream - no C++ nodes (their Python twins issue the
+    # same library calls), no teacher graph, no teacher/student overlap (the timed region above ran with all three)
+    saved = (abn._node_mod, trainer.graph_teacher, trainer._side, blocks._node_cache[0])
     abn._abn_node()
     abn._node_mod, trainer.graph_teacher, trainer._side = None, False, None
+    blocks._node_cache[0] = None
     rec = hip.enable_call_timing()
     try:
         for _ in range(steps):
@@ -120,7 +121,7 @@ def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
         torch.cuda.synchronize()
     finally:
         hip.disable_call_timing()
-        abn._node_mod, trainer.graph_teacher, trainer._side = saved
+        abn._node_mod, trainer.graph_teacher, trainer._side, blocks._node_cache[0] = saved
     # an event pair with nothing between it does not read zero (~5 us here); it is REPORTED, not subtracted: a call's
     # events bracket launch gaps too, so the per-call durations are upper bounds of the kernel time (rocprofv3's kernel
     # durations in profiles/ are ~10 % shorter) and the roofline fraction computed from them is conservative
@@ -263,13 +264,13 @@ def main():
         roof["launches_per_step"] = k["launches"] / min(args.steps, 3)
         # HBM traffic of that kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_to_json.py); null if absent
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_bench.json")
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
         if os.path.exists(pmc):
             try:
                 rec = json.load(open(pmc)).get(name.split("[")[0])
                 if rec and rec.get("global_batch") == args.global_batch and world == 1:
                     roof["traffic"] = rec["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r01_pmc_bench.json"
+                    roof["traffic_source"] = "profiles/r02_pmc_bench.json"
             except (OSError, ValueError):
                 pass
 

@@ -249,3 +249,39 @@ def test_cached_flipped_weights_equal_flip_transpose():
         p.grad = torch.randn_like(p) * 0.01
     opt.step()
     check()
+
+
+def test_conv_abn_python_twin_equals_cpp_node():
+    """blocks._ConvABNFunction (the complete Python implementation, what bench.py's instrumented pass runs) and
+    csrc/abn_node.cpp::ConvABNTrainNode issue the same library calls: bit-identical outputs, gradients and statistics."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    norm = partial(abn.InPlaceABN, activation="leaky_relu", activation_param=0.01)
+    node = blocks._gemm_node()
+    assert node is not None and hasattr(node, "conv_abn_train")
+    x0 = synth.t_normal(9, (4, 1024, 15, 13), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(10, (4, 1024, 15, 13), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    torch.backends.cudnn.deterministic = True
+    try:
+        for use_node in (True, False):
+            blocks._node_cache[0] = node if use_node else None
+            try:
+                blk = blocks.ResidualBlock(1024, (256, 256, 1024), norm_act=norm, stride=1, dilation=1)
+                blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+                blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
+                x = x0.clone().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = blk(x * 1.0)
+                y.backward(dy)
+                outs.append([y.detach(), blk.convs.bn1.weight.grad.clone(), blk.convs.bn3.bias.grad.clone(),
+                             blk.convs.bn3.running_var.clone(), blk.convs.conv3.weight.grad.clone(), x.grad.clone()])
+            finally:
+                blocks._node_cache[0] = node
+    finally:
+        torch.backends.cudnn.deterministic = False
+    for i, (a, b) in enumerate(zip(*outs)):
+        if i < 5:
+            assert torch.equal(a, b), i
+        else:   # the node folds the shortcut's gradient into the GEMM (one rounding), the twin leaves the add to autograd (two)
+            assert _rel(a, b.float()) < 1e-2

@@ -268,6 +268,65 @@ def _own_gemm_with_stats(K, N):
     return not (K * N >= (1 << 20) and K >= 1024)
 
 
+class _ConvABNFunction(torch.autograd.Function):
+    """Python twin of csrc/abn_node.cpp::ConvABNTrainNode (single process; the node adds the SyncBN exchange and the
+    shortcut fold): z = x . w^T with the statistics in the GEMM epilogue -> finalize -> y = act(norm(z) [+ residual]).
+    The complete implementation and the fallback; bench.py's instrumented pass runs it (every library call visible)."""
+
+    @staticmethod
+    def forward(ctx, x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, fused):
+        from . import hip
+        B, K, H, W = x.shape
+        N = w4.shape[0]
+        M, HW = B * H * W, H * W
+        rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0] * t.shape[2] * t.shape[3], t.shape[1])
+        z = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        y = torch.empty_like(z)
+        buf = torch.empty(6 * N, dtype=torch.float32, device=x.device)
+        w2 = w4.reshape(N, K)
+        if fused:
+            part = torch.empty(hip.conv1x1_row_tiles(M), 3, N, dtype=torch.float32, device=x.device)
+            hip.conv1x1(rows(x), w2, rows(z), out_mode=2, partial=part)
+            hip.conv1x1_stats_finalize(part, M, N, weight, running_mean, running_var, momentum, eps, buf, None, act)
+            hip.abn_apply(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, buf[3 * N:4 * N], buf[5 * N:],
+                          bias, act, slope)
+        else:
+            hip.gemm_bf16(0, rows(x), w2, rows(z))
+            hip.abn_forward(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, weight, bias, running_mean,
+                            running_var, momentum, eps, True, buf, None, act, slope)
+        needs_y = residual is not None and (act & hip.ACT_MASK) != hip.ACT_IDENTITY
+        ctx.save_for_backward(x, w4, z, y if needs_y else None, weight, bias, buf)
+        ctx.cfg = (act, slope, residual is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import hip
+        x, w4, z, y, weight, bias, buf = ctx.saved_tensors
+        act, slope, has_res = ctx.cfg
+        B, K, H, W = x.shape
+        N = w4.shape[0]
+        M, HW = B * H * W, H * W
+        rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0] * t.shape[2] * t.shape[3], t.shape[1])
+        dy, _, _, _, _ = hip.rows_view(dy if dy.dtype == x.dtype else dy.to(x.dtype))
+        dz = torch.empty_like(z)
+        dres = torch.empty_like(z) if has_res else None
+        sums = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+        hip.abn_backward(z, N, dy, N, y, N if y is not None else 0, dz, N, dres, N if has_res else 0, M, N, None, HW,
+                         buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:], bias, weight, sums, float(M), True, True, act, slope)
+        w2 = w4.reshape(N, K)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            hip.gemm_bf16(1, rows(dz), w2, rows(dx))
+        if ctx.needs_input_grad[1]:
+            S = _wgrad_split(M)
+            dzr, xr = rows(dz), rows(x)
+            dw = (torch.bmm(dzr.view(S, M // S, N).transpose(1, 2), xr.view(S, M // S, K)).sum(0) if S > 1 else dzr.t() @ xr)
+            dw = dw.as_strided(w4.shape, w4.stride())
+        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None
+
+
 def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_param=None, with_skip=False):
     """``bn(conv(x) [, residual])`` of a wide 1x1 convolution and a training-mode HIP ABN as ONE autograd node
     (csrc/abn_node.cpp::ConvABNTrainNode): the ABN's batch statistics come out of the GEMM's epilogue.  Returns None when the
@@ -278,13 +337,28 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
             and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
             and x.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
         return None
+    from . import abn as _abn
+    from . import hip
     node = _gemm_node()
-    if node is None or not hasattr(node, "conv_abn_train") or not node.dense_channels_last(x):
+    if node is None or not hasattr(node, "conv_abn_train"):
+        # no C++ node (not built, or switched off by bench.py's instrumented pass): the Python twin, single process only
+        dense = lambda t: t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and t.shape[2] > 1 and t.shape[3] > 1
+        if (_lib_gemm() is None or _abn._group_size(bn._group()) > 1 or not dense(x)
+                or (residual is not None and not (dense(residual) and residual.dtype == x.dtype))):
+            return None
+        w16 = conv.working_weight()
+        if w16 is None:
+            w16 = conv.weight.to(x.dtype)
+        act = _abn._act_code(bn.activation if activation is None else activation) | (hip.NORM_ABS_GAMMA if bn._abs_gamma else 0)
+        slope = bn.activation_param if activation_param is None else activation_param
+        bn.__dict__.pop("_eval_cache", None)
+        y = _ConvABNFunction.apply(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                   act, slope, _own_gemm_with_stats(conv.in_channels, conv.out_channels))
+        return (y, x) if with_skip else y
+    if not node.dense_channels_last(x):
         return None
     if residual is not None and not (residual.dtype == x.dtype and node.dense_channels_last(residual)):
         return None
-    from . import abn as _abn
-    from . import hip
     group = bn._group()
     world = _abn._group_size(group)
     sync = group is not False and (world > 1 or (_abn._FORCE_SYNC and torch.distributed.is_initialized()))

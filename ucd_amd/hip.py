@@ -558,3 +558,13 @@ def window_mean(x, ph, pw):
         _check(lib.ucd_window_mean(ptr(xv), ld, dtype_code(xv), B, H, W, Cc, ph, pw, ptr(out), Cc, ptr(ws), nbytes, stream()),
                "ucd_window_mean")
     return out
+
+
+def conv1x1_stats_finalize(partial, M, Cc, weight, running_mean, running_var, momentum, eps, buf, pack=None, flags=0):
+    _check(load().ucd_conv1x1_stats_finalize(ptr(partial), M, Cc, ptr(weight), ptr(running_mean), ptr(running_var),
+                                             float(momentum), float(eps), ptr(buf), ptr(pack), int(flags) & NORM_ABS_GAMMA,
+                                             stream()), "ucd_conv1x1_stats_finalize")
+
+
+def conv1x1_row_tiles(M):
+    return load().ucd_conv1x1_row_tiles(M)
