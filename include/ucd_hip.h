@@ -369,6 +369,15 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
                    float ce_weight, float kd_weight, float* loss_out, float* d_sem, int ld_d,
                    void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
+/* Validation on the device: bilinear up-sampling of the low-resolution logits
+ * (segmentation_module.py:133), arg-max over the classes (train.py:242 `outputs.max(dim=1)`) and the confusion matrix of
+ * metrics/stream_metrics.py:65-71 (`bincount(n * label + pred)` over the pixels with 0 <= label < n_classes) in one pass;
+ * the full-resolution logits never exist and nothing is copied to the host.  hist [n_classes, n_classes] int64 is
+ * ACCUMULATED into (zero it before the first batch; integer atomics: exact, order-independent); pred (optional,
+ * [B, H, W] int64) receives the arg-max map (first maximum, torch.max's rule). */
+int ucd_seg_confusion(const float* sem, int ld_s, const int64_t* labels, int B, int H, int W, int h, int w, int Ctot,
+                      int n_classes, int64_t* hist, int64_t* pred, ucd_stream_t stream);
+
 /* ---- label path of the training data pipeline on the device (first piece) ------------------------
  * Replaces, for the label maps of a batch, the reference's host-side RandomResizedCrop (crop + PIL NEAREST resize,
  * dataset/transform.py:481-553), RandomHorizontalFlip (:300-318) and the per-pixel Python lambda that remaps labels for

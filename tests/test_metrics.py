@@ -61,3 +61,40 @@ def test_device_confusion_matrix_matches_reference_golden(name):
     m, r = _run(StreamSegMetrics, name, g, to=lambda a: torch.from_numpy(a).to(dev))
     assert m.confusion_matrix.is_cuda
     _check(name, g, m, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ctot,n,H,W,h,w,B", [(21, 21, 129, 129, 9, 9, 3), (20, 20, 190, 251, 12, 16, 2), (151, 151, 128, 128, 8, 8, 2),
+                                            (21, 21, 513, 513, 33, 33, 4)])
+def test_fused_upsample_argmax_confusion_matches_oracle(Ctot, n, H, W, h, w, B):
+    """ucd_seg_confusion (bilinear up-sampling + arg-max + histogram, full-resolution logits never built) against the oracle
+    path the reference takes (train.py:236-246: interpolate -> max(dim=1) -> numpy bincount per image) on the CPU: the
+    confusion matrix is integer work -> bit-exact; the arg-max map may differ only where two interpolated logits tie to the
+    last bit between the two implementations of the interpolation (none on these inputs)."""
+    import torch.nn.functional as F
+    from ucd_amd import hip, synth
+    dev = torch.device("cuda:0")
+    sem = synth.t_normal(5 + Ctot, (B, Ctot, h, w), stream=1) * 2.0
+    labels = torch.from_numpy(synth.randint(7, (B, H, W), 0, n + 3, stream=2))
+    labels[labels >= n] = 255                                             # some ignored pixels
+    up = F.interpolate(sem, size=(H, W), mode="bilinear", align_corners=False)
+    pred_ref = up.max(dim=1)[1]
+    om = OracleMetrics(n)
+    om.update(labels.numpy(), pred_ref.numpy())
+    m = StreamSegMetrics(n)
+    m.update_from_logits(labels.to(dev), sem.to(dev))
+    m.update_from_logits(labels.to(dev), sem.to(dev))                     # accumulates across batches
+    cm = m.confusion_matrix.cpu().numpy()
+    assert np.array_equal(cm, 2 * om.confusion_matrix)
+    assert m.total_samples == 2 * B
+    # the arg-max map itself
+    s = sem.to(dev).permute(0, 2, 3, 1).reshape(B * h * w, Ctot).contiguous()
+    hist = torch.zeros(n, n, dtype=torch.int64, device=dev)
+    pred = torch.empty(B, H, W, dtype=torch.int64, device=dev)
+    hip._check(hip.load().ucd_seg_confusion(hip.ptr(s), Ctot, hip.ptr(labels.to(dev)), B, H, W, h, w, Ctot, n, hip.ptr(hist),
+                                            hip.ptr(pred), hip.stream()), "ucd_seg_confusion")
+    assert torch.equal(pred.cpu(), pred_ref)
+    r, ro = m.get_results(), None
+    om.update(labels.numpy(), pred_ref.numpy())
+    ro = om.get_results()
+    assert r["Mean IoU"] == pytest.approx(ro["Mean IoU"], rel=1e-12)

@@ -236,6 +236,73 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   }
 }
 
+// ---- validation: up-sampling + arg-max + confusion matrix ---------------------------------------
+// The reference's validation (train.py:242-246, metrics/stream_metrics.py:44-47,65-71) up-samples the logits, takes
+// outputs.max(dim=1), copies predictions and labels to the host and runs a numpy bincount per image.  Here a block owns a
+// 32 x 64 pixel tile like the loss kernel: the low-resolution cells under it are staged in LDS, every pixel's logits are
+// interpolated in registers (the same arithmetic as above = torch's), the first maximum wins (torch.max's tie rule), and
+// (label, prediction) pairs with 0 <= label < n are counted in an LDS histogram (n <= 64) or straight in global memory,
+// as integers: the matrix is exact and order-independent.  pred (optional) receives the arg-max map.
+__global__ __launch_bounds__(kThreads) void seg_confusion_kernel(const float* __restrict__ sem, int ld_s,
+                                                                const int64_t* __restrict__ labels, int H, int W, int h, int w,
+                                                                int Ctot, int n_classes, float scale_h, float scale_w,
+                                                                unsigned long long* __restrict__ hist, int use_lds_hist,
+                                                                int64_t* __restrict__ pred) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.z, ty0 = blockIdx.y * kTileY, tx0 = blockIdx.x * kTileX;
+  int ya, yb, xa, xb, dummy;
+  float f0, f1;
+  up_src(ty0, h, scale_h, ya, dummy, f0, f1);
+  up_src(min(ty0 + kTileY, H) - 1, h, scale_h, dummy, yb, f0, f1);
+  up_src(tx0, w, scale_w, xa, dummy, f0, f1);
+  up_src(min(tx0 + kTileX, W) - 1, w, scale_w, dummy, xb, f0, f1);
+  const int ny = yb - ya + 1, nx = xb - xa + 1, ncell = ny * nx;
+  float* s_log = smem;                                          // [ncell][Ctot]
+  unsigned int* l_hist = reinterpret_cast<unsigned int*>(s_log + ncell * Ctot);   // [n][n] when use_lds_hist
+  for (int i = threadIdx.x; i < ncell * Ctot; i += kThreads) {
+    const int cell = i / Ctot, c = i - cell * Ctot;
+    const int cy = ya + cell / nx, cx = xa + cell % nx;
+    s_log[i] = sem[((size_t)(b * h + cy) * w + cx) * ld_s + c];
+  }
+  if (use_lds_hist)
+    for (int i = threadIdx.x; i < n_classes * n_classes; i += kThreads) l_hist[i] = 0u;
+  __syncthreads();
+  const int X = tx0 + (threadIdx.x & 63);
+  int x0 = 0, x1 = 0;
+  float lx0 = 0.f, lx1 = 0.f;
+  if (X < W) up_src(X, w, scale_w, x0, x1, lx0, lx1);
+  for (int it = 0; it < kRows; ++it) {
+    const int Y = ty0 + (threadIdx.x >> 6) * kRows + it;
+    if (X >= W || Y >= H) continue;
+    int y0, y1;
+    float ly0, ly1;
+    up_src(Y, h, scale_h, y0, y1, ly0, ly1);
+    const int c00 = (y0 - ya) * nx + (x0 - xa), c01 = (y0 - ya) * nx + (x1 - xa);
+    const int c10 = (y1 - ya) * nx + (x0 - xa), c11 = (y1 - ya) * nx + (x1 - xa);
+    float best = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < Ctot; ++c) {
+      const float z = ly0 * (lx0 * s_log[c00 * Ctot + c] + lx1 * s_log[c01 * Ctot + c]) +
+                      ly1 * (lx0 * s_log[c10 * Ctot + c] + lx1 * s_log[c11 * Ctot + c]);
+      if (z > best) { best = z; arg = c; }
+    }
+    const size_t pix = ((size_t)b * H + Y) * W + X;
+    if (pred) pred[pix] = arg;
+    const int64_t lab = labels[pix];
+    if (lab >= 0 && lab < n_classes && arg < n_classes) {
+      if (use_lds_hist) atomicAdd(&l_hist[(int)lab * n_classes + arg], 1u);
+      else atomicAdd(&hist[(size_t)lab * n_classes + arg], 1ull);
+    }
+  }
+  if (use_lds_hist) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_classes * n_classes; i += kThreads) {
+      const unsigned int v = l_hist[i];
+      if (v) atomicAdd(&hist[i], (unsigned long long)v);
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void seg_losses_reduce_kernel(const float* __restrict__ part, int n, float inv_pix,
                                                                 float* __restrict__ out) {
   __shared__ double red[2][16];
@@ -298,6 +365,25 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   int rc = check_launch(fn);
   if (rc) return rc;
   seg_losses_reduce_kernel<<<1, 1024, 0, s>>>(part, B * tiles_x * tiles_y, inv_pix, loss_out);
+  return check_launch(fn);
+}
+
+int ucd_seg_confusion(const float* sem, int ld_s, const int64_t* labels, int B, int H, int W, int h, int w, int Ctot,
+                      int n_classes, int64_t* hist, int64_t* pred, ucd_stream_t stream) {
+  static const char* fn = "ucd_seg_confusion";
+  UCD_REQUIRE(sem && labels && hist, UCD_EINVAL, "%s: NULL argument", fn);
+  UCD_REQUIRE(B > 0 && H > 0 && W > 0 && h > 0 && w > 0 && Ctot > 0 && n_classes > 0 && ld_s >= Ctot, UCD_EINVAL, "%s: bad sizes", fn);
+  UCD_REQUIRE((float)H / h >= 4.f && (float)W / w >= 4.f, UCD_EUNSUPPORTED,
+              "%s: built for up-sampling factors >= 4 (the model's is 16)", fn);
+  const int tiles_x = ceil_div(W, kTileX), tiles_y = ceil_div(H, kTileY);
+  const int ny = (int)(kTileY * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
+  const int use_lds_hist = n_classes <= 64;
+  const size_t lds = ((size_t)ny * nx * Ctot) * sizeof(float) + (use_lds_hist ? (size_t)n_classes * n_classes * 4 : 0);
+  UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
+  UCD_TRY_LDS(seg_confusion_kernel, 150 * 1024);
+  seg_confusion_kernel<<<dim3(tiles_x, tiles_y, B), kThreads, lds, (hipStream_t)stream>>>(
+      sem, ld_s, labels, H, W, h, w, Ctot, n_classes, (float)h / (float)H, (float)w / (float)W, (unsigned long long*)hist,
+      use_lds_hist, pred);
   return check_launch(fn);
 }
 

@@ -107,6 +107,7 @@ SIGNATURES = {
     "ucd_pixcon_loss": (_i, [_p, _i, _i, _p, _p, _i, _i, _p, _p, _i, _p, _i, _f, _i, _i, _p, _p, _i, _p, _p, _z, _p]),
     "ucd_pixcon_loss_given_p": (_i, [_p, _i, _i, _p, _p, _i, _p, _i, _f, _i, _p, _p, _i, _p, _p, _z, _p]),
     "ucd_pixcon_scatter_grad": (_i, [_p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "ucd_seg_confusion": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p, _p, _p]),
     "ucd_seg_losses_workspace_bytes": (_z, [_i, _i, _i]),
     "ucd_seg_losses": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _p, _i, _p, _z, _p]),
 }

@@ -3,8 +3,9 @@
 Mirror of the reference's ``metrics/stream_metrics.py:34-122`` (``StreamSegMetrics``: same methods, same result keys and
 arithmetic), which builds the matrix with a numpy ``bincount`` per image on the host after copying the full-resolution
 predictions over PCIe (``train.py:242-246``).  Here ``update`` takes device tensors (labels and arg-max predictions of the
-whole batch) and adds one ``bincount`` of the batch to a device-resident [n, n] matrix; the host sees numbers only in
-``get_results``.  ``synch`` reduces matrix and sample count to rank 0 like the reference.  The matplotlib rendering of the
+whole batch) and adds one ``bincount`` of the batch to a device-resident [n, n] matrix; ``update_from_logits`` goes one
+step further and takes the model's LOW-resolution logits: up-sampling, arg-max and histogram are one HIP kernel, the
+full-resolution logits never exist.  The host sees numbers only in ``get_results``.  ``synch`` reduces matrix and sample count to rank 0 like the reference.  The matplotlib rendering of the
 confusion matrix (``confusion_matrix_to_fig``) is out of scope.
 """
 from __future__ import annotations
@@ -31,6 +32,24 @@ class StreamSegMetrics:
         mask = (lt >= 0) & (lt < n)                                            # stream_metrics.py:65
         idx = n * lt[mask].long() + lp[mask].long()
         hist = torch.bincount(idx, minlength=n * n).reshape(n, n).double()
+        self.confusion_matrix = hist if self.confusion_matrix is None else self.confusion_matrix + hist
+
+    def update_from_logits(self, label_trues, sem):
+        """``update(labels, upsample(sem).argmax(1))`` without the full-resolution logits: bilinear up-sampling, arg-max and
+        the histogram in one kernel (``ucd_seg_confusion``; ``sem`` = the model's low-resolution logits [B, Ctot, h, w])."""
+        from . import hip
+        B, Ctot, h, w = sem.shape
+        H, W = label_trues.shape[-2:]
+        n = self.n_classes
+        s = sem.detach().permute(0, 2, 3, 1).reshape(B * h * w, Ctot).float().contiguous()
+        lab = label_trues.contiguous()
+        if lab.dtype != torch.int64:
+            lab = lab.long()
+        hist = torch.zeros(n, n, dtype=torch.int64, device=sem.device)
+        hip._check(hip.load().ucd_seg_confusion(hip.ptr(s), Ctot, hip.ptr(lab), B, H, W, h, w, Ctot, n, hip.ptr(hist), None,
+                                                hip.stream()), "ucd_seg_confusion")
+        self.total_samples += B
+        hist = hist.double()
         self.confusion_matrix = hist if self.confusion_matrix is None else self.confusion_matrix + hist
 
     def synch(self, device):

@@ -248,10 +248,19 @@ class Trainer:
             for images, labels in loader:
                 images = images.to(dev, dtype=torch.float32)
                 labels = labels.to(dev, dtype=torch.long)
-                with self._autocast():
-                    outputs, _ = model(images, ret_intermediate=False)
-                class_loss += self.criterion(outputs.float(), labels.clone()).mean()
-                metrics.update(labels, outputs.argmax(dim=1))
+                if self.fuse_logit_losses and hasattr(metrics, "update_from_logits"):
+                    # low-resolution logits only: loss and confusion matrix come from the fused kernels (the reference
+                    # up-samples, copies predictions to the host and histograms there, train.py:236-246)
+                    with self._autocast():
+                        _, feats = model(images, ret_intermediate=False, upsample=False)
+                    sem = feats["sem"]
+                    class_loss += fused_seg_losses(sem, None, labels, self.old_classes if self.unce else 1, 1.0, 0.0)[1]
+                    metrics.update_from_logits(labels, sem)
+                else:
+                    with self._autocast():
+                        outputs, _ = model(images, ret_intermediate=False)
+                    class_loss += self.criterion(outputs.float(), labels.clone()).mean()
+                    metrics.update(labels, outputs.argmax(dim=1))
                 n += 1
             metrics.synch(dev)
             score = metrics.get_results()
