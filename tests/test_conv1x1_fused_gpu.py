@@ -285,3 +285,45 @@ def test_conv_abn_python_twin_equals_cpp_node():
             assert torch.equal(a, b), i
         else:   # the node folds the shortcut's gradient into the GEMM (one rounding), the twin leaves the add to autograd (two)
             assert _rel(a, b.float()) < 1e-2
+
+
+@pytest.mark.parametrize("B,K,N,H,W,d", [(2, 64, 64, 9, 11, 1), (3, 128, 192, 17, 13, 2), (2, 256, 128, 33, 33, 6), (1, 64, 64, 5, 5, 12),
+                                         (2, 64, 256, 16, 8, 18)])
+def test_conv3x3_implicit_gemm_mode(B, K, N, H, W, d):
+    """taps = 9: the same kernel as a 3x3 convolution (stride 1, padding = dilation; modules/residual.py:69, the ASPP branches
+    of modules/deeplab.py:27-29) against F.conv2d in fp32 on the same bf16 operands: exact on small integers (tap shifts,
+    zero padding, dilation larger than the map, tile edges), bf16-rounding close on random data, statistics / affine
+    epilogues, and the input gradient as the same call on the flipped + transposed weight."""
+    from ucd_amd import hip
+    cl = torch.channels_last
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0] * t.shape[2] * t.shape[3], t.shape[1])
+    wrow = lambda w: w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1])
+    g = torch.Generator(DEV).manual_seed(K + H)
+    xi = torch.randint(-3, 4, (B, K, H, W), device=DEV, generator=g).bfloat16().contiguous(memory_format=cl)
+    wi = torch.randint(-2, 3, (N, K, 3, 3), device=DEV, generator=g).bfloat16().contiguous(memory_format=cl)
+    y = torch.empty(B, N, H, W, device=DEV, dtype=torch.bfloat16).contiguous(memory_format=cl)
+    hip.conv1x1(rows(xi), wrow(wi), rows(y), conv3=(H, W, d))
+    exact = F.conv2d(xi.float(), wi.float(), None, 1, d, d)
+    assert torch.equal(y.float(), exact.bfloat16().float())
+    x = (torch.randn(B, K, H, W, device=DEV, generator=g) * 1.2 + 0.1).bfloat16().contiguous(memory_format=cl)
+    w = (torch.randn(N, K, 3, 3, device=DEV, generator=g) * (2.0 / (9 * K)) ** 0.5).bfloat16().contiguous(memory_format=cl)
+    ref = F.conv2d(x.float(), w.float(), None, 1, d, d)
+    M = B * H * W
+    part = torch.full((hip.conv1x1_row_tiles(M), 3, N), float("nan"), device=DEV)
+    hip.conv1x1(rows(x), wrow(w), rows(y), conv3=(H, W, d), out_mode=2, partial=part)
+    assert _rel(y, ref) < 3e-3
+    buf = torch.zeros(6 * N, device=DEV)
+    hip.conv1x1_stats_finalize(part, M, N, None, None, None, 0.1, 1e-5, buf)
+    yf = rows(y).float()
+    torch.testing.assert_close(buf[3 * N:4 * N], yf.mean(0), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(buf[4 * N:5 * N], 1 / torch.sqrt(yf.var(0, unbiased=False) + 1e-5), rtol=1e-4, atol=1e-6)
+    om, osc, osh = torch.randn(N, device=DEV, generator=g) * 0.3, torch.rand(N, device=DEV, generator=g) + 0.5, torch.randn(N, device=DEV, generator=g) * 0.2
+    hip.conv1x1(rows(x), wrow(w), rows(y), conv3=(H, W, d), out_mode=1, out_norm=(om, osc, osh, None, hip.ACT_LEAKY_RELU, 0.01))
+    assert _rel(y, F.leaky_relu((ref - om.view(1, -1, 1, 1)) * osc.view(1, -1, 1, 1) + osh.view(1, -1, 1, 1), 0.01)) < 3e-3
+    # input gradient
+    dy = torch.randn(B, N, H, W, device=DEV, generator=g).bfloat16().contiguous(memory_format=cl)
+    wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=cl)
+    dx = torch.empty_like(x)
+    hip.conv1x1(rows(dy), wrow(wt), rows(dx), conv3=(H, W, d))
+    refdx = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), 1, d, d)
+    assert _rel(dx, refdx) < 3e-3

@@ -56,6 +56,7 @@ struct Args {
   int accumulate;
   int tiles_m, tiles_n;
   int param_off;     // byte offset of the input-transform constants in LDS
+  int iH, iW, dil;   // CONV3: spatial size of the [B, H, W, K] map behind A and the dilation (= padding) of the 3x3 taps
 };
 
 // The fused transforms take leaky_relu(slope) only; identity arrives as slope = 1 (elu layers keep the separate ABN
@@ -78,7 +79,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // {fill the stage: global_load_lds for W (and for A when it needs no transform), registers + transform for A otherwise;
 // wait; barrier; 16 MFMAs per wave; barrier}, and the memory latency of one workgroup's fill is covered by the MFMAs of
 // the three others - 128 KB of loads in flight per CU with no software pipeline for the compiler to undo.
-template <int BN, bool PRO, int OUT>
+// CONV3: the same kernel as an implicit-GEMM 3x3 convolution (stride 1, padding = dilation): the K loop runs over the 9
+// taps x K/64 steps, the A tile of tap (kh, kw) is the row tile shifted by ((kh-1) d, (kw-1) d) pixels - with LDS-DMA the
+// source address is per lane, so the shift and the zero padding (lanes outside the map fetch a 16-byte zero constant) are
+// free; W is the channels-last 4-D weight [N][kh][kw][K] read as 9 [N][K] slices (row pitch 9 K).
+__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
+
+template <int BN, bool PRO, int OUT, bool CONV3 = false>
 __global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) void conv1x1_kernel(Args p) {
   constexpr int WN = BN / 2;           // columns per wave
   constexpr int TN = WN / 32;          // 32-wide accumulator tiles per wave along N
@@ -111,10 +118,21 @@ __global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) v
   constexpr int CA = 4, CB = BN / 32;                  // chunks per wave: A 16 chunks, B BN/8 chunks, 4 waves
   const bf16* ga[CA];
   const bf16* gb[CB];
+  int py[CA], px[CA], pimg[CA], pslot[CA];              // CONV3: pixel coordinates of this lane's staged rows
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
     const int row = 8 * (wave * CA + i) + (lane >> 3);
-    ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    const int slot = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
+    ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + slot;
+    if (CONV3) {
+      const int m = m0 + row, hw = p.iH * p.iW;
+      const int mm = min(m, p.M - 1);
+      const int b = mm / hw, rem = mm - b * hw;
+      py[i] = m < p.M ? rem / p.iW : -(1 << 20);           // rows past M: never inside the map -> zeros
+      px[i] = rem - (rem / p.iW) * p.iW;
+      pimg[i] = b * hw;
+      pslot[i] = slot;
+    }
   }
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
@@ -138,14 +156,17 @@ __global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) v
   }
   const unsigned char* afrag = As + 0;                 // fragment bases resolved per read (swizzled)
   const int fr = lane & 31, fh = lane >> 5;
-  const int nk = p.K / kBK;
+  const int kpt = p.K / kBK;                           // K steps per tap
+  const int nk = CONV3 ? 9 * kpt : kpt;
   uint4 ra[4];
   if (PRO) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i]);
   }
   for (int kb = 0; kb < nk; ++kb) {
-    const int k0 = kb * kBK;
+    const int tap = CONV3 ? kb / kpt : 0;
+    const int k0 = (kb - tap * kpt) * kBK;
+    const int wk0 = CONV3 ? tap * p.K + k0 : k0;       // column offset inside a weight row (pitch 9 K)
     if (kb) __syncthreads();                           // the previous step's fragment reads are done
     if (PRO) {
 #pragma unroll
@@ -176,12 +197,24 @@ __global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) v
       for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i] + kn);
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
+      if (CONV3) {
+        const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
 #pragma unroll
-      for (int i = 0; i < CA; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + k0), (lptr_t)(As + (wave * CA + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < CA; ++i) {
+          const int yy = py[i] + dy, xx = px[i] + dx;
+          const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
+          const bf16* src = ok ? p.A + (size_t)(pimg[i] + yy * p.iW + xx) * p.lda + pslot[i] + k0
+                               : reinterpret_cast<const bf16*>(&g_zero16);
+          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * CA + i) * 1024), 16, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < CA; ++i)
+          __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + k0), (lptr_t)(As + (wave * CA + i) * 1024), 16, 0, 0);
+      }
 #pragma unroll
       for (int i = 0; i < CB; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + k0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + wk0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
     }
     if (!PRO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of the A tile have landed
@@ -565,6 +598,11 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   UCD_REQUIRE(d && d->a && d->w && d->y, UCD_EINVAL, "%s: NULL operand", fn);
   UCD_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, UCD_EINVAL, "%s: empty product", fn);
   UCD_REQUIRE(d->K % kBK == 0 && d->N % 64 == 0, UCD_EUNSUPPORTED, "%s: K (%d) and N (%d) must be multiples of 64", fn, d->K, d->N);
+  const bool conv3 = d->taps == 9;
+  UCD_REQUIRE(d->taps == 0 || d->taps == 1 || conv3, UCD_EINVAL, "%s: taps must be 1 (1x1) or 9 (3x3)", fn);
+  UCD_REQUIRE(!conv3 || (d->H > 0 && d->W > 0 && d->dilation >= 1 && (long long)d->M % ((long long)d->H * d->W) == 0 &&
+                         d->ldw >= 9 * d->K && !d->in_scale && d->out_mode <= 2),
+              UCD_EINVAL, "%s: 3x3 mode needs H, W, dilation, M = B*H*W, ldw >= 9 K, no input transform, out_mode <= 2", fn);
   UCD_REQUIRE(aligned16(d->a) && aligned16(d->w) && aligned16(d->y) && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldy % 8 == 0 &&
                   d->lda >= d->K && d->ldw >= d->K && d->ldy >= d->N,
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
@@ -587,6 +625,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   a.R = (const bf16*)d->residual; a.ldr = d->ldr;
   a.out_act = d->out_act & UCD_ACT_MASK; a.out_slope = a.out_act == UCD_ACT_IDENTITY ? 1.f : d->out_slope;
   a.partial = d->partial; a.accumulate = d->accumulate;
+  a.iH = d->H; a.iW = d->W; a.dil = d->dilation;
   const int BN = d->N % 128 == 0 ? 128 : 64;
   a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
   const int grid = ceil_div(a.tiles_m, 8) * 8 * a.tiles_n;
@@ -610,11 +649,20 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
     case 2: UCD_C1_LAUNCH(BNV, PROV, 2) break;                                  \
     default: UCD_C1_LAUNCH(BNV, PROV, 3) break;                                 \
   }
-  if (BN == 128) {
+#define UCD_C3_OUT(BNV)                                                                        \
+  switch (d->out_mode) {                                                                       \
+    case 0: conv1x1_kernel<BNV, false, 0, true><<<grid, kThreads, lds, s>>>(a); break;         \
+    case 1: conv1x1_kernel<BNV, false, 1, true><<<grid, kThreads, lds, s>>>(a); break;         \
+    default: conv1x1_kernel<BNV, false, 2, true><<<grid, kThreads, lds, s>>>(a); break;        \
+  }
+  if (conv3) {
+    if (BN == 128) { UCD_C3_OUT(128) } else { UCD_C3_OUT(64) }
+  } else if (BN == 128) {
     if (pro) { UCD_C1_OUT(128, true) } else { UCD_C1_OUT(128, false) }
   } else {
     if (pro) { UCD_C1_OUT(64, true) } else { UCD_C1_OUT(64, false) }
   }
+#undef UCD_C3_OUT
 #undef UCD_C1_OUT
 #undef UCD_C1_LAUNCH
   return check_launch(fn);

@@ -45,7 +45,8 @@ class Conv1x1Desc(C.Structure):
                 ("in_slope", C.c_float), ("out_mode", C.c_int),
                 ("out_mean", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p), ("out_invstd", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("out_act", C.c_int), ("out_slope", C.c_float),
-                ("partial", C.c_void_p), ("accumulate", C.c_int)]
+                ("partial", C.c_void_p), ("accumulate", C.c_int),
+                ("taps", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dilation", C.c_int)]
 
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -496,15 +497,19 @@ def attmap(x, ld_x, y, ld_y, B, HW, Cc):
 # ---------------------------------------------------------------------------------------------
 # 1x1 convolutions as fused GEMMs (csrc/conv1x1.hip)
 # ---------------------------------------------------------------------------------------------
-def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, partial=None, accumulate=False):
+def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, partial=None, accumulate=False, conv3=None):
     """y[M, N] = out(in(a)[M, K] . w[N, K]^T).  ``in_norm`` = (mean, scale, shift, act, slope) of the producer's ABN or None;
-    ``out_norm`` = (mean, scale, shift, invstd, act, slope) for out_mode 1 / 3.  All 2-D bf16 row matrices."""
+    ``out_norm`` = (mean, scale, shift, invstd, act, slope) for out_mode 1 / 3.  All 2-D bf16 row matrices.
+    ``conv3 = (H, W, dilation)``: 3x3 convolution (stride 1, padding = dilation) of the [B, H, W, K] map behind ``a`` with the
+    channels-last weight ``w`` given as its [N, 9 K] row matrix."""
     lib = load()
     d = Conv1x1Desc()
     M, K = a.shape
     N = w.shape[0]
     d.a, d.lda, d.w, d.ldw, d.y, d.ldy = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0)
     d.M, d.N, d.K = M, N, K
+    if conv3 is not None:
+        d.taps, d.H, d.W, d.dilation = 9, int(conv3[0]), int(conv3[1]), int(conv3[2])
     if in_norm is not None:
         mean, scale, shift, act, slope = in_norm
         d.in_mean, d.in_scale, d.in_shift, d.in_act, d.in_slope = ptr(mean), ptr(scale), ptr(shift), act & ACT_MASK, slope
@@ -518,7 +523,7 @@ def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, par
     d.partial = ptr(partial)
     d.accumulate = 1 if accumulate else 0
     work = 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)))
-    with _timed("ucd_conv1x1", work):
+    with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work):
         _check(lib.ucd_conv1x1(C.byref(d), stream()), "ucd_conv1x1")
     return y
 
