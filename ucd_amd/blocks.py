@@ -268,13 +268,23 @@ def _own_gemm_with_stats(K, N):
     return not (K * N >= (1 << 20) and K >= 1024)
 
 
+def _own_conv3x3(M, K, N):
+    """The implicit-GEMM 3x3 (csrc/conv1x1.hip, taps = 9) instead of MIOpen: measured on MI355X (tools/conv3x3_probe.py,
+    B = 24): 256->256 at 33^2 52 vs 56 us, 128->128 at 65^2 49 vs 52, 64->64 at 129^2 58 vs 62, the ASPP branches 334-357 vs
+    377-384 - and the following ABN's statistics for +1 us instead of a separate pass; MIOpen keeps the 512->512 layers
+    (137 vs 168 us) and maps too small to give every CU a tile (3 images per GPU: 23 vs 36 us)."""
+    tiles = ((M + 127) // 128) * max(1, N // 128)
+    return tiles >= 256 and not (K >= 512 and N >= 512)
+
+
 class _ConvABNFunction(torch.autograd.Function):
     """Python twin of csrc/abn_node.cpp::ConvABNTrainNode (single process; the node adds the SyncBN exchange and the
     shortcut fold): z = x . w^T with the statistics in the GEMM epilogue -> finalize -> y = act(norm(z) [+ residual]).
     The complete implementation and the fallback; bench.py's instrumented pass runs it (every library call visible)."""
 
     @staticmethod
-    def forward(ctx, x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, fused):
+    def forward(ctx, x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, fused, dilation=0,
+                wflip=None, own_dgrad=False):
         from . import hip
         B, K, H, W = x.shape
         N = w4.shape[0]
@@ -283,10 +293,16 @@ class _ConvABNFunction(torch.autograd.Function):
         z = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         y = torch.empty_like(z)
         buf = torch.empty(6 * N, dtype=torch.float32, device=x.device)
-        w2 = w4.reshape(N, K)
-        if fused:
+        conv3 = dilation > 0
+        w2 = w4.permute(0, 2, 3, 1).reshape(N, 9 * K) if conv3 else w4.reshape(N, K)
+        ctx.conv3 = (dilation, wflip, own_dgrad)
+        if conv3 and not fused:
+            z = F.conv2d(x, w4, None, 1, dilation, dilation).contiguous(memory_format=torch.channels_last)
+            hip.abn_forward(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, weight, bias, running_mean,
+                            running_var, momentum, eps, True, buf, None, act, slope)
+        elif fused:
             part = torch.empty(hip.conv1x1_row_tiles(M), 3, N, dtype=torch.float32, device=x.device)
-            hip.conv1x1(rows(x), w2, rows(z), out_mode=2, partial=part)
+            hip.conv1x1(rows(x), w2, rows(z), out_mode=2, partial=part, conv3=(H, W, dilation) if conv3 else None)
             hip.conv1x1_stats_finalize(part, M, N, weight, running_mean, running_var, momentum, eps, buf, None, act)
             hip.abn_apply(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, buf[3 * N:4 * N], buf[5 * N:],
                           bias, act, slope)
@@ -314,6 +330,21 @@ class _ConvABNFunction(torch.autograd.Function):
         sums = torch.empty(2 * N, dtype=torch.float32, device=x.device)
         hip.abn_backward(z, N, dy, N, y, N if y is not None else 0, dz, N, dres, N if has_res else 0, M, N, None, HW,
                          buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:], bias, weight, sums, float(M), True, True, act, slope)
+        dilation, wflip, own_dgrad = ctx.conv3
+        if dilation > 0:
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                if wflip is None:
+                    wflip = w4.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
+                if own_dgrad:
+                    dx = torch.empty_like(x)
+                    hip.conv1x1(rows(dz), wflip.permute(0, 2, 3, 1).reshape(K, 9 * N), rows(dx), conv3=(H, W, dilation))
+                else:
+                    dx = F.conv2d(dz, wflip, None, 1, dilation, dilation)
+            if ctx.needs_input_grad[1]:
+                dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [dilation, dilation], [dilation, dilation],
+                                                         False, [0, 0], 1, [False, True, False])[1]
+            return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None
         w2 = w4.reshape(N, K)
         dx = dw = None
         if ctx.needs_input_grad[0]:
@@ -324,7 +355,7 @@ class _ConvABNFunction(torch.autograd.Function):
             dzr, xr = rows(dz), rows(x)
             dw = (torch.bmm(dzr.view(S, M // S, N).transpose(1, 2), xr.view(S, M // S, K)).sum(0) if S > 1 else dzr.t() @ xr)
             dw = dw.as_strided(w4.shape, w4.stride())
-        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None
+        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None
 
 
 def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_param=None, with_skip=False):
@@ -333,10 +364,25 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     pair is not eligible (the caller then runs the modules one after the other), else ``y`` or ``(y, shortcut alias of x)``."""
     if os.environ.get("UCD_FUSED_CONV1X1", "1") == "0":
         return None
-    if not (isinstance(conv, Conv1x1) and conv.as_gemm and conv.bias is None and conv.weight.requires_grad and _is_fused_abn(bn)
-            and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda and x.dim() == 4
-            and x.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
+    is3 = isinstance(conv, Conv3x3)
+    if not ((is3 or (isinstance(conv, Conv1x1) and conv.as_gemm)) and conv.bias is None and conv.weight.requires_grad
+            and _is_fused_abn(bn) and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda
+            and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
         return None
+    dilation, wflip, fused, own_dgrad = 0, None, None, False
+    if is3:
+        if not (conv.stride == (1, 1) and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1]
+                and conv.groups == 1 and not with_skip and conv.weight.is_contiguous(memory_format=torch.channels_last)):
+            return None
+        M = x.shape[0] * x.shape[2] * x.shape[3]
+        dilation = conv.dilation[0]
+        fused = _own_conv3x3(M, conv.in_channels, conv.out_channels)
+        own_dgrad = _own_conv3x3(M, conv.out_channels, conv.in_channels)
+        if not fused and not own_dgrad:
+            return None                         # nothing of ours to gain: the module path (MIOpen + ABN node) stays
+        wflip = conv._w16_flip if conv.working_weight() is not None else None
+    else:
+        fused = _own_gemm_with_stats(conv.in_channels, conv.out_channels)
     from . import abn as _abn
     from . import hip
     node = _gemm_node()
@@ -353,7 +399,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         slope = bn.activation_param if activation_param is None else activation_param
         bn.__dict__.pop("_eval_cache", None)
         y = _ConvABNFunction.apply(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                   act, slope, _own_gemm_with_stats(conv.in_channels, conv.out_channels))
+                                   act, slope, fused, dilation, wflip, own_dgrad)
         return (y, x) if with_skip else y
     if not node.dense_channels_last(x):
         return None
@@ -373,7 +419,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     bn.__dict__.pop("_eval_cache", None)
     out = node.conv_abn_train(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
                               slope, comm.handle if comm is not None else 0, world, _hip_stream(), bn._direct_grad_ptr(),
-                              bool(with_skip), _own_gemm_with_stats(conv.in_channels, conv.out_channels))
+                              bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad))
     return (out[0], out[1]) if with_skip else out[0]
 
 
@@ -477,7 +523,20 @@ class ResidualBlock(nn.Module):
         xr = rows(x)
         h1 = torch.empty((B, c.conv1.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
         hip.conv1x1(xr, w2d(c.conv1, x), rows(h1), out_mode=1, out_norm=self._eval_norm(c.bn1))
-        h2 = c.bn2(c.conv2(h1))                                    # in place under no_grad (InPlaceABN contract)
+        cv = c.conv2
+        if (isinstance(cv, Conv3x3) and cv.stride == (1, 1) and cv.padding == cv.dilation and cv.bias is None
+                and cv.in_channels % 64 == 0 and cv.out_channels % 64 == 0
+                and _own_conv3x3(B * H * W, cv.in_channels, cv.out_channels)):
+            w3 = cv.working_weight()
+            if w3 is None:
+                w3 = cv.weight.to(x.dtype)
+            if not w3.is_contiguous(memory_format=cl):
+                w3 = w3.contiguous(memory_format=cl)
+            h2 = torch.empty((B, cv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
+            hip.conv1x1(rows(h1), w3.permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * cv.in_channels), rows(h2), out_mode=1,
+                        out_norm=self._eval_norm(c.bn2), conv3=(H, W, cv.dilation[0]))       # conv2 + bn2: one kernel
+        else:
+            h2 = c.bn2(c.conv2(h1))                                # in place under no_grad (InPlaceABN contract)
         if hasattr(self, "proj_conv"):
             if isinstance(self.proj_conv, Conv1x1) and self.proj_conv.in_channels % 64 == 0:
                 res = torch.empty((B, self.proj_conv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
@@ -515,7 +574,9 @@ class ResidualBlock(nn.Module):
             first = _conv_abn_train(c.conv1, c.bn1, x, with_skip=skip)
             if first is not None:
                 h1, res = first if skip else (first, residual)
-                h2 = c.bn2(c.conv2(h1))
+                h2 = _conv_abn_train(c.conv2, c.bn2, h1)      # 3x3 as implicit GEMM + statistics (stride-1 layers)
+                if h2 is None:
+                    h2 = c.bn2(c.conv2(h1))
                 out = _conv_abn_train(c.conv3, c.bn3, h2, residual=res, activation=act, activation_param=slope)
                 if out is None:
                     out = c.bn3(c.conv3(h2), residual=res, activation=act, activation_param=slope)
@@ -527,11 +588,18 @@ class ResidualBlock(nn.Module):
                 first = _conv1_with_skip(self.convs.conv1, x)
                 if first is not None:
                     h, residual = first
+            bn2_done = False
             for name, mod in self.convs.named_children():
                 if mod is last:
                     h = mod(h, residual=residual, activation=act, activation_param=slope)
                 elif first is not None and name == "conv1":
                     continue                                   # already applied together with the shortcut
+                elif name == "conv2" and self.training and hasattr(self.convs, "bn2") and self.convs.bn2 is not last:
+                    y = _conv_abn_train(mod, self.convs.bn2, h)   # narrow blocks: the 3x3 + its ABN as one node
+                    bn2_done = y is not None
+                    h = y if bn2_done else mod(h)
+                elif name == "bn2" and bn2_done:
+                    continue
                 else:
                     h = mod(h)
             return h

@@ -345,11 +345,18 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
   static variable_list forward(AutogradContext* ctx, at::Tensor x, at::Tensor w4, at::Tensor weight, at::Tensor bias,
                                c10::optional<at::Tensor> residual_, at::Tensor running_mean, at::Tensor running_var,
                                double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
-                               int64_t stream, int64_t param_grad, bool with_skip, bool fused) {
+                               int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
+                               c10::optional<at::Tensor> wflip_, bool own_dgrad) {
+    // dilation = 0: 1x1 convolution; dilation >= 1: 3x3, stride 1, padding = dilation (implicit GEMM, taps = 9), weight in
+    // channels-last memory order; wflip = w.flip(2, 3).transpose(0, 1) (channels-last) for the input gradient
     TORCH_CHECK(dense_channels_last(x) && x.scalar_type() == at::kBFloat16, "ucd conv+abn node: x must be dense channels-last bf16");
-    TORCH_CHECK(w4.dim() == 4 && w4.scalar_type() == at::kBFloat16 && w4.size(1) == x.size(1) && w4.size(2) == 1 &&
-                    w4.size(3) == 1 && w4.is_contiguous(),
-                "ucd conv+abn node: weight [Co, Ci, 1, 1] bf16 expected");
+    const bool conv3 = dilation > 0;
+    TORCH_CHECK(w4.dim() == 4 && w4.scalar_type() == at::kBFloat16 && w4.size(1) == x.size(1) &&
+                    (conv3 ? (w4.size(2) == 3 && w4.size(3) == 3 && w4.is_contiguous(at::MemoryFormat::ChannelsLast))
+                           : (w4.size(2) == 1 && w4.size(3) == 1 && w4.is_contiguous())),
+                "ucd conv+abn node: weight [Co, Ci, 1, 1] (contiguous) or [Co, Ci, 3, 3] (channels-last) bf16 expected");
+    TORCH_CHECK(!(conv3 && with_skip), "ucd conv+abn node: the shortcut fold belongs to the 1x1 layers");
+    at::Tensor wflip = wflip_.has_value() ? *wflip_ : at::Tensor();
     at::Tensor residual = residual_.has_value() ? *residual_ : at::Tensor();
     const bool has_res = residual.defined();
     const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0);
@@ -371,8 +378,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       float* partial = (float*)workspace(x, need > ws_bytes ? need : ws_bytes, stream);
       ucd_conv1x1_desc d;
       memset(&d, 0, sizeof(d));
-      d.a = x.data_ptr(); d.lda = (int)K; d.w = w4.data_ptr(); d.ldw = (int)K; d.y = z.data_ptr(); d.ldy = (int)N;
+      d.a = x.data_ptr(); d.lda = (int)K; d.w = w4.data_ptr(); d.ldw = (int)(conv3 ? 9 * K : K); d.y = z.data_ptr(); d.ldy = (int)N;
       d.M = (int)M; d.N = (int)N; d.K = (int)K; d.out_mode = 2; d.partial = partial;
+      if (conv3) { d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation; }
       check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
       if (!sync) {
         check(ucd_conv1x1_stats_finalize(partial, (int)M, (int)N, fptr(weight), running_mean.data_ptr<float>(),
@@ -395,10 +403,15 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
               "ucd_abn_sync_forward");
       }
     } else {
-      const size_t wsb = ucd_gemm_workspace_bytes();
-      check(ucd_gemm_bf16(0, (int)M, (int)N, (int)K, x.data_ptr(), (int)K, w4.data_ptr(), (int)K, z.data_ptr(), (int)N,
-                          workspace(x, wsb, stream, 1), wsb, 1, (ucd_stream_t)stream),
-            "ucd_gemm_bf16");
+      if (conv3) {
+        z = at::conv2d(x, w4, {}, {1, 1}, {dilation, dilation}, {dilation, dilation}, 1);
+        if (!dense_channels_last(z)) z = z.contiguous(at::MemoryFormat::ChannelsLast);
+      } else {
+        const size_t wsb = ucd_gemm_workspace_bytes();
+        check(ucd_gemm_bf16(0, (int)M, (int)N, (int)K, x.data_ptr(), (int)K, w4.data_ptr(), (int)K, z.data_ptr(), (int)N,
+                            workspace(x, wsb, stream, 1), wsb, 1, (ucd_stream_t)stream),
+              "ucd_gemm_bf16");
+      }
       void* ws = workspace(x, ws_bytes, stream);
       if (sync)
         check(ucd_abn_sync_forward_comm((ucd_comm_t)comm, (int)world, z.data_ptr(), (int)N, y.data_ptr(), (int)N, resp,
@@ -413,7 +426,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
               "ucd_abn_forward");
     }
     const bool needs_y = has_res && (act & UCD_ACT_MASK) != UCD_ACT_IDENTITY;
-    ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf});
+    ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf, wflip});
     ctx->saved_data["act"] = act;
     ctx->saved_data["slope"] = slope;
     ctx->saved_data["comm"] = comm;
@@ -422,6 +435,8 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     ctx->saved_data["has_res"] = has_res;
     ctx->saved_data["param_grad"] = param_grad;
     ctx->saved_data["with_skip"] = with_skip;
+    ctx->saved_data["dilation"] = dilation;
+    ctx->saved_data["own_dgrad"] = own_dgrad;
     if (with_skip) return {y, x};
     return {y};
   }
@@ -429,6 +444,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     auto saved = ctx->get_saved_variables();
     at::Tensor x = saved[0], w4 = saved[1], z = saved[2], y = saved[3], weight = saved[4], bias = saved[5], buf = saved[6];
+    at::Tensor wflip = saved[7];
+    const int64_t dilation = ctx->saved_data["dilation"].toInt();
+    const bool conv3 = dilation > 0, own_dgrad = ctx->saved_data["own_dgrad"].toBool();
     const int64_t act = ctx->saved_data["act"].toInt(), comm = ctx->saved_data["comm"].toInt();
     const int64_t world = ctx->saved_data["world"].toInt(), stream = ctx->saved_data["stream"].toInt();
     const double slope = ctx->saved_data["slope"].toDouble();
@@ -470,6 +488,29 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         if (!param_grad) { dbias = sums.narrow(0, 0, N); dweight = sums.narrow(0, N, N); }
       }
     }
+    if (conv3) {
+      // 3x3: input gradient = the same convolution on the flipped + transposed weight (own implicit GEMM, or MIOpen's
+      // FORWARD solver when the cached weight is missing / the map is too small to fill the chip); weight gradient: MIOpen
+      if (ctx->needs_input_grad(0) && dz.defined()) {
+        if (!wflip.defined()) wflip = w4.flip({2, 3}).transpose(0, 1).contiguous(at::MemoryFormat::ChannelsLast);
+        if (own_dgrad) {
+          dx = at::empty_like(x);
+          ucd_conv1x1_desc d;
+          memset(&d, 0, sizeof(d));
+          d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)(9 * N); d.y = dx.data_ptr(); d.ldy = (int)K;
+          d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0;
+          d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation;
+          check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
+        } else {
+          dx = at::conv2d(dz, wflip, {}, {1, 1}, {dilation, dilation}, {dilation, dilation}, 1);
+        }
+      }
+      if (ctx->needs_input_grad(1) && dz.defined())
+        dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {dilation, dilation}, {dilation, dilation}, false,
+                                                  {0, 0}, 1, {false, true, false}));
+      return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
+              none, none, none};
+    }
     const size_t wsb = ucd_gemm_workspace_bytes();
     void* gws = workspace(x, wsb, stream, 1);
     if (ctx->needs_input_grad(0)) {
@@ -509,16 +550,18 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       }
       dw = dw.as_strided(w4.sizes(), w4.strides());
     }
-    return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none};
+    return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
+            none, none, none};
   }
 };
 
 std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor weight, at::Tensor bias,
                                        c10::optional<at::Tensor> residual, at::Tensor running_mean, at::Tensor running_var,
                                        double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
-                                       int64_t stream, int64_t param_grad, bool with_skip, bool fused) {
+                                       int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
+                                       c10::optional<at::Tensor> wflip, bool own_dgrad) {
   return ConvABNTrainNode::apply(x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world,
-                                 stream, param_grad, with_skip, fused);
+                                 stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad);
 }
 
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,
