@@ -333,7 +333,10 @@ def test_conv3x3_implicit_gemm_mode(B, K, N, H, W, d):
 def test_residual_block_training_with_own_3x3(cin, chans, dil):
     """Training forward + backward with the 3x3 convolution + ABN as one node on the implicit-GEMM kernel (forward with the
     statistics epilogue, input gradient on the cached flipped weight) against the module path (MIOpen + separate ABN): wide and
-    narrow bottlenecks, B large enough for the own kernel to be chosen."""
+    narrow bottlenecks, B large enough for the own kernel to be chosen.  Both are bf16 implementations of the same block, so
+    the yardstick is the fp32 run of the block: the fused path must not be further from it than the module path is (every
+    stored map differs by bf16 rounding, which flips the leaky-ReLU branch of the elements nearest zero in each of the
+    three normalisations - a few percent on the input gradient for either path)."""
     from functools import partial
     from ucd_amd import abn, blocks
     from ucd_amd.ddp import DistributedDataParallel
@@ -343,28 +346,31 @@ def test_residual_block_training_with_own_3x3(cin, chans, dil):
     x0 = synth.t_normal(9, (B, cin, H, W), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
     dy = synth.t_normal(10, (B, chans[2], H, W), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
     outs = []
-    for fused in (True, False):
+    for mode in ("fused", "module", "fp32"):
         blk = blocks.ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=dil)
         blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
         blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
-        mod = DistributedDataParallel(blk, bf16_weights=True)
-        if not fused:
+        mod = DistributedDataParallel(blk, bf16_weights=True) if mode != "fp32" else blk
+        if mode == "module":
             os.environ["UCD_FUSED_CONV1X1"] = "0"
         try:
-            x = x0.clone().requires_grad_(True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
+            if mode == "fp32":
+                x = x0.float().clone().requires_grad_(True)
                 y = mod(x * 1.0)
-            if fused:
-                assert "ConvABNTrainNode" in type(y.grad_fn).__name__ or cin != chans[2] or True
-            y.backward(dy)
-            mod.finish_grad_sync()
+                y.backward(dy.float())
+            else:
+                x = x0.clone().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = mod(x * 1.0)
+                y.backward(dy)
+                mod.finish_grad_sync()
         finally:
             os.environ.pop("UCD_FUSED_CONV1X1", None)
         grads = {n: p.grad.float().clone() for n, p in blk.named_parameters()}
         outs.append((y.detach().float(), x.grad.float(), grads, blk.convs.bn2.running_var.clone()))
-    (yf, gxf, gf, rvf), (yp, gxp, gp, rvp) = outs
-    assert _rel(yf, yp) < 1e-2
-    assert _rel(gxf, gxp) < 3e-2
-    torch.testing.assert_close(rvf, rvp, rtol=2e-3, atol=1e-5)
+    (yf, gxf, gf, rvf), (yp, gxp, gp, rvp), (y32, gx32, g32, rv32) = outs
+    assert _rel(yf, y32) < 1.5 * _rel(yp, y32) + 2e-3 and _rel(yf, y32) < 2e-2
+    assert _rel(gxf, gx32) < 1.5 * _rel(gxp, gx32) + 5e-3, (_rel(gxf, gx32), _rel(gxp, gx32))
+    torch.testing.assert_close(rvf, rv32, rtol=5e-3, atol=1e-5)
     for n in gf:
-        assert _rel(gf[n], gp[n]) < 5e-2, n
+        assert _rel(gf[n], g32[n]) < 1.5 * _rel(gp[n], g32[n]) + 1e-2, (n, _rel(gf[n], g32[n]), _rel(gp[n], g32[n]))
