@@ -329,8 +329,8 @@ def test_conv3x3_implicit_gemm_mode(B, K, N, H, W, d):
     assert _rel(dx, refdx) < 3e-3
 
 
-@pytest.mark.parametrize("cin,chans,dil", [(1024, (256, 256, 1024), 1), (256, (64, 64, 256), 1), (512, (128, 128, 512), 2)])
-def test_residual_block_training_with_own_3x3(cin, chans, dil):
+@pytest.mark.parametrize("cin,chans,dil,hw", [(1024, (256, 256, 1024), 1, 33), (256, (64, 64, 256), 1, 65), (512, (128, 128, 512), 2, 49)])
+def test_residual_block_training_with_own_3x3(cin, chans, dil, hw):
     """Training forward + backward with the 3x3 convolution + ABN as one node on the implicit-GEMM kernel (forward with the
     statistics epilogue, input gradient on the cached flipped weight) against the module path (MIOpen + separate ABN): wide and
     narrow bottlenecks, B large enough for the own kernel to be chosen.  Both are bf16 implementations of the same block, so
@@ -341,7 +341,7 @@ def test_residual_block_training_with_own_3x3(cin, chans, dil):
     from ucd_amd import abn, blocks
     from ucd_amd.ddp import DistributedDataParallel
     norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
-    B, H, W = 24, 33, 33
+    B, H, W = 24, hw, hw
     assert blocks._own_conv3x3(B * H * W, chans[0], chans[1])
     x0 = synth.t_normal(9, (B, cin, H, W), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
     dy = synth.t_normal(10, (B, chans[2], H, W), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
