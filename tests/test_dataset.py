@@ -1,0 +1,143 @@
+"""Incremental VOC dataset: listing, image filtering and index files on a synthetic VOC tree (CPU, against the
+oracle's restatement of dataset/utils.py:19-42 and dataset/voc.py:176-203); on the GPU the batch transform of the loader
+against the same stack run per sample with Pillow on the host, from the same `random` seed."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dataset as OD
+from ucd_amd import tasks
+from ucd_amd.dataset import DeviceBatcher, VOCSegmentation, VOCSegmentationIncremental, filter_images
+
+PIL = pytest.importorskip("PIL.Image")
+
+CLASS_SETS = [[0, 1, 5], [0, 16], [0, 3, 17, 255], [0, 20, 255], [0, 2], [0, 15, 19], [0, 18, 16, 4], [0, 6, 255], [0, 17], [0, 20, 1]]
+
+
+def _make_tree(root, n=10, seed=7):
+    rng = np.random.RandomState(seed)
+    os.makedirs(root / "splits"); os.makedirs(root / "JPEGImages"); os.makedirs(root / "SegmentationClassAug")
+    lines, labels = [], []
+    for k in range(n):
+        H, W = int(rng.randint(90, 180)), int(rng.randint(90, 180))
+        img = rng.randint(0, 256, size=(H // 6 + 1, W // 6 + 1, 3)).astype(np.uint8).repeat(6, 0).repeat(6, 1)[:H, :W]
+        lab = rng.choice(CLASS_SETS[k % len(CLASS_SETS)], size=(H // 10 + 1, W // 10 + 1)).astype(np.uint8).repeat(10, 0).repeat(10, 1)[:H, :W]
+        PIL.fromarray(img).save(root / "JPEGImages" / f"im{k}.png")               # lossless, named like the split file says
+        PIL.fromarray(lab).save(root / "SegmentationClassAug" / f"im{k}.png")
+        lines.append(f"/JPEGImages/im{k}.png /SegmentationClassAug/im{k}.png\n")
+        labels.append(lab)
+    (root / "splits" / "train_aug.txt").write_text("".join(lines))
+    (root / "splits" / "val.txt").write_text("".join(lines[: n // 2]))
+    return labels
+
+
+def test_listing_follows_the_split_files(tmp_path):
+    labels = _make_tree(tmp_path)
+    tr, va = VOCSegmentation(str(tmp_path), "train"), VOCSegmentation(str(tmp_path), "val")
+    assert len(tr) == 10 and len(va) == 5
+    img, lab = tr[3]
+    assert img.dtype == np.uint8 and img.shape[2] == 3 and np.array_equal(lab, labels[3])
+    with pytest.raises(ValueError):
+        VOCSegmentation(str(tmp_path), "nonexistent")
+    with pytest.raises(RuntimeError):
+        VOCSegmentation(str(tmp_path / "missing"), "train")
+
+
+@pytest.mark.parametrize("task,step", [("15-5", 0), ("15-5", 1), ("15-5s", 3), ("19-1", 1), ("10-10", 1)])
+@pytest.mark.parametrize("overlap", [True, False])
+def test_image_filter_matches_oracle(tmp_path, task, step, overlap):
+    maps = _make_tree(tmp_path)
+    labels, labels_old, _ = tasks.get_task_labels("voc", task, step)
+    full = VOCSegmentation(str(tmp_path), "train")
+    got = filter_images(full, labels, labels_old, overlap=overlap)
+    assert got == OD.filter_images(maps, labels, labels_old, overlap=overlap)
+    if task == "15-5" and step == 0:      # by hand: images holding any of 1..15 / of those, the ones without a future class 16..20
+        assert got == ([0, 2, 4, 5, 6, 7, 9] if overlap else [0, 4, 7])
+    if task == "15-5" and step == 1:
+        assert got == [1, 2, 3, 5, 6, 8, 9]
+
+
+def test_incremental_dataset_index_file_and_label_table(tmp_path):
+    maps = _make_tree(tmp_path / "voc")
+    labels, labels_old, _ = tasks.get_task_labels("voc", "15-5", 1)
+    idx = tmp_path / "idx" / "train-1.npy"
+    d = VOCSegmentationIncremental(str(tmp_path / "voc"), train=True, labels=labels, labels_old=labels_old, idxs_path=str(idx),
+                                   overlap=True)
+    assert os.path.exists(idx) and np.load(idx).tolist() == d.indices == [1, 2, 3, 5, 6, 8, 9]
+    np.save(idx, np.array([0, 1]))                                            # an existing index file wins (voc.py:149-150)
+    d2 = VOCSegmentationIncremental(str(tmp_path / "voc"), train=True, labels=labels, labels_old=labels_old, idxs_path=str(idx))
+    assert d2.indices == [0, 1] and len(d2) == 2
+    img, lab = d[0]
+    assert isinstance(img, torch.Tensor) and img.dtype == torch.uint8 and np.array_equal(lab.numpy(), maps[1])
+    for dm in ("current", "current+old", "new"):
+        dd = VOCSegmentationIncremental(str(tmp_path / "voc"), train=True, labels=labels, labels_old=labels_old, data_masking=dm)
+        for k in (1, 2, 6):
+            assert np.array_equal(dd.lut.numpy()[maps[k]], OD.target_transform(maps[k], labels, labels_old, dm)), (dm, k)
+    with pytest.raises(AssertionError):
+        VOCSegmentationIncremental(str(tmp_path / "voc"), labels=[1, 2], labels_old=[2])
+    assert len(VOCSegmentationIncremental(str(tmp_path / "voc"), train=False)) == 5       # no labels: the whole split
+
+
+def _pil_train_sample(img, lab, S, lut, mean, std):
+    """transform.Compose of run.py:49-55 on one sample with Pillow (transform.py:505-560, 313-337): the draws, then pixels."""
+    from ucd_amd.datapipe import random_resized_crop_params
+    i, j, h, w = random_resized_crop_params(img.shape[0], img.shape[1], scale=(0.5, 2.0))
+    flip = random.random() < 0.5
+    pi = PIL.fromarray(img).crop((j, i, j + w, i + h)).resize((S, S), PIL.BILINEAR)
+    pl = PIL.fromarray(lab).crop((j, i, j + w, i + h)).resize((S, S), PIL.NEAREST)
+    if flip:
+        pi, pl = pi.transpose(PIL.FLIP_LEFT_RIGHT), pl.transpose(PIL.FLIP_LEFT_RIGHT)
+    x = torch.from_numpy(np.asarray(pi, dtype=np.uint8).copy()).permute(2, 0, 1).float().div(255)
+    x = (x - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
+    return x, torch.from_numpy(lut[np.asarray(pl, dtype=np.uint8)].astype(np.int64))
+
+
+@pytest.mark.gpu
+def test_device_batcher_matches_pillow_per_sample(tmp_path):
+    _make_tree(tmp_path)
+    labels, labels_old, _ = tasks.get_task_labels("voc", "15-5", 1)
+    d = VOCSegmentationIncremental(str(tmp_path), train=True, labels=labels, labels_old=labels_old)
+    S = 65
+    bt = DeviceBatcher("cuda:0", S, d.lut, train=True)
+    loader = torch.utils.data.DataLoader(d, batch_size=3, shuffle=False, drop_last=True, collate_fn=bt)
+    random.seed(11)
+    got = [(x.cpu(), y.cpu()) for x, y in loader]
+    assert len(got) == 2 and got[0][0].shape == (3, 3, S, S) and got[0][1].dtype == torch.int64
+    random.seed(11)
+    k = 0
+    for x, y in got:
+        for b in range(3):
+            img, lab = d[k]
+            xr, yr = _pil_train_sample(img.numpy(), lab.numpy(), S, d.lut.numpy(), bt.mean, bt.std)
+            assert torch.equal(y[b], yr), k                                   # labels: bit-exact
+            torch.testing.assert_close(x[b], xr, rtol=0, atol=2e-6)           # images: Pillow's u8 result, then fp32 normalise
+            k += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("crop", [True, False])
+def test_device_batcher_validation_paths(tmp_path, crop):
+    _make_tree(tmp_path)
+    d = VOCSegmentationIncremental(str(tmp_path), train=False, labels=list(range(1, 21)))
+    S = 64
+    bt = DeviceBatcher("cuda:0", S, d.lut, train=False, crop=crop)
+    img, lab = d[2]
+    x, y = bt([(img, lab)])
+    mean, std = torch.tensor(bt.mean).view(3, 1, 1), torch.tensor(bt.std).view(3, 1, 1)
+    if crop:
+        pi, pl = PIL.fromarray(img.numpy()), PIL.fromarray(lab.numpy())
+        w, h = pi.size
+        ow, oh = (S, int(S * h / w)) if w <= h else (int(S * w / h), S)
+        pi, pl = pi.resize((ow, oh), PIL.BILINEAR), pl.resize((ow, oh), PIL.NEAREST)
+        i, j = int(round((oh - S) / 2.0)), int(round((ow - S) / 2.0))
+        ri = np.asarray(pi.crop((j, i, j + S, i + S)), dtype=np.uint8)
+        rl = np.asarray(pl.crop((j, i, j + S, i + S)), dtype=np.uint8)
+    else:
+        ri, rl = img.numpy(), lab.numpy()
+    xr = (torch.from_numpy(ri.copy()).permute(2, 0, 1).float().div(255) - mean) / std
+    assert x.shape == (1, 3) + ri.shape[:2]
+    torch.testing.assert_close(x[0].cpu(), xr, rtol=0, atol=2e-6)
+    assert torch.equal(y[0].cpu(), torch.from_numpy(d.lut.numpy()[rl].astype(np.int64)))

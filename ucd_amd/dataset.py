@@ -1,0 +1,181 @@
+"""Pascal-VOC incremental-segmentation dataset on top of the device data pipeline.
+
+Host-side mirror of the reference's ``dataset/voc.py`` (``VOCSegmentation`` :38-119, ``VOCSegmentationIncremental`` :122-237),
+``dataset/utils.py`` (``filter_images`` :19-42, ``Subset`` :45-87) and of the transform stack ``run.py:49-73`` builds - same
+constructor arguments, same file layout (``splits/train_aug.txt`` / ``val.txt`` lines ``/JPEGImages/x.jpg
+/SegmentationClassAug/x.png``), same index files (``data/voc/<task>[-ov]/train-<step>.npy``), same label masking /
+re-ordering - split where the hardware wants it:
+
+* the host decodes (Pillow) and hands out the RAW uint8 image / label pair of a sample;
+* ``DeviceBatcher`` (the ``collate_fn``) draws the reference's random parameters on the host (``RandomResizedCrop.get_params``,
+  the flip coin: same ``random`` draws in the same order as ``dataset/transform.py``) and runs crop + Pillow-exact resize + flip
+  + ToTensor + Normalize (images) and crop + NEAREST resize + flip + the step's label re-mapping (labels) on the GPU
+  (``ucd_amd.datapipe``: bit-exact against Pillow / the reference's per-pixel lambda).  The reference does all of it per sample
+  on the host with ``num_workers=0`` (37 img/s measured against 142 846 on the device, tools/datapipe_bench.py).
+
+Validation with ``--crop_val`` (``Resize`` + ``CenterCrop``, run.py:58-65) resizes on the host with Pillow (exact by
+construction) and normalises on the device.  ADE20K / Cityscapes have the same structure (dataset/ade.py, cityscape.py) and
+are not wired.
+"""
+from __future__ import annotations
+
+import os
+import random
+
+import numpy as np
+import torch
+import torch.utils.data as data
+
+from . import datapipe
+
+
+def _open_rgb(path):
+    from PIL import Image
+    return np.array(Image.open(path).convert("RGB"), dtype=np.uint8)
+
+
+def _open_label(path):
+    from PIL import Image
+    return np.array(Image.open(path), dtype=np.uint8)
+
+
+class VOCSegmentation(data.Dataset):
+    """File listing of the reference's ``VOCSegmentation`` (dataset/voc.py:49-93); items are decoded uint8 arrays
+    ``(image [H, W, 3], label [H, W])`` - no transform here."""
+
+    def __init__(self, root, image_set="train", is_aug=True, transform=None):
+        self.root = os.path.expanduser(root)
+        self.image_set = image_set
+        splits_dir = os.path.join(self.root, "splits")
+        if not os.path.isdir(self.root):
+            raise RuntimeError(f"Dataset not found or corrupted. at location = {self.root}")
+        if is_aug and image_set == "train":
+            mask_dir = os.path.join(self.root, "SegmentationClassAug")
+            assert os.path.exists(mask_dir), "SegmentationClassAug not found"
+            split_f = os.path.join(splits_dir, "train_aug.txt")
+        else:
+            split_f = os.path.join(splits_dir, image_set.rstrip("\n") + ".txt")
+        if not os.path.exists(split_f):
+            raise ValueError(f'Wrong image_set entered! Please use image_set="train" or image_set="trainval" or image_set="val" {split_f}')
+        with open(split_f, "r") as f:
+            file_names = [x[:-1].split(" ") for x in f.readlines()]
+        self.images = [(os.path.join(self.root, x[0][1:]), os.path.join(self.root, x[1][1:])) for x in file_names]
+
+    def __getitem__(self, index):
+        return _open_rgb(self.images[index][0]), _open_label(self.images[index][1])
+
+    def label(self, index):
+        return _open_label(self.images[index][1])
+
+    def __len__(self):
+        return len(self.images)
+
+
+def filter_images(dataset, labels, labels_old=None, overlap=True):
+    """Indices of the images that carry at least one of ``labels`` (overlap) and - disjoint setting - nothing outside
+    ``labels + labels_old + {0, 255}`` (dataset/utils.py:19-42, on the labels as stored)."""
+    labels = [l for l in labels if l != 0]
+    labels_cum = labels + list(labels_old or []) + [0, 255]
+    idxs = []
+    for i in range(len(dataset)):
+        cls = np.unique(dataset.label(i) if hasattr(dataset, "label") else np.array(dataset[i][1]))
+        if any(x in labels for x in cls) and (overlap or all(x in labels_cum for x in cls)):
+            idxs.append(i)
+    return idxs
+
+
+class VOCSegmentationIncremental(data.Dataset):
+    """``VOCSegmentationIncremental(root, train, transform, labels, labels_old, idxs_path, masking, overlap, data_masking,
+    test_on_val)`` of the reference (dataset/voc.py:124-216).  ``transform`` is accepted and ignored: the transform of a batch
+    runs on the device (``DeviceBatcher``); ``self.lut`` is the step's label table (inverted order + masking)."""
+
+    def __init__(self, root, train=True, transform=None, labels=None, labels_old=None, idxs_path=None, masking=True,
+                 overlap=True, data_masking="current", test_on_val=False, **kwargs):
+        full_voc = VOCSegmentation(root, "train" if train else "val", is_aug=True, transform=None)
+        self.full, self.train = full_voc, train
+        self.labels, self.labels_old = [], []
+        if labels is not None:
+            labels_old = labels_old if labels_old is not None else []
+            labels = [l for l in labels if l != 0]
+            labels_old = [l for l in labels_old if l != 0]
+            assert not any(l in labels_old for l in labels), "labels and labels_old must be disjoint sets"
+            self.labels, self.labels_old = [0] + labels, [0] + labels_old
+            self.order = [0] + labels_old + labels
+            if idxs_path is not None and os.path.exists(idxs_path):
+                idxs = np.load(idxs_path).tolist()
+            else:
+                idxs = filter_images(full_voc, labels, labels_old, overlap=overlap)
+                if idxs_path is not None and (not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0):
+                    os.makedirs(os.path.dirname(idxs_path) or ".", exist_ok=True)
+                    np.save(idxs_path, np.array(idxs, dtype=int))
+            if test_on_val:
+                rnd = np.random.RandomState(1)
+                rnd.shuffle(idxs)
+                train_len = int(0.8 * len(idxs))
+                idxs = idxs[:train_len] if train else idxs[train_len:]
+            self.indices = idxs
+            self.lut = datapipe.target_lut(labels, labels_old, masking=masking, data_masking=data_masking)
+        else:
+            self.indices = list(range(len(full_voc)))
+            self.lut = torch.arange(256, dtype=torch.uint8)
+
+    def __getitem__(self, index):
+        img, lab = self.full[self.indices[index]]
+        return torch.from_numpy(img), torch.from_numpy(lab)
+
+    def __len__(self):
+        return len(self.indices)
+
+
+class DeviceBatcher:
+    """``collate_fn`` of the loader: a list of raw ``(image u8 [H, W, 3], label u8 [H, W])`` pairs -> the batch the train step
+    takes, ``(images float32 [B, 3, S, S] channels-last, labels int64 [B, S, S])`` on ``device``.
+
+    train:  RandomResizedCrop(S, (0.5, 2.0)) + RandomHorizontalFlip + ToTensor + Normalize   (run.py:49-55) - parameters
+            drawn on the host exactly like dataset/transform.py (``random`` module, per sample: crop box, then flip coin),
+            pixels on the device;
+    val:    Resize(S) + CenterCrop(S) + ToTensor + Normalize when ``crop`` (run.py:58-65; Pillow on the host, then the device
+            path with the identity box), else ToTensor + Normalize on the full image (batch size 1, run.py:66-73)."""
+
+    def __init__(self, device, size, lut, train=True, crop=True, scale=(0.5, 2.0), mean=(0.485, 0.456, 0.406),
+                 std=(0.229, 0.224, 0.225)):
+        self.device, self.size, self.train, self.crop = torch.device(device), int(size), train, crop
+        self.scale = scale
+        self.images = datapipe.DeviceImagePath(self.size, mean, std)
+        self.labels = datapipe.DeviceLabelPath(self.size, lut)
+        self.mean, self.std, self.lut = mean, std, lut
+
+    def __call__(self, samples):
+        dev, S = self.device, self.size
+        if self.train:
+            boxes, flips = [], []
+            for img, _ in samples:
+                boxes.append(datapipe.random_resized_crop_params(img.shape[0], img.shape[1], scale=self.scale))
+                flips.append(random.random() < 0.5)
+            imgs = [s[0].to(dev, non_blocking=True) for s in samples]
+            labs = [s[1].to(dev, non_blocking=True) for s in samples]
+            return self.images(imgs, boxes, flips), self.labels(labs, boxes, flips)
+        if self.crop:
+            from PIL import Image
+            imgs, labs = [], []
+            for img, lab in samples:
+                pi, pl = Image.fromarray(img.numpy()), Image.fromarray(lab.numpy())
+                w, h = pi.size
+                if w <= h:
+                    ow, oh = S, int(S * h / w)
+                else:
+                    oh, ow = S, int(S * w / h)                       # transform.Resize(size): smaller edge -> size
+                pi, pl = pi.resize((ow, oh), Image.BILINEAR), pl.resize((ow, oh), Image.NEAREST)
+                i, j = int(round((oh - S) / 2.0)), int(round((ow - S) / 2.0))          # transform.CenterCrop
+                imgs.append(torch.from_numpy(np.asarray(pi.crop((j, i, j + S, i + S)), dtype=np.uint8).copy()).to(dev))
+                labs.append(torch.from_numpy(np.asarray(pl.crop((j, i, j + S, i + S)), dtype=np.uint8).copy()).to(dev))
+            boxes, flips = [(0, 0, S, S)] * len(samples), [False] * len(samples)
+            return self.images(imgs, boxes, flips), self.labels(labs, boxes, flips)
+        out_i, out_l = [], []
+        for img, lab in samples:                                     # full-size validation: per image
+            x = img.to(dev).permute(2, 0, 1).float().div_(255.0)
+            m = torch.tensor(self.mean, device=dev).view(3, 1, 1)
+            s = torch.tensor(self.std, device=dev).view(3, 1, 1)
+            out_i.append(((x - m) / s).unsqueeze(0).contiguous(memory_format=torch.channels_last))
+            out_l.append(self.lut.to(dev)[lab.to(dev).long()].long().unsqueeze(0))
+        return torch.cat(out_i), torch.cat(out_l)

@@ -2,9 +2,10 @@
 run.py:116-400; launcher README.md:35).  Keeps the reference's control flow, optimiser / scheduler
 semantics (run.py:175-189) and checkpoint layout (run.py:32-43: ``checkpoints/step/{task}-{dataset}_
 {name}_{step}.pth`` with keys epoch, model_state [``module.``-prefixed], optimizer_state, scheduler_state,
-best_score, trainer_state).  Data: the PIL dataset pipeline of the reference (dataset/*) is outside this
-round's scope; ``--data_root synthetic`` (or a missing data directory) trains on
-the closed-form synthetic batches the benchmark uses.
+best_score, trainer_state).  Data: with a VOC tree under ``--data_root`` (``splits/``, ``JPEGImages/``,
+``SegmentationClassAug/``) the reference's incremental dataset is used - host decode, batch transform on the device
+(``ucd_amd/dataset.py``); ``--data_root synthetic`` (or a missing data directory) trains on the
+closed-form synthetic batches the benchmark uses.
 """
 from __future__ import annotations
 
@@ -112,14 +113,43 @@ def main(opts):
 
     classes = tasks.get_per_task_classes(opts.dataset, opts.task, opts.step)
     labels, labels_old, _ = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
-    if opts.data_root != "synthetic" and os.path.isdir(os.path.join(opts.data_root, opts.dataset)):
-        raise NotImplementedError("the PIL dataset pipeline is outside this round's scope (SURVEY.md 8-f2); "
-                                  "use --data_root synthetic")
-    n_train = 24 * 8
-    train_dst = SyntheticSegmentation(n_train, opts.crop_size, [l for l in labels if l != 0] or [1], seed=opts.step)
+    real = opts.data_root != "synthetic" and os.path.isdir(os.path.join(opts.data_root, "splits"))
+    if real and opts.dataset != "voc":
+        raise NotImplementedError("real-data loading is wired for --dataset voc (ucd_amd/dataset.py); ADE20K and Cityscapes "
+                                  "share its structure and are not wired - use --data_root synthetic")
+    val_dst = None
+    collate_train = collate_val = None
+    if real:
+        # the reference's get_dataset (run.py:46-113): index files under data/voc/<task>[-ov]/, masking / overlap flags; host
+        # decode, batch transform on the device (collate_fn), so num_workers must stay 0 (device work in the main process)
+        from .dataset import DeviceBatcher, VOCSegmentationIncremental
+        _, _, path_base = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
+        path_base += "-ov" if opts.overlap else ""
+        os.makedirs(path_base, exist_ok=True)
+        train_dst = VOCSegmentationIncremental(opts.data_root, train=True, labels=list(labels), labels_old=list(labels_old),
+                                               idxs_path=path_base + f"/train-{opts.step}.npy", masking=not opts.no_mask,
+                                               overlap=opts.overlap)
+        if not opts.no_cross_val:
+            train_len = int(0.8 * len(train_dst))
+            train_dst, val_dst = torch.utils.data.random_split(train_dst, [train_len, len(train_dst) - train_len])
+            lut = train_dst.dataset.lut
+        else:
+            val_dst = VOCSegmentationIncremental(opts.data_root, train=False, labels=list(labels), labels_old=list(labels_old),
+                                                 idxs_path=path_base + f"/val-{opts.step}.npy", masking=not opts.no_mask,
+                                                 overlap=True)
+            lut = train_dst.lut
+        if device.type != "cuda":
+            raise RuntimeError("the device data pipeline needs a GPU (there is no CPU fallback)")
+        collate_train = DeviceBatcher(device, opts.crop_size, lut, train=True)
+        collate_val = DeviceBatcher(device, opts.crop_size, lut, train=False, crop=opts.crop_val)
+        workers = 0
+    else:
+        n_train = 24 * 8
+        train_dst = SyntheticSegmentation(n_train, opts.crop_size, [l for l in labels if l != 0] or [1], seed=opts.step)
+        workers = opts.num_workers
     sampler = torch.utils.data.distributed.DistributedSampler(train_dst, num_replicas=world_size, rank=rank)
-    train_loader = torch.utils.data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler,
-                                               num_workers=opts.num_workers, drop_last=True)
+    train_loader = torch.utils.data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler, num_workers=workers,
+                                               drop_last=True, collate_fn=collate_train)
     model, model_old = build_models(opts, device, classes)
     optimizer = make_optimizer(opts, model)
     scheduler = PolyLR(optimizer, max_iters=opts.epochs * len(train_loader), power=opts.lr_power)
@@ -140,11 +170,12 @@ def main(opts):
     # validation set + streaming metrics (run.py:161-164, 304-338): synthetic images carrying every class seen so far
     n_classes = sum(classes)
     seen = [l for l in (list(labels_old) + list(labels)) if l != 0] or [1]
-    val_dst = SyntheticSegmentation(max(2 * opts.batch_size, 2), opts.crop_size, seen, seed=1000 + opts.step)
+    if val_dst is None:
+        val_dst = SyntheticSegmentation(max(2 * opts.batch_size, 2), opts.crop_size, seen, seed=1000 + opts.step)
     val_loader = torch.utils.data.DataLoader(
         val_dst, batch_size=opts.batch_size if opts.crop_val else 1,
         sampler=torch.utils.data.distributed.DistributedSampler(val_dst, num_replicas=world_size, rank=rank, shuffle=False),
-        num_workers=opts.num_workers)
+        num_workers=workers, collate_fn=collate_val)
     val_metrics = StreamSegMetrics(n_classes)
 
     cur_epoch, best_score = 0, 0.0
@@ -176,6 +207,23 @@ def main(opts):
     if rank == 0 and not opts.test:
         save_ckpt(ckpt_path, model, trainer, optimizer, scheduler, cur_epoch, best_score)
     dist.barrier()
+    if real:
+        # final pass over the test split with every class seen so far (run.py:108-111, 340-372)
+        from .dataset import DeviceBatcher, VOCSegmentationIncremental
+        image_set = "train" if opts.val_on_trainset else "val"
+        labels_cum = list(labels_old) + list(labels)
+        test_dst = VOCSegmentationIncremental(opts.data_root, train=opts.val_on_trainset, labels=labels_cum,
+                                              idxs_path=path_base + f"/test_on_{image_set}-{opts.step}.npy")
+        test_loader = torch.utils.data.DataLoader(
+            test_dst, batch_size=opts.batch_size if opts.crop_val else 1, num_workers=0,
+            sampler=torch.utils.data.distributed.DistributedSampler(test_dst, num_replicas=world_size, rank=rank, shuffle=False),
+            collate_fn=DeviceBatcher(device, opts.crop_size, test_dst.lut, train=False, crop=opts.crop_val))
+        model.eval()
+        val_loss, val_score, _ = trainer.validate(loader=test_loader, metrics=val_metrics, logger=logger)
+        logger.info(f"*** End of Test, Total Loss={float(val_loss[0]) + float(val_loss[1])}, Class Loss={float(val_loss[0])},"
+                    f" Reg Loss={float(val_loss[1])}")
+        if rank == 0:
+            logger.info(val_metrics.to_str(val_score))
     dist.destroy_process_group()
 
 
