@@ -402,7 +402,9 @@ def test_config0_logits_and_sem_match_reference_golden():
     got = logits.flatten()[torch.from_numpy(g["sample_idx"]).to(dev)].cpu().numpy()
     assert np.linalg.norm(got - g["logits_sample"]) / np.linalg.norm(g["logits_sample"]) < 1e-3
     np.testing.assert_allclose(got, g["logits_sample"], rtol=2e-3, atol=2e-3)
-    np.testing.assert_allclose(feat["sem"].cpu().numpy()[:, :, ::4, ::4], g["sem"], rtol=2e-3, atol=2e-3)
+    # fp32 MIOpen convolutions: the solver a fresh box picks (find mode times them) may be Winograd, ~1e-3 of the activation
+    # scale per layer; 2 of 640 samples reached 2.8e-3 on one box, hence 4e-3 absolute on values of magnitude ~3
+    np.testing.assert_allclose(feat["sem"].cpu().numpy()[:, :, ::4, ::4], g["sem"], rtol=2e-3, atol=4e-3)
 
 
 @pytest.mark.parametrize("tag", ["33", "48", "odd"])
