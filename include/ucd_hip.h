@@ -41,7 +41,9 @@ enum ucd_act { UCD_ACT_IDENTITY = 0, UCD_ACT_LEAKY_RELU = 1, UCD_ACT_ELU = 2 /* 
  * d weight = sign(weight) * sum dz*xhat, sign(0) = +1); without it the layer is F.batch_norm (inplace_abn.ABN). */
 #define UCD_ACT_MASK 0xff
 #define UCD_NORM_ABS_GAMMA 0x100
-enum ucd_pixcon_precision { UCD_PIXCON_F32 = 0, UCD_PIXCON_F16 = 1 };
+/* UCD_PIXCON_F16_SPLIT: the fp16 path forced onto its fixed-split kernels (what UCD_PIXCON_F16 falls back to for
+ * T < 0.06, more than 32 teacher classes or more than 1023 anchor blocks); kept selectable as the A/B reference. */
+enum ucd_pixcon_precision { UCD_PIXCON_F32 = 0, UCD_PIXCON_F16 = 1, UCD_PIXCON_F16_SPLIT = 2 };
 enum ucd_error {
   UCD_OK = 0,
   UCD_EINVAL = -1,      /* bad argument (null pointer, negative size, unknown enum) */

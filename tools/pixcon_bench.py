@@ -1,5 +1,6 @@
 """GPU micro-benchmark of the contrastive loss kernels at the SURVEY 8-d micro-shapes.
-usage: python tools/pixcon_bench.py [f16|f32] [A_frac]   (cfg2: BHW=26136)"""
+usage: python tools/pixcon_bench.py [f16|f16_split|f32] [dom]   (cfg2: BHW=26136; "dom": one teacher class dominates, like the
+benchmark step / a trained teacher - 2/3 of the pairs are positives)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +13,10 @@ torch.manual_seed(0)
 f_n = torch.randn(B, N, h, h, device=dev).abs_().contiguous(memory_format=torch.channels_last)   # post-activation-like features
 f_o = (f_n + 0.3 * torch.randn_like(f_n)).contiguous(memory_format=torch.channels_last)
 l_po = 2 * torch.randn(B, K, h, h, device=dev)
+if "dom" in sys.argv[2:]:
+    l_po[:, 9] += 6.0
 labels = synth.seg_labels(7, B, H, H, range(16, 21)).to(dev)
-pb = pixcon_prepare(f_n, labels, l_po, f_o, sort_by_label=True, fp16=(prec == "f16"))
+pb = pixcon_prepare(f_n, labels, l_po, f_o, sort_by_label=True, fp16=prec.startswith("f16"))
 m = pb.meta_host()
 print("A", m.A, "Co", m.Co, "Cpad", m.Cpad, "n_valid", m.n_valid)
 def run():

@@ -108,7 +108,7 @@ def pixcon_loss_raw(pb, temperature=0.07, shift_pos=True, use_prob=True, need_gr
     prepared with fp16=True)."""
     lib = hip.load()
     prec = hip.PIXCON_PRECISION[precision]
-    if prec == hip.PIXCON_F16 and pb.ch16 is None:
+    if prec != hip.PIXCON_F32 and pb.ch16 is None:
         raise RuntimeError("precision='f16' needs pixcon_prepare(..., fp16=True)")
     dev = pb.chat.device
     loss_out = torch.empty(2, dtype=torch.float32, device=dev)
@@ -133,7 +133,7 @@ class _FusedContrastive(torch.autograd.Function):
     @staticmethod
     def forward(ctx, f_n, labels, l_po, f_o, temperature, max_label, precision):
         pb = pixcon_prepare(f_n, labels, l_po, f_o, max_label=max_label, sort_by_label=True,
-                            fp16=hip.PIXCON_PRECISION[precision] == hip.PIXCON_F16)
+                            fp16=hip.PIXCON_PRECISION[precision] != hip.PIXCON_F32)
         loss_out, grad_a, _ = pixcon_loss_raw(pb, temperature, True, True, need_grad=ctx.needs_input_grad[0],
                                               precision=precision)
         ctx.pb, ctx.grad_a, ctx.shape, ctx.dtype = pb, grad_a, f_n.shape, f_n.dtype

@@ -452,8 +452,8 @@ extern "C" {
 
 size_t ucd_pixcon_loss_workspace_bytes(int BHW, int N, int K) {
   (void)N;
-  const size_t a = make_plan(BHW, K).total, b = pixcon16_workspace_bytes(BHW);
-  return a > b ? a : b;
+  const size_t a = make_plan(BHW, K).total, b = pixcon16_workspace_bytes(BHW), c = pixcon16p_workspace_bytes(BHW);
+  return a > b ? (a > c ? a : c) : (b > c ? b : c);
 }
 
 static int pixcon_loss_impl(const char* fn, const float* chat, int ldc, int N, const uint8_t* row_label, const float* pcat,
@@ -463,13 +463,17 @@ static int pixcon_loss_impl(const char* fn, const float* chat, int ldc, int N, c
                             size_t workspace_bytes, ucd_stream_t stream) {
   UCD_REQUIRE(row_label && meta && loss_out && workspace, UCD_EINVAL, "%s: NULL argument", fn);
   UCD_REQUIRE(BHW > 0 && N > 0 && temperature > 0.f, UCD_EINVAL, "%s: bad sizes", fn);
-  UCD_REQUIRE(precision == UCD_PIXCON_F32 || precision == UCD_PIXCON_F16, UCD_EINVAL, "%s: unknown precision %d", fn, precision);
+  UCD_REQUIRE(precision == UCD_PIXCON_F32 || precision == UCD_PIXCON_F16 || precision == UCD_PIXCON_F16_SPLIT, UCD_EINVAL,
+              "%s: unknown precision %d", fn, precision);
   UCD_REQUIRE(!grad_a || (aligned16(grad_a) && ldg % 4 == 0 && ldg >= N && ldg <= kN), UCD_EALIGN,
               "%s: grad_a must be 16-byte aligned, ldg a multiple of 4 in [N, %d]", fn, kN);
-  if (precision == UCD_PIXCON_F16) {
+  if (precision == UCD_PIXCON_F16 || precision == UCD_PIXCON_F16_SPLIT) {
     UCD_REQUIRE(ch16 && aligned16(ch16) && N <= kN, UCD_EINVAL, "%s: the fp16 path needs ch16 [Cpad, %d]", fn, kN);
     UCD_REQUIRE(!use_prob || (p16 && aligned16(p16) && K > 0 && K <= 112), UCD_EUNSUPPORTED,
                 "%s: the fp16 path needs p16 and K <= 112", fn);
+    if (precision == UCD_PIXCON_F16 && pixcon16p_eligible(BHW, temperature, use_prob, K))
+      return pixcon16p_launch((const _Float16*)ch16, row_label, (const _Float16*)p16, K, meta, BHW, temperature, shift_pos,
+                              use_prob, loss_out, grad_a, ldg, row_stats, workspace, workspace_bytes, (hipStream_t)stream);
     return pixcon16_launch((const _Float16*)ch16, row_label, (const _Float16*)p16, K, meta, BHW, temperature, shift_pos,
                            use_prob, loss_out, grad_a, ldg, row_stats, workspace, workspace_bytes, (hipStream_t)stream);
   }

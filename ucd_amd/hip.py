@@ -21,8 +21,9 @@ ACT_MASK = 0xFF
 NORM_ABS_GAMMA = 0x100   # flag bit of `act`: gamma~ = |weight| + eps (InPlaceABN / InPlaceABNSync), see include/ucd_hip.h
 PIX_TILE = 128          # kPixTile of csrc/pixcon.h
 PIXCON_LD = 256         # feature rows of the contrast matrix are padded to 256 columns
-PIXCON_F32, PIXCON_F16 = 0, 1
-PIXCON_PRECISION = {"f32": PIXCON_F32, "fp32": PIXCON_F32, "f16": PIXCON_F16, "fp16": PIXCON_F16}
+PIXCON_F32, PIXCON_F16, PIXCON_F16_SPLIT = 0, 1, 2
+PIXCON_PRECISION = {"f32": PIXCON_F32, "fp32": PIXCON_F32, "f16": PIXCON_F16, "fp16": PIXCON_F16,
+                    "f16_split": PIXCON_F16_SPLIT}
 
 
 class PixconMeta(C.Structure):
