@@ -30,3 +30,8 @@ torch.cuda.synchronize()
 ts = sorted(s.elapsed_time(e) for s, e in evs)
 flop = float(m.A) * (m.A + m.Co) * (4 * N + 2 * K)
 print(f"{prec}: median {ts[5]:.3f} ms  min {ts[0]:.3f} ms  -> {flop / ts[5] / 1e9:.1f} TFLOP/s algorithmic; loss {out[0][0].item():.5f}")
+if prec == "f16":   # the plan the device built (header of the workspace, pixcon_loss_f16p.hip)
+    from ucd_amd import hip
+    ws = hip.workspace(hip.load().ucd_pixcon_loss_workspace_bytes(pb.BHW, pb.N, pb.K), dev, "pixloss")
+    hdr = ws[:32].view(torch.int32).cpu().tolist()
+    print("plan: counters", hdr[0:2], "units", hdr[2:4], "tiles per unit", hdr[4:6], "anchor blocks", hdr[6])

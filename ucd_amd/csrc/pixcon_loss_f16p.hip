@@ -255,25 +255,65 @@ struct RowState {
   bool gt_i;
 };
 
+struct TileSrc {   // what a fetch needs
+  const _Float16* ch16;
+  const uint8_t* row_label;
+  const _Float16* p16;
+  int KP16, s_row, s_c, chunks, ppitch;
+};
+template <bool PROB>
+__device__ __forceinline__ void fetch_tile(StageP& st, const TileSrc& src, int j0) {
+  tile_fetch_p(st, src.ch16, src.row_label, j0);
+  if (PROB) st.side = *reinterpret_cast<const u32x4*>(src.p16 + (size_t)(j0 + src.s_row) * 2 * src.KP16 + src.s_c * 8);
+  fetch_fence();
+}
+
+// One tile step = 32 MFMA gaps around ONE barrier in the middle (t = this tile, ring buffer BUF = t mod 4):
+//   gaps 0..15   acc += C(t-1)^T . w(t-1)   | score fragments of tile t+1 (buffer BUF+1)   | epilogue elements 0..7 of tile t
+//                gaps 11..15 also commit tile t+2 (fetched during the previous step) to buffer BUF+2
+//   barrier; fetch tile t+3 into the stage registers (a second set, i.e. two steps of latency, measured slower)
+//   gaps 16..31  x(t+1) = S^T of tile t+1    | value fragments of tile t (buffer BUF)         | epilogue elements 8..15
+// Between two barriers the workgroup reads buffers BUF-1 (previous step's second half), BUF+1 and writes BUF+2; the
+// value-fragment reads of the second half stay in flight across the end of the step (nothing waits for them there).
 template <int MODE, bool PROB, int BUF>
 __device__ __forceinline__ void tile_step(f32x16 (&acc)[8], const f16x8 (&a16)[16], Frags& f, const f32x16& x_cur,
-                                          f32x16& x_next, const f16x8 (&w_prev)[2], f16x8 (&w_new)[2], const u32x4& lw_cur,
-                                          u32x4& lw_next, RowState& rs, const f32x16& pm, const _Float16* cs0,
-                                          const u32* labs0, int sbase, int vbase, int half, int j0) {
-  constexpr int b_cur = BUF, b_nxt = (BUF + 1) % kRing;
+                                          f32x16& x_next, const f16x8 (&w_prev)[2], f16x8 (&w_new)[2], const u32x4& lw_in,
+                                          u32x4& lw_next, RowState& rs, const f32x16& pm, _Float16* cs0, u32* labs0,
+                                          _Float16* ps0, int sbase, int vbase, int half, bool self_tile, const u32x4& self_patch,
+                                          StageP& stage, const TileSrc& src, int j0_fetch) {
+  constexpr int b_cur = BUF, b_nxt = (BUF + 1) % kRing, b_new = (BUF + 2) % kRing;
   const _Float16* cs_cur = cs0 + b_cur * kBufHalfs;
   const _Float16* cs_nxt = cs0 + b_nxt * kBufHalfs;
+  _Float16* cs_new = cs0 + b_new * kBufHalfs;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  lw_next = *reinterpret_cast<const u32x4*>(labs0 + b_nxt * 8 + 4 * half);
-  const int dself = rs.self0 - j0;
+  u32x4 lw_cur = lw_in;
+  if (MODE == 1 && self_tile) {   // the tile that holds this wave's own anchors (wave-uniform): the self pair is no positive
+    lw_cur[0] |= self_patch[0]; lw_cur[1] |= self_patch[1]; lw_cur[2] |= self_patch[2]; lw_cur[3] |= self_patch[3];
+  }
+  const int crow = threadIdx.x >> 5, ccol = threadIdx.x & 31;
+  _Float16* cdst = cs_new + crow * kPitchH + ccol * 8;
   float arg[16], wv[16], dv[16];
 #pragma unroll
   for (int g = 0; g < 32; ++g) {
     if (g < 16) {
       acc[g >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(join(f.vlo[g], f.vhi[g]), w_prev[g & 1], acc[g >> 1], 0, 0, 0);
       f.sf[g] = lds_b128(cs_nxt + sbase + 16 * g);
+      if (g == 11) *reinterpret_cast<u32x4*>(cdst) = stage.a;
+      if (g == 12) *reinterpret_cast<u32x4*>(cdst + 8 * kPitchH) = stage.b;
+      if (g == 13) *reinterpret_cast<u32x4*>(cdst + 16 * kPitchH) = stage.c;
+      if (g == 14) *reinterpret_cast<u32x4*>(cdst + 24 * kPitchH) = stage.d;
+      if (g == 15) {
+        if (threadIdx.x < 8) labs0[b_new * 8 + (threadIdx.x & 1) * 4 + (threadIdx.x >> 1)] = stage.lab4;
+        if (PROB && (int)threadIdx.x < kTJ * src.chunks)
+          *reinterpret_cast<u32x4*>(ps0 + (b_new * kTJ + src.s_row) * src.ppitch + src.s_c * 8) = stage.side;
+      }
     } else {
       const int k = g - 16;
+      if (k == 0) {
+        __syncthreads();
+        fetch_tile<PROB>(stage, src, j0_fetch);
+        lw_next = *reinterpret_cast<const u32x4*>(labs0 + b_nxt * 8 + 4 * half);
+      }
       x_next = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.sf[k], a16[k], k == 0 ? zero : x_next, 0, 0, 0);
       const _Float16* a0 = cs_cur + vbase + (16 * (k & 1)) * kPitchH + 32 * (k >> 1);
       f.vlo[k] = lds_tr(a0);
@@ -285,35 +325,33 @@ __device__ __forceinline__ void tile_step(f32x16 (&acc)[8], const f16x8 (&a16)[1
     const int e = g >> 1;
     if ((g & 1) == 0) {
       if (MODE == 0) {
-        rs.mx = fmaxf(rs.mx, x_cur[e]);
+        // v_max_f32 directly: fmaxf() canonicalises both operands first (two more instructions per element)
+        asm("v_max_f32 %0, %1, %2" : "=v"(rs.mx) : "v"(rs.mx), "v"(x_cur[e]));
         arg[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(x_cur[e], rs.k2, -rs.m_run));
         asm volatile("" : "+v"(arg[e]), "+v"(rs.mx));
       } else {
+        // with s' = s2 - m2 - log2(neg):  q = neg / (2^(s2-m2) + neg) = 1 / (1 + 2^s'),
+        //                                 (s2 - m2) - log2(2^(s2-m2) + neg) = s' - log2(1 + 2^s')
         arg[e] = __builtin_fmaf(x_cur[e], rs.k2, -rs.m2);
-        dv[e] = __builtin_amdgcn_exp2f(arg[e]) + rs.neg_true;
-        asm volatile("" : "+v"(arg[e]), "+v"(dv[e]));
+        dv[e] = __builtin_amdgcn_exp2f(arg[e]) + 1.f;
+        wv[e] = __builtin_amdgcn_rcpf(dv[e]);
+        dv[e] = __builtin_amdgcn_logf(dv[e]);
+        asm volatile("" : "+v"(arg[e]), "+v"(dv[e]), "+v"(wv[e]));
       }
     } else {
       const u32 lc = label_byte(lw_cur, e);
       if (MODE == 0) {
-        const bool m = ((int)lc != rs.la) && (lc != (u32)kPadLabel);
-        const float ev = m ? arg[e] : 0.f;
+        // padding rows (label 255, zero features) pass as negatives with E = 2^-m_run exactly; the unit subtracts them
+        const float ev = ((int)lc != rs.la) ? arg[e] : 0.f;
         rs.neg += ev;
         wv[e] = ev;
         asm volatile("" : "+v"(wv[e]), "+v"(rs.neg));
       } else {
-        const bool m = ((int)lc == rs.la) && (tile_row(e, 0) != dself);
-        float term = arg[e] - __builtin_amdgcn_logf(dv[e]);    // log2 units; scaled by ln 2 once per row
-        float q = rs.neg_true * __builtin_amdgcn_rcpf(dv[e]);
-        if (PROB) {
-          const float pw = rs.gt_i ? 1.f : pm[e];
-          term *= pw;
-          q *= pw;
-        }
-        rs.lossacc += m ? term : 0.f;
-        q = m ? q : 0.f;
-        rs.qsum += q;
-        wv[e] = q;
+        float mf = ((int)lc == rs.la) ? 1.f : 0.f;
+        if (PROB) mf = rs.gt_i ? mf : mf * pm[e];
+        rs.lossacc = __builtin_fmaf(mf, arg[e] - dv[e], rs.lossacc);    // log2 units; scaled by ln 2 once per row
+        wv[e] *= mf;
+        rs.qsum += wv[e];
         asm volatile("" : "+v"(wv[e]), "+v"(rs.lossacc), "+v"(rs.qsum));
       }
       if ((e & 7) == 7) {
@@ -424,8 +462,10 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
           mx = fmaxf(mx, mxp[(size_t)s * kBI + (i_row - b * kBI)]);
         }
       }
+      // the positives' shift with log2(neg) folded in (neg = negs 2^m_run; rows without negatives: 2^-100 stands in
+      // for zero, q rounds to 0 and the log terms cancel to fp32 resolution)
       rs.neg_true = negs * exp2f(rs.m_run);
-      rs.m2 = shift_pos ? mx * k2 : 0.f;
+      rs.m2 = (shift_pos ? mx * k2 : 0.f) + fmaxf(__log2f(negs) + rs.m_run, -100.f);
     }
     f16x8 pah[2], pal[2];
     // positives share the anchor's label, so the pair weight is 1 for an anchor of a new class and p_i . p_j otherwise
@@ -451,21 +491,32 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
       for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
     StageP stage;
-    auto fetch = [&](int v) {
-      const int j0 = ul.at(min(v, v_end - 1)) * kTJ;
-      tile_fetch_p(stage, ch16, row_label, j0);
-      if (PROB) stage.side = *reinterpret_cast<const u32x4*>(p16 + (size_t)(j0 + s_row) * 2 * KP16 + s_c * 8);
-      fetch_fence();
-    };
+    TileSrc src;
+    src.ch16 = ch16; src.row_label = row_label; src.p16 = p16; src.KP16 = KP16; src.s_row = s_row; src.s_c = s_c;
+    src.chunks = chunks; src.ppitch = ppitch;
+    auto j0_of = [&](int v) { return ul.at(min(v, v_end - 1)) * kTJ; };
     auto commit = [&](int buf) {
       tile_commit_p(stage, cs0 + buf * kBufHalfs, labs0 + buf * 8);
       if (PROB && (int)threadIdx.x < kTJ * chunks)
         *reinterpret_cast<u32x4*>(ps0 + (buf * kTJ + s_row) * ppitch + s_c * 8) = stage.side;
     };
-    fetch(v_begin); commit(0);
-    fetch(v_begin + 1); commit(1);
-    fetch(v_begin + 2); commit(2);
+    fetch_tile<PROB>(stage, src, j0_of(v_begin)); commit(0);
+    fetch_tile<PROB>(stage, src, j0_of(v_begin + 1)); commit(1);
+    fetch_tile<PROB>(stage, src, j0_of(v_begin + 2));     // committed by step 0
     __syncthreads();
+
+    // the self pair: row lane&31 of the tile that starts at this wave's first anchor; it is one of this lane's 16 elements
+    // when bit 2 of the row equals the lane's half: its label byte is overwritten with 255 there (never an anchor label)
+    u32x4 self_patch = {0u, 0u, 0u, 0u};
+    const int i0w = b * kBI + wave * kTI;
+    if (MODE == 1) {
+      const int r = lane & 31;
+      if (((r >> 2) & 1) == half) {
+        const u32 m = 0xffu << (8 * (r & 3));
+        self_patch[0] = (r >> 3) == 0 ? m : 0u; self_patch[1] = (r >> 3) == 1 ? m : 0u;
+        self_patch[2] = (r >> 3) == 2 ? m : 0u; self_patch[3] = (r >> 3) == 3 ? m : 0u;
+      }
+    }
 
     Frags f;
     f32x16 xa, xb;
@@ -487,15 +538,13 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
     auto step = [&](auto bt, f32x16& x_cur, f32x16& x_next, f16x8 (&w_prev)[2], f16x8 (&w_new)[2], u32x4& lw_cur,
                     u32x4& lw_next, int t) {
       constexpr int B = decltype(bt)::value;
-      fetch(v_begin + t + 3);
       const int j0 = ul.at(v_begin + t) * kTJ;
       if (PROB && need_prob) pm = prob_tile_p(ps0 + B * kTJ * ppitch, ppitch, KP16, nk, pah, pal, lane);
-      tile_step<MODE, PROB, B>(acc, a16, f, x_cur, x_next, w_prev, w_new, lw_cur, lw_next, rs, pm, cs0, labs0, sbase, vbase,
-                               half, j0);
+      tile_step<MODE, PROB, B>(acc, a16, f, x_cur, x_next, w_prev, w_new, lw_cur, lw_next, rs, pm, cs0, labs0, ps0, sbase, vbase,
+                               half, j0 == i0w, self_patch, stage, src, j0_of(v_begin + t + 3));
 #pragma unroll
       for (int q = 0; q < 8; ++q) asm volatile("" : "+a"(acc[q]));   // accumulators stay in the AGPR half
-      commit((B + 3) % kRing);
-      __syncthreads();
+      asm volatile("" : "+v"(x_next));   // the scores are read by VALU instructions next step: keep them out of the AGPRs
     };
     for (int t = 0; t < nt; t += 4) {
       step(std::integral_constant<int, 0>{}, xa, xb, wa, wb, lwa, lwb, t);
@@ -514,6 +563,23 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
     if (MODE == 0) {
       rs.neg += __shfl_xor(rs.neg, 32, 64);
       rs.mx = fmaxf(rs.mx, __shfl_xor(rs.mx, 32, 64));
+      // padding rows among the unit's tiles: rows [A, Apad) and [Apad + Co, Cpad); each added exp2(0 * k2 - m_run)
+      int npad = 0;
+      {
+        const int Apad = meta->Apad, Cend = Apad + meta->Co, Cpad = meta->Cpad;
+        const int ra[3] = {ul.a0, ul.a1, ul.a2}, rn[3] = {ul.n0, ul.n1, ul.n2};
+        int base = 0;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int lo = max(v_begin, base), hi = min(v_end, base + rn[q]);   // list positions of range q inside the unit
+          if (hi > lo) {
+            const int r0 = (ra[q] + lo - base) * kTJ, r1 = (ra[q] + hi - base) * kTJ;
+            npad += max(0, min(r1, Apad) - max(r0, A)) + max(0, min(r1, Cpad) - max(r0, Cend));
+          }
+          base += rn[q];
+        }
+      }
+      rs.neg -= (float)npad * __builtin_amdgcn_exp2f(__builtin_fmaf(0.f, rs.k2, -rs.m_run));
     } else {
       rs.lossacc += __shfl_xor(rs.lossacc, 32, 64);
       rs.qsum += __shfl_xor(rs.qsum, 32, 64);
