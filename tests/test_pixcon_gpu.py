@@ -219,6 +219,61 @@ def test_fp16_extreme_logit_range(T):
     assert err < 3e-3, err
 
 
+@pytest.mark.parametrize("dominant,B,h,H", [(9, 4, 33, 513), (3, 2, 21, 321), (None, 3, 33, 513)])
+def test_fp16_planned_sweeps_vs_split_kernels_and_oracle(dominant, B, h, H):
+    """The planned form of the fp16 path (pixcon_loss_f16p.hip: unit lists built on the device, sweep 1 skipping the tiles that
+    lie wholly inside an anchor block's own label, the row maximum seeded with S_ii, padding rows corrected per unit, the self
+    pair patched into the label word) against the fixed-split kernels it replaces (precision "f16_split", the A/B
+    reference) and the fp32 oracle: one teacher class dominating (2/3 of all pairs are positives, whole anchor blocks carry
+    one label - the skipping case) and the uniform case.  The plan itself is read back: with a dominant label sweep 1 must
+    have dropped tiles."""
+    from ucd_amd import hip
+    from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare
+    N, K = 256, 16
+    f_n, f_o, l_po, labels = synth.contrastive_case(5150 + h, B, N, h, h, K, H, H, list(range(16, 21)))
+    if dominant is not None:
+        l_po[:, dominant] += 6.0
+    prep = OC.pre_contrastive_pixel(f_n, labels, l_po, f_o)
+    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    _, da, neg, G, num = OC.pixcon_loss_backward(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    fn_d = fn_d.contiguous(memory_format=torch.channels_last)
+    out = {}
+    for sort in (True, False):
+        pb = pixcon_prepare(fn_d, lab_d, lpo_d, fo_d, sort_by_label=sort, fp16=True)
+        m = pb.meta_host()
+        for prec in ("f16", "f16_split"):
+            loss_out, grad_a, stats = pixcon_loss_raw(pb, 0.07, True, True, need_grad=True, row_stats=True, precision=prec)
+            if prec == "f16":
+                ws = hip.workspace(hip.load().ucd_pixcon_loss_workspace_bytes(pb.BHW, pb.N, pb.K), fn_d.device, "pixloss")
+                hdr = ws[:32].view(torch.int32).cpu().tolist()                      # ctr1 ctr2 U1 U2 CH1 CH2 nblk
+                nblk, ntiles = (m.A + 127) // 128, m.Cpad // 32
+                assert hdr[6] == nblk and hdr[0] >= hdr[2] > 0 and hdr[1] >= hdr[3] > 0          # every unit was drawn
+                tiles1 = hdr[2] * hdr[4]                                            # upper bound of sweep-1 tile steps
+                if sort and dominant is not None:
+                    assert tiles1 < 0.8 * nblk * ntiles, (tiles1, nblk * ntiles)     # pure-positive tiles were skipped
+                if not sort:
+                    assert tiles1 >= nblk * ntiles                                  # nothing to skip without the grouping
+            g_pix = torch.zeros(B * h * h, N, device=fn_d.device)
+            g_pix[pb.anchor_pix[:m.A].long()] = grad_a[:m.A, :N].float()
+            s_pix = torch.zeros(3, B * h * h, device=fn_d.device)
+            s_pix[:, pb.anchor_pix[:m.A].long()] = stats[:, :m.A]
+            out[(prec, sort)] = (loss_out[0].item(), g_pix, s_pix)
+            assert abs(loss_out[0].item() - ref.item()) / abs(ref.item()) < 1e-3, (prec, sort)
+            if not sort:                                                            # oracle rows are in pixel order
+                torch.testing.assert_close(stats[0, :m.A].cpu().double(), neg, rtol=2e-3, atol=1e-6)
+                torch.testing.assert_close(stats[1, :m.A].cpu().double(), num.double(), rtol=0, atol=0)
+                err = (grad_a[:m.A, :N].cpu().double() - da).abs().max().item() / da.abs().max().item()
+                assert err < 2e-3, (prec, err)
+    for sort in (True, False):
+        (l1, g1, s1), (l2, g2, s2) = out[("f16", sort)], out[("f16_split", sort)]
+        assert abs(l1 - l2) / abs(l2) < 2e-4
+        assert ((g1 - g2).norm() / g2.norm()).item() < 1e-3
+        torch.testing.assert_close(s1[0], s2[0], rtol=1e-3, atol=1e-6)               # negative sums per anchor
+        torch.testing.assert_close(s1[2], s2[2], rtol=1e-3, atol=1e-5)               # per-row losses
+    assert ((out[("f16", True)][1] - out[("f16", False)][1]).norm() / out[("f16", False)][1].norm()).item() < 1e-3
+
+
 def test_full_size_invariants_b24_513():
     """BASELINE.json's full per-GPU shape (B = 24, 513x513 -> 26136 pixels, up to 26136 x 52272 pairs), where the oracle's
     A x C matrices (5.5 GB each) do not fit a test: size-independent properties instead.  (1) The loss and the gradient do

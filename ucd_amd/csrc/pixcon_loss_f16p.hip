@@ -387,9 +387,10 @@ struct UnitList {   // up to three tile ranges addressed as one list
   __device__ __forceinline__ int at(int v) const { return v < n0 ? a0 + v : (v < n0 + n1 ? a1 + (v - n0) : a2 + (v - n0 - n1)); }
 };
 
-// One persistent workgroup per CU; MODE / PROB as in tile_step.  negp / mxp / lossp / qsump: [slot][128]; Up / Vp:
+// One persistent workgroup per CU; MODE as in tile_step; HAS_PROB: the call weights positives with the teacher's joint
+// probabilities - a unit then runs the PROB instance of its body only when one of its 128 anchors is an old-class anchor.  negp / mxp / lossp / qsump: [slot][128]; Up / Vp:
 // [slot][128][256].
-template <int MODE, bool PROB>
+template <int MODE, bool HAS_PROB>
 __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
     const _Float16* ch16, const uint8_t* row_label, const _Float16* p16, int KP16, const ucd_pixcon_meta* __restrict__ meta,
     PlanHdr* hdr, const int* __restrict__ seg, const int* __restrict__ us, const int* __restrict__ order,
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
   const int vbase = (4 * half + ((lane & 15) >> 2)) * kPitchH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const int nk = KP16 / 16;
   // probability rows of a tile: one 16-byte piece per thread (KP16 <= 32: at most 8 pieces per row)
-  const int chunks = PROB ? (2 * KP16) / 8 : 1;
+  const int chunks = HAS_PROB ? (2 * KP16) / 8 : 1;
   const int s_idx = min((int)threadIdx.x, kTJ * chunks - 1);
   const int s_row = s_idx / chunks, s_c = s_idx - s_row * chunks;
 
@@ -433,6 +434,9 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
 
     const int i_row = b * kBI + wave * kTI + (lane & 31);
     const bool row_ok = i_row < A;
+    const int unit_prob = HAS_PROB ? __syncthreads_or(row_ok && (int)row_label[row_ok ? i_row : 0] < min_new) : 0;
+    auto run_unit = [&](auto prob_tag) __attribute__((always_inline)) {
+    constexpr bool PROB = decltype(prob_tag)::value;
     RowState rs;
     rs.la = row_ok ? (int)row_label[i_row] : -1;
     rs.k2 = k2;
@@ -592,6 +596,9 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
       }
       store_values(acc, out_acc + o * kN, half);
     }
+    };
+    if (HAS_PROB && unit_prob) run_unit(std::true_type{});
+    else run_unit(std::false_type{});
     __syncthreads();   // the ring and s_unit are reused by the next unit
   }
 }
@@ -710,9 +717,11 @@ int pixcon16p_launch(const _Float16* ch16, const uint8_t* row_label, const _Floa
   if (rc) return rc;
   const size_t lds_base = (size_t)kRing * kBufHalfs * 2 + kRing * 8 * 4 + 16;
   const size_t lds_prob = lds_base + (size_t)kRing * kTJ * (2 * KP16 + 8) * 2;
-  UCD_TRY_LDS((pixcon16p_sweep_kernel<0, false>), 160 * 1024);
-  UCD_TRY_LDS((pixcon16p_sweep_kernel<1, false>), 160 * 1024);
-  UCD_TRY_LDS((pixcon16p_sweep_kernel<1, true>), 160 * 1024);
+  // opt in to more than 64 KiB of dynamic LDS, per call (no process-wide state); only what is needed: the block-wide vote of
+  // the probability instance keeps a static word of its own
+  UCD_TRY_LDS((pixcon16p_sweep_kernel<0, false>), (int)lds_base);
+  UCD_TRY_LDS((pixcon16p_sweep_kernel<1, false>), (int)lds_base);
+  UCD_TRY_LDS((pixcon16p_sweep_kernel<1, true>), (int)lds_prob);
   pixcon16p_sweep_kernel<0, false><<<grid, kThreads, lds_base, s>>>(ch16, row_label, nullptr, 0, meta, hdr, seg1, us1, order1, us1,
                                                                     k2, shift_pos, nullptr, nullptr, negp, mxp, Up);
   rc = check_launch(fn);
