@@ -461,6 +461,8 @@ def test_bf16_step_bias_against_the_fp32_step_of_the_product():
         assert rel[k] < BF16_BIAS_BOUND[k], (k, rel[k])
 
 
-# measured on MI355X: ce 0.3 %, con 0.8 %, lkd 3.6 % (the KD term compares student and teacher soft-max tails: the most
-# rounding-sensitive of the three), loss (= ce + con / 100) 0.4 %
-BF16_BIAS_BOUND = {"ce": 1.5e-2, "con": 2.5e-2, "lkd": 6e-2, "loss": 1.5e-2}
+# The difference is a sample of rounding noise, not a bias: over three input seeds and both bf16 code paths (fused conv+ABN
+# nodes / module by module) it scatters with either sign - ce -2.1 .. +3.2 %, con -1.3 .. 0 %, lkd -3.0 .. +4.5 %, loss
+# -1.9 .. +2.5 % (tools/bf16_bias_probe.py, profiles/r02_bf16_bias_probe.txt): a random-init 100-layer network amplifies
+# which leaky-ReLU branch the elements nearest zero take.  The bounds are that spread plus margin.
+BF16_BIAS_BOUND = {"ce": 5e-2, "con": 2.5e-2, "lkd": 8e-2, "loss": 4e-2}

@@ -200,7 +200,15 @@ class Conv1x1(Conv2d):
 
     def __init__(self, in_channels, out_channels, bias=False):
         super().__init__(in_channels, out_channels, 1, stride=1, padding=0, bias=bias)
-        self.as_gemm = min(in_channels, out_channels) >= 256 and max(in_channels, out_channels) >= 1024
+        # wide: the tuned library GEMM beats MIOpen's convolution (docstring); as_gemm: the layer runs on the row matrix at all -
+        # the narrow 64-aligned layers too since the own kernel exists (tools/conv1x1_probe.py: 256->64 at 129^2 39 us against
+        # 55 us hipBLASLt and 61 us MIOpen; 64->256 41 / 54 / 86; 512->128 at 65^2 25 / 29 / 44; 128->512 28 / 36 / 50)
+        self.wide = min(in_channels, out_channels) >= 256 and max(in_channels, out_channels) >= 1024
+        self.as_gemm = self.wide or (in_channels % 64 == 0 and out_channels % 64 == 0)
+        # input gradient d x = d z . w (a GEMM with K = Co, N = Ci) through the own kernel on the cached transposed weight where
+        # it beats the library: short K (tools/conv1x1_probe.py: 256 -> 1024 22.8 vs 31.3 us, the narrow layers 25-41 vs 29-54)
+        self.own_dgrad = (in_channels % 64 == 0 and out_channels % 64 == 0 and out_channels <= 512
+                          and in_channels * out_channels <= (1 << 18))
 
     def forward(self, x):
         # bf16 activations only: in the fp32 parity mode (--opt_level O0) every convolution stays on one code
@@ -284,7 +292,7 @@ class _ConvABNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, fused, dilation=0,
-                wflip=None, own_dgrad=False):
+                wflip=None, own_dgrad=False, wgrad_conv=False):
         from . import hip
         B, K, H, W = x.shape
         N = w4.shape[0]
@@ -295,7 +303,7 @@ class _ConvABNFunction(torch.autograd.Function):
         buf = torch.empty(6 * N, dtype=torch.float32, device=x.device)
         conv3 = dilation > 0
         w2 = w4.permute(0, 2, 3, 1).reshape(N, 9 * K) if conv3 else w4.reshape(N, K)
-        ctx.conv3 = (dilation, wflip, own_dgrad)
+        ctx.conv3 = (dilation, wflip, own_dgrad, wgrad_conv)
         if conv3 and not fused:
             z = F.conv2d(x, w4, None, 1, dilation, dilation).contiguous(memory_format=torch.channels_last)
             hip.abn_forward(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, weight, bias, running_mean,
@@ -330,7 +338,7 @@ class _ConvABNFunction(torch.autograd.Function):
         sums = torch.empty(2 * N, dtype=torch.float32, device=x.device)
         hip.abn_backward(z, N, dy, N, y, N if y is not None else 0, dz, N, dres, N if has_res else 0, M, N, None, HW,
                          buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:], bias, weight, sums, float(M), True, True, act, slope)
-        dilation, wflip, own_dgrad = ctx.conv3
+        dilation, wflip, own_dgrad, wgrad_conv = ctx.conv3
         if dilation > 0:
             dx = dw = None
             if ctx.needs_input_grad[0]:
@@ -344,18 +352,24 @@ class _ConvABNFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [dilation, dilation], [dilation, dilation],
                                                          False, [0, 0], 1, [False, True, False])[1]
-            return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None
         w2 = w4.reshape(N, K)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            hip.gemm_bf16(1, rows(dz), w2, rows(dx))
-        if ctx.needs_input_grad[1]:
+            if own_dgrad and wflip is not None:
+                hip.conv1x1(rows(dz), wflip.reshape(K, N), rows(dx))
+            else:
+                hip.gemm_bf16(1, rows(dz), w2, rows(dx))
+        if ctx.needs_input_grad[1] and wgrad_conv:
+            dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        elif ctx.needs_input_grad[1]:
             S = _wgrad_split(M)
             dzr, xr = rows(dz), rows(x)
             dw = (torch.bmm(dzr.view(S, M // S, N).transpose(1, 2), xr.view(S, M // S, K)).sum(0) if S > 1 else dzr.t() @ xr)
             dw = dw.as_strided(w4.shape, w4.stride())
-        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_param=None, with_skip=False):
@@ -369,7 +383,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
             and _is_fused_abn(bn) and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda
             and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
         return None
-    dilation, wflip, fused, own_dgrad = 0, None, None, False
+    dilation, wflip, fused, own_dgrad, wgrad_conv = 0, None, None, False, False
     if is3:
         if not (conv.stride == (1, 1) and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1]
                 and conv.groups == 1 and not with_skip and conv.weight.is_contiguous(memory_format=torch.channels_last)):
@@ -383,6 +397,9 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         wflip = conv._w16_flip if conv.working_weight() is not None else None
     else:
         fused = _own_gemm_with_stats(conv.in_channels, conv.out_channels)
+        wflip = conv._w16_flip if (conv.own_dgrad and conv.working_weight() is not None) else None
+        own_dgrad = wflip is not None
+        wgrad_conv = not conv.wide
     from . import abn as _abn
     from . import hip
     node = _gemm_node()
@@ -399,7 +416,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         slope = bn.activation_param if activation_param is None else activation_param
         bn.__dict__.pop("_eval_cache", None)
         y = _ConvABNFunction.apply(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                   act, slope, fused, dilation, wflip, own_dgrad)
+                                   act, slope, fused, dilation, wflip, own_dgrad, wgrad_conv)
         return (y, x) if with_skip else y
     if not node.dense_channels_last(x):
         return None
@@ -419,7 +436,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     bn.__dict__.pop("_eval_cache", None)
     out = node.conv_abn_train(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
                               slope, comm.handle if comm is not None else 0, world, _hip_stream(), bn._direct_grad_ptr(),
-                              bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad))
+                              bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad), bool(wgrad_conv))
     return (out[0], out[1]) if with_skip else out[0]
 
 

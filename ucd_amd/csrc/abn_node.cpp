@@ -346,9 +346,10 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                c10::optional<at::Tensor> residual_, at::Tensor running_mean, at::Tensor running_var,
                                double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
                                int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
-                               c10::optional<at::Tensor> wflip_, bool own_dgrad) {
+                               c10::optional<at::Tensor> wflip_, bool own_dgrad, bool wgrad_conv) {
     // dilation = 0: 1x1 convolution; dilation >= 1: 3x3, stride 1, padding = dilation (implicit GEMM, taps = 9), weight in
-    // channels-last memory order; wflip = w.flip(2, 3).transpose(0, 1) (channels-last) for the input gradient
+    // channels-last memory order; wflip = w.flip(2, 3).transpose(0, 1) (channels-last; for a 1x1 layer the transposed
+    // weight [Ci, Co]) for the input gradient through the own kernel (own_dgrad); wgrad_conv: weight gradient by MIOpen
     TORCH_CHECK(dense_channels_last(x) && x.scalar_type() == at::kBFloat16, "ucd conv+abn node: x must be dense channels-last bf16");
     const bool conv3 = dilation > 0;
     TORCH_CHECK(w4.dim() == 4 && w4.scalar_type() == at::kBFloat16 && w4.size(1) == x.size(1) &&
@@ -437,6 +438,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     ctx->saved_data["with_skip"] = with_skip;
     ctx->saved_data["dilation"] = dilation;
     ctx->saved_data["own_dgrad"] = own_dgrad;
+    ctx->saved_data["wgrad_conv"] = wgrad_conv;
     if (with_skip) return {y, x};
     return {y};
   }
@@ -509,13 +511,24 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {dilation, dilation}, {dilation, dilation}, false,
                                                   {0, 0}, 1, {false, true, false}));
       return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-              none, none, none};
+              none, none, none, none};
     }
     const size_t wsb = ucd_gemm_workspace_bytes();
     void* gws = workspace(x, wsb, stream, 1);
     if (ctx->needs_input_grad(0)) {
       const bool fold = dskip.defined() && dz.defined() && dskip.scalar_type() == at::kBFloat16;
-      if (fold) {
+      if (own_dgrad && dz.defined() && wflip.defined()) {
+        // narrow / short-K layers: d x = d z . w through the own kernel on the cached transposed weight [Ci, Co]; the
+        // shortcut's gradient is the accumulate operand (no separate add)
+        if (fold && !dense_channels_last(dskip)) dskip = dskip.contiguous(at::MemoryFormat::ChannelsLast);
+        dx = fold ? dskip : at::empty_like(x);
+        ucd_conv1x1_desc d;
+        memset(&d, 0, sizeof(d));
+        d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)N; d.y = dx.data_ptr(); d.ldy = (int)K;
+        d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0; d.accumulate = fold ? 1 : 0;
+        check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
+        if (!fold && dskip.defined()) dx = dx + dskip;
+      } else if (fold) {
         if (!dense_channels_last(dskip)) dskip = dskip.contiguous(at::MemoryFormat::ChannelsLast);
         if (!ucd_gemm_has_plan(1, (int)M, (int)K, (int)N, (int)N, (int)K, (int)K)) {   // tune once, into scratch
           at::Tensor scratch = at::empty_like(x);
@@ -537,7 +550,11 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         dx = dskip;
       }
     }
-    if (ctx->needs_input_grad(1) && dz.defined()) {
+    if (ctx->needs_input_grad(1) && dz.defined() && ctx->saved_data["wgrad_conv"].toBool()) {
+      // narrow layers (<= 512 channels at 65^2 / 129^2): MIOpen's weight-gradient solver beats the split-M products
+      dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {0, 0}, {1, 1}, false, {0, 0}, 1,
+                                                {false, true, false}));
+    } else if (ctx->needs_input_grad(1) && dz.defined()) {
       at::Tensor dz2 = dz.permute({0, 2, 3, 1}).reshape({M, N}), x2 = x.permute({0, 2, 3, 1}).reshape({M, K});
       const int64_t S = wgrad_split(M);
       if (S > 1) {
@@ -551,7 +568,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       dw = dw.as_strided(w4.sizes(), w4.strides());
     }
     return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none};
+            none, none, none, none};
   }
 };
 
@@ -559,9 +576,9 @@ std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor w
                                        c10::optional<at::Tensor> residual, at::Tensor running_mean, at::Tensor running_var,
                                        double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
                                        int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
-                                       c10::optional<at::Tensor> wflip, bool own_dgrad) {
+                                       c10::optional<at::Tensor> wflip, bool own_dgrad, bool wgrad_conv) {
   return ConvABNTrainNode::apply(x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world,
-                                 stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad);
+                                 stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad, wgrad_conv);
 }
 
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,

@@ -71,15 +71,16 @@ class Bf16Weights:
             hook.remove()
 
     def _build_flip_table(self):
-        """Flipped + transposed bf16 copies of the stride-1 weights whose input gradient runs on the FORWARD solver
-        (``blocks._StrideOneConvFn``: dx = conv2d(dy, w.flip(2, 3).transpose(0, 1))): one flat buffer, refreshed together with
+        """Flipped + transposed bf16 copies of the stride-1 weights whose input gradient runs as a FORWARD convolution
+        (``blocks._StrideOneConvFn`` / the conv+ABN node: dx = conv2d(dy, w.flip(2, 3).transpose(0, 1)); for a 1x1 layer this is
+        the transposed weight [Ci, Co] the own GEMM kernel takes): one flat buffer, refreshed together with
         the working copies by ONE batched kernel (``ucd_flip_weights_batched``) instead of a flip + copy per layer and step."""
         from .blocks import Conv1x1, Conv3x3
         self.flat16_flip = None
         if not self.trainable:
             return
         mods = [m for m in self.convs if isinstance(m, (Conv3x3, Conv1x1)) and m.weight.requires_grad and m.bias is None
-                and m.stride == (1, 1) and m.groups == 1 and not (isinstance(m, Conv1x1) and m.as_gemm)
+                and m.stride == (1, 1) and m.groups == 1 and not (isinstance(m, Conv1x1) and m.as_gemm and not m.own_dgrad)
                 and m.weight.is_contiguous(memory_format=torch.channels_last)]
         if not mods:
             return
