@@ -424,7 +424,8 @@ int ucd_image_path(const uint8_t* const* src, const int* desc, int B, int S, int
  * act_in / act_out: UCD_ACT_LEAKY_RELU or UCD_ACT_IDENTITY (elu layers keep the separate ucd_abn_* kernels); modes 1 and 3
  * need out_mean, out_scale and out_shift (pass zeros / ones for a missing term).
  * Shapes: K and N multiples of 64, any M; pointers 16-byte aligned, leading dimensions (elements) multiples of 8.
- * partial has ucd_conv1x1_row_tiles(M) row tiles.  The input gradient of the layer is the same call on (dY, W^T)
+ * partial: out_mode 2 needs ucd_conv1x1_stats_partial_bytes(M, N) bytes (the row tiles' [3][N] triples); out_mode 3 needs
+ * ucd_conv1x1_row_tiles(M) rows of [2][N].  The input gradient of the layer is the same call on (dY, W^T)
  * (ucd_transpose_bf16 builds W^T); the weight gradient is ucd_conv1x1_wgrad. */
 typedef struct ucd_conv1x1_desc {
   const void* a;  int lda;
@@ -447,6 +448,7 @@ typedef struct ucd_conv1x1_desc {
 } ucd_conv1x1_desc;
 
 int ucd_conv1x1_row_tiles(int M);
+size_t ucd_conv1x1_stats_partial_bytes(int M, int C);
 int ucd_conv1x1(const ucd_conv1x1_desc* desc, ucd_stream_t stream);
 
 /* out_mode 2 partials -> batch statistics of the [M, C] product -> buf = [sums(2C) | kshift(C) | mean | invstd | scale]

@@ -66,7 +66,7 @@ def test_conv1x1_modes_against_fp32_product(M, K, N):
     assert _rel(y, (ref - om) * osc + osh) < 3e-3
     # statistics epilogue + finalize (|gamma| + eps scale, running statistics)
     tiles = hip.load().ucd_conv1x1_row_tiles(M)
-    part = torch.full((tiles, 3, N), float("nan"), device=DEV)
+    part = hip.conv1x1_stats_partial(M, N, DEV).fill_(float("nan"))
     hip.conv1x1(a, w, y, out_mode=2, partial=part)
     buf = torch.zeros(6 * N, device=DEV)
     rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
@@ -309,7 +309,7 @@ def test_conv3x3_implicit_gemm_mode(B, K, N, H, W, d):
     w = (torch.randn(N, K, 3, 3, device=DEV, generator=g) * (2.0 / (9 * K)) ** 0.5).bfloat16().contiguous(memory_format=cl)
     ref = F.conv2d(x.float(), w.float(), None, 1, d, d)
     M = B * H * W
-    part = torch.full((hip.conv1x1_row_tiles(M), 3, N), float("nan"), device=DEV)
+    part = hip.conv1x1_stats_partial(M, N, DEV).fill_(float("nan"))
     hip.conv1x1(rows(x), wrow(w), rows(y), conv3=(H, W, d), out_mode=2, partial=part)
     assert _rel(y, ref) < 3e-3
     buf = torch.zeros(6 * N, device=DEV)

@@ -89,20 +89,23 @@ def test_conv3x3_input_gradient_on_the_forward_solver(ci, co, hw, d):
     assert rel(y, yr) < 1e-2 and rel(x.grad, xr.grad) < 1e-2 and rel(conv.weight.grad, wr.grad) < 1e-2
 
 
-@pytest.mark.parametrize("ci,co,hw", [(256, 64, 65), (64, 256, 65), (512, 128, 33)])
-def test_narrow_conv1x1_input_gradient_on_the_forward_solver(ci, co, hw):
-    """The narrow 1x1 convolutions stay with MIOpen; their input gradient is the forward solver on the transposed weight."""
+@pytest.mark.parametrize("ci,co,hw", [(256, 64, 65), (64, 256, 65), (512, 128, 33), (256, 40, 65), (72, 256, 33)])
+def test_narrow_conv1x1_standalone_forward_and_gradients(ci, co, hw):
+    """A narrow 1x1 convolution called on its own (outside the conv+ABN node): 64-aligned channel counts run on the row
+    matrix like the wide layers; the others stay with MIOpen, their input gradient on the forward solver (transposed
+    weight).  Either way: the arithmetic of F.conv2d on the bf16-rounded operands."""
     dev = torch.device("cuda:0")
     torch.manual_seed(ci + co)
     B = 8
     conv = Conv1x1(ci, co).to(dev).to(memory_format=torch.channels_last)
-    assert not conv.as_gemm
+    aligned = ci % 64 == 0 and co % 64 == 0
+    assert conv.as_gemm == aligned and not conv.wide
     x32 = torch.randn(B, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     dy32 = torch.randn(B, co, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     x = x32.to(torch.bfloat16).requires_grad_(True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = conv(x)
-    assert "StrideOneConv" in y.grad_fn.name(), y.grad_fn.name()
+    assert aligned or "StrideOneConv" in y.grad_fn.name(), y.grad_fn.name()
     y.backward(dy32.to(torch.bfloat16))
     xr = x32.to(torch.bfloat16).float().requires_grad_(True)
     wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)

@@ -59,7 +59,7 @@ def check(M, K, N, g):
     errs["pro+affine+res"] = ((y.float() - ref3).norm() / ref3.norm()).item()
     # mode 2: statistics
     tiles = hip.load().ucd_conv1x1_row_tiles(M)
-    part = torch.zeros(tiles, 3, N, device=dev)
+    part = hip.conv1x1_stats_partial(M, N, dev)
     hip.conv1x1(a, w, y, out_mode=2, partial=part)
     errs["stats_y"] = ((y.float() - ref).norm() / ref.norm()).item()
     buf = torch.zeros(6 * N, device=dev)
@@ -110,10 +110,12 @@ def timing(M, K, N):
     res = torch.randn(M, N, device=dev).bfloat16()
     v = torch.rand(max(K, N), device=dev) + 0.5
     tiles = hip.load().ucd_conv1x1_row_tiles(M)
-    part = torch.zeros(tiles, 3, N, device=dev)
+    part = hip.conv1x1_stats_partial(M, N, dev)
     t_lib = bench(lambda: hip.gemm_bf16(0, a, w, y)) if hip.gemm_available() else float("nan")
     t_plain = bench(lambda: hip.conv1x1(a, w, y))
     t_stats = bench(lambda: hip.conv1x1(a, w, y, out_mode=2, partial=part))
+    sbuf = torch.zeros(6 * N, device=dev)
+    t_fin = bench(lambda: hip.conv1x1_stats_finalize(part, M, N, None, None, None, 0.1, 1e-5, sbuf))
     t_pro = bench(lambda: hip.conv1x1(a, w, y, in_norm=(v, v, v, 1, 0.01)))
     t_aff = bench(lambda: hip.conv1x1(a, w, y, out_mode=1, out_norm=(v, v, v, None, 1, 0.01)))
     t_affr = bench(lambda: hip.conv1x1(a, w, y, out_mode=1, out_norm=(v, v, v, None, 1, 0.01), residual=res))
@@ -122,7 +124,7 @@ def timing(M, K, N):
     t_full = bench(lambda: hip.conv1x1(a, w, y, in_norm=(v, v, v, 1, 0.01), out_mode=1, out_norm=(v, v, v, None, 1, 0.01), residual=res))
     byt = 2 * (M * K + M * N + N * K)
     line = (f"M={M:6d} K={K:4d} N={N:4d}  hipBLASLt {t_lib:7.1f} us | own plain {t_plain:7.1f} us ({byt / t_plain / 1e6:5.2f} TB/s, "
-            f"{2 * M * K * N / t_plain / 1e6:6.1f} TF/s)  +stats {t_stats:6.1f} pro {t_pro:6.1f} aff {t_aff:6.1f} aff+res {t_affr:6.1f} bwdact {t_bwd:6.1f} pro+aff+res {t_full:6.1f}")
+            f"{2 * M * K * N / t_plain / 1e6:6.1f} TF/s)  +stats {t_stats:6.1f} (finalize {t_fin:4.1f}) pro {t_pro:6.1f} aff {t_aff:6.1f} aff+res {t_affr:6.1f} bwdact {t_bwd:6.1f} pro+aff+res {t_full:6.1f}")
     if N % 128 == 0 and K % 128 == 0:
         dw = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
         t_w = bench(lambda: hip.conv1x1_wgrad(res, a, dw))

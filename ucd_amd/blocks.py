@@ -309,7 +309,7 @@ class _ConvABNFunction(torch.autograd.Function):
             hip.abn_forward(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, weight, bias, running_mean,
                             running_var, momentum, eps, True, buf, None, act, slope)
         elif fused:
-            part = torch.empty(hip.conv1x1_row_tiles(M), 3, N, dtype=torch.float32, device=x.device)
+            part = hip.conv1x1_stats_partial(M, N, x.device)
             hip.conv1x1(rows(x), w2, rows(z), out_mode=2, partial=part, conv3=(H, W, dilation) if conv3 else None)
             hip.conv1x1_stats_finalize(part, M, N, weight, running_mean, running_var, momentum, eps, buf, None, act)
             hip.abn_apply(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, buf[3 * N:4 * N], buf[5 * N:],

@@ -374,8 +374,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)N);
     const void* resp = has_res ? residual.data_ptr() : nullptr;
     if (fused) {
-      const int tiles = ucd_conv1x1_row_tiles((int)M);
-      size_t need = (size_t)tiles * 3 * N * sizeof(float);
+      size_t need = ucd_conv1x1_stats_partial_bytes((int)M, (int)N);
       float* partial = (float*)workspace(x, need > ws_bytes ? need : ws_bytes, stream);
       ucd_conv1x1_desc d;
       memset(&d, 0, sizeof(d));

@@ -41,6 +41,7 @@ typedef __hip_bfloat16 bf16;
 
 constexpr int kThreads = 256;
 constexpr int kBM = 128;
+
 constexpr int kBK = 64;
 
 struct Args {
@@ -359,33 +360,59 @@ __global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) v
 
 // Per-tile shifted sums (k_t, s1_t, s2_t) -> sums about the common shift K = k_0 -> the usual finalize.
 //   sum (y - K) = s1_t + c_t (k_t - K),   sum (y - K)^2 = s2_t + 2 (k_t - K) s1_t + c_t (k_t - K)^2   (exact identities)
-// A block owns 8 channels x 32 tile-lanes (fixed combination order: deterministic).  MODE 1 finalises, MODE 2 packs
-// (mean_r, M2_r) for the SyncBN all-gather.
+// A workgroup of 1024 threads owns 8 channels x 128 tile lanes, four tiles (twelve loads) in flight per thread; fixed
+// combination order (deterministic).  MODE 1 finalises, MODE 2 packs (mean_r, M2_r) for the SyncBN all-gather.
+// Measured alternatives (tools/conv1x1_probe.py, 3121 row tiles x 64 channels, the 129^2 layers): 256 threads with one tile
+// in flight 24-34 us; a two-stage form (64 channels x a group of tiles per workgroup, the last arrival - an atomic ticket
+// behind __threadfence - finalising) 20-34 us: the device-scope fences cost more than the second launch they save.
+constexpr int kStatThreads = 1024;
 template <int MODE>
-__global__ __launch_bounds__(kThreads) void tile_stats_reduce_kernel(const float* __restrict__ partial, int tiles, int M, int C,
-                                                                    float* __restrict__ sums, float* __restrict__ kout,
-                                                                    FinalizeArgs fin) {
-  __shared__ float lds[2][32][9];
+__global__ __launch_bounds__(kStatThreads) void tile_stats_reduce_kernel(const float* __restrict__ partial, int tiles, int M, int C,
+                                                                        float* __restrict__ sums, float* __restrict__ kout,
+                                                                        FinalizeArgs fin) {
+  constexpr int TL = kStatThreads / 8;
+  __shared__ float lds[2][TL][9];
   const int ch = threadIdx.x & 7, tl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + ch;
   float S1 = 0.f, S2 = 0.f, K = 0.f;
   if (c < C) {
     K = partial[c];
-    for (int t = tl; t < tiles; t += 32) {
-      const float* pt = partial + (size_t)t * 3 * C + c;
+    auto add = [&](int t, float k, float a, float b) {
       const float cnt = (float)min(kBM, M - t * kBM);
-      const float dk = pt[0] - K, a = pt[C], b = pt[2 * C];
+      const float dk = k - K;
       S1 += a + cnt * dk;
       S2 += b + 2.f * dk * a + cnt * dk * dk;
+    };
+    int t = tl;
+    for (; t + 3 * TL < tiles; t += 4 * TL) {
+      const float* p0 = partial + (size_t)t * 3 * C + c;
+      const float* p1 = p0 + (size_t)TL * 3 * C;
+      const float* p2 = p1 + (size_t)TL * 3 * C;
+      const float* p3 = p2 + (size_t)TL * 3 * C;
+      const float k0 = p0[0], a0 = p0[C], b0 = p0[2 * C], k1 = p1[0], a1 = p1[C], b1 = p1[2 * C];
+      const float k2 = p2[0], a2 = p2[C], b2 = p2[2 * C], k3 = p3[0], a3 = p3[C], b3 = p3[2 * C];
+      add(t, k0, a0, b0); add(t + TL, k1, a1, b1); add(t + 2 * TL, k2, a2, b2); add(t + 3 * TL, k3, a3, b3);
+    }
+    for (; t < tiles; t += TL) {
+      const float* pt = partial + (size_t)t * 3 * C + c;
+      add(t, pt[0], pt[C], pt[2 * C]);
     }
   }
   lds[0][tl][ch] = S1;
   lds[1][tl][ch] = S2;
   __syncthreads();
+  if (tl < 8) {   // 128 tile lanes -> 8, then one
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TL / 8; ++i) { t1 += lds[0][tl * (TL / 8) + i][ch]; t2 += lds[1][tl * (TL / 8) + i][ch]; }
+    lds[0][tl * (TL / 8)][ch] = t1;
+    lds[1][tl * (TL / 8)][ch] = t2;
+  }
+  __syncthreads();
   if (tl == 0 && c < C) {
     float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) { t1 += lds[0][i][ch]; t2 += lds[1][i][ch]; }
+    for (int i = 0; i < 8; ++i) { t1 += lds[0][i * (TL / 8)][ch]; t2 += lds[1][i * (TL / 8)][ch]; }
     sums[c] = t1;
     sums[C + c] = t2;
     kout[c] = K;
@@ -668,6 +695,8 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   return check_launch(fn);
 }
 
+size_t ucd_conv1x1_stats_partial_bytes(int M, int C) { return (size_t)ceil_div(M, kBM) * 3 * C * sizeof(float); }
+
 int ucd_conv1x1_stats_finalize(const float* partial, int M, int C, const float* weight, float* running_mean,
                                float* running_var, float momentum, float eps, float* buf, float* pack, int flags,
                                ucd_stream_t stream) {
@@ -679,9 +708,9 @@ int ucd_conv1x1_stats_finalize(const float* partial, int M, int C, const float* 
                    (flags & UCD_NORM_ABS_GAMMA) != 0};
   hipStream_t s = (hipStream_t)stream;
   if (pack)
-    tile_stats_reduce_kernel<2><<<ceil_div(C, 8), kThreads, 0, s>>>(partial, tiles, M, C, sums, kshift, fin);
+    tile_stats_reduce_kernel<2><<<ceil_div(C, 8), kStatThreads, 0, s>>>(partial, tiles, M, C, sums, kshift, fin);
   else
-    tile_stats_reduce_kernel<1><<<ceil_div(C, 8), kThreads, 0, s>>>(partial, tiles, M, C, sums, kshift, fin);
+    tile_stats_reduce_kernel<1><<<ceil_div(C, 8), kStatThreads, 0, s>>>(partial, tiles, M, C, sums, kshift, fin);
   return check_launch(fn);
 }
 

@@ -95,6 +95,7 @@ SIGNATURES = {
     "ucd_attmap_workspace_bytes": (_z, [_i, _i]),
     "ucd_attmap": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "ucd_conv1x1_row_tiles": (_i, [_i]),
+    "ucd_conv1x1_stats_partial_bytes": (_z, [_i, _i]),
     "ucd_conv1x1": (_i, [C.POINTER(Conv1x1Desc), _p]),
     "ucd_conv1x1_stats_finalize": (_i, [_p, _i, _i, _p, _p, _p, _f, _f, _p, _p, _i, _p]),
     "ucd_abn_reduce_partials": (_i, [_p, _i, _i, _p, _p, _p, _i, _p]),
@@ -575,3 +576,8 @@ def conv1x1_stats_finalize(partial, M, Cc, weight, running_mean, running_var, mo
 
 def conv1x1_row_tiles(M):
     return load().ucd_conv1x1_row_tiles(M)
+
+
+def conv1x1_stats_partial(M, Cc, device):
+    """Float buffer for the out_mode-2 partials of an [M, Cc] product (a triple per row tile and channel)."""
+    return torch.empty(load().ucd_conv1x1_stats_partial_bytes(M, Cc) // 4, dtype=torch.float32, device=device)
