@@ -20,7 +20,7 @@ namespace ucd {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kTileY = 32, kTileX = 64;     // a thread walks kRows consecutive rows of one pixel column
+constexpr int kTileY = 64, kTileX = 64;     // a thread walks kRows consecutive rows of one pixel column
 constexpr int kRows = kTileY / 4;
 
 __device__ __forceinline__ void up_src(int dst, int in_size, float scale, int& i0, int& i1, float& l0, float& l1) {
@@ -51,16 +51,21 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   up_src(tx0, w, scale_w, xa, dummy, f0, f1);
   up_src(min(tx0 + kTileX, W) - 1, w, scale_w, dummy, xb, f0, f1);
   const int ny = yb - ya + 1, nx = xb - xa + 1, ncell = ny * nx;
+  // CT > 0: kRep copies of the gradient accumulators, a lane adds into copy (lane & 15): the 15-16 consecutive pixel
+  // columns under one low-resolution cell would otherwise hit the same LDS word with one ds_add each (a 16-way
+  // serialisation per class: 0.98 -> measured below); copies are ncell * Ctot floats apart, an odd count of banks
+  constexpr int kRep = CT > 0 ? 16 : 1;
   float* s_log = smem;                      // [ncell][Ctot] student logits
   float* t_log = s_log + ncell * Ctot;      // [ncell][K]    teacher logits
-  float* g_acc = t_log + ncell * K;         // [ncell][Ctot] gradient accumulators
-  float* red = g_acc + ncell * Ctot;        // [2][4] block loss partials
+  float* g_acc = t_log + ncell * K;         // [kRep][ncell][Ctot] gradient accumulators
+  float* red = g_acc + kRep * ncell * Ctot; // [2][4] block loss partials
+  const int gstride = ncell * Ctot;
   for (int i = threadIdx.x; i < ncell * Ctot; i += kThreads) {
     const int cell = i / Ctot, c = i - cell * Ctot;
     const int cy = ya + cell / nx, cx = xa + cell % nx;
     s_log[i] = sem_s[((size_t)(b * h + cy) * w + cx) * ld_s + c];
-    g_acc[i] = 0.f;
   }
+  for (int i = threadIdx.x; i < kRep * gstride; i += kThreads) g_acc[i] = 0.f;
   if (sem_t)
     for (int i = threadIdx.x; i < ncell * K; i += kThreads) {
       const int cell = i / K, c = i - cell * K;
@@ -80,13 +85,14 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   auto flush = [&]() {
     if (CT > 0 && cur_y0 >= 0) {
       const int r0 = (cur_y0 - ya) * nx, r1 = (cur_y1 - ya) * nx;
+      float* ga = g_acc + (threadIdx.x & (kRep - 1)) * gstride;
 #pragma unroll
       for (int c = 0; c < CTA; ++c)
         if (c < Ctot) {
-          atomicAdd(&g_acc[(r0 + x0 - xa) * Ctot + c], lx0 * acc0[c]);
-          atomicAdd(&g_acc[(r0 + x1 - xa) * Ctot + c], lx1 * acc0[c]);
-          atomicAdd(&g_acc[(r1 + x0 - xa) * Ctot + c], lx0 * acc1[c]);
-          atomicAdd(&g_acc[(r1 + x1 - xa) * Ctot + c], lx1 * acc1[c]);
+          atomicAdd(&ga[(r0 + x0 - xa) * Ctot + c], lx0 * acc0[c]);
+          atomicAdd(&ga[(r0 + x1 - xa) * Ctot + c], lx1 * acc0[c]);
+          atomicAdd(&ga[(r1 + x0 - xa) * Ctot + c], lx0 * acc1[c]);
+          atomicAdd(&ga[(r1 + x1 - xa) * Ctot + c], lx1 * acc1[c]);
         }
     }
   };
@@ -217,7 +223,9 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   flush();
   __syncthreads();
   for (int i = threadIdx.x; i < ncell * Ctot; i += kThreads) {
-    const float v = g_acc[i];
+    float v = g_acc[i];
+#pragma unroll
+    for (int r = 1; r < kRep; ++r) v += g_acc[r * gstride + i];
     if (v != 0.f) {
       const int cell = i / Ctot, c = i - cell * Ctot;
       const int cy = ya + cell / nx, cx = xa + cell % nx;
@@ -345,7 +353,7 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const int tiles_x = ceil_div(W, kTileX), tiles_y = ceil_div(H, kTileY);
   // worst-case LDS: (tile/scale + 3) cells per dimension
   const int ny = (int)(kTileY * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
-  const size_t lds = ((size_t)ny * nx * (2 * Ctot + K) + 8) * sizeof(float);
+  const size_t lds = ((size_t)ny * nx * ((Ctot <= 24 ? 17 : 2) * Ctot + K) + 8) * sizeof(float);
   UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
   UCD_TRY_LDS(seg_losses_kernel<24>, 150 * 1024);
   UCD_TRY_LDS(seg_losses_kernel<0>, 150 * 1024);
