@@ -36,7 +36,7 @@ __device__ __forceinline__ void up_src(int dst, int in_size, float scale, int& i
 // CT > 0: Ctot <= CT and the per-class gradient of a thread's pixel column is accumulated in 2*CT registers
 // over consecutive rows that share the same low-res row pair (8x fewer LDS atomics); CT == 0: any Ctot,
 // four LDS atomics per pixel and class.
-template <int CT>
+template <int CT, int KT = CT>
 __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
     const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
     int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
@@ -119,6 +119,86 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
     const bool ignored = lab64 == ignore_index;
     int lab = ignored ? 0 : (int)lab64;
     if (lab < K) lab = 0;                                    // loss.py:104-105
+    if (CT > 0) {
+      // Register form (Ctot <= CT, K <= KT).  Every interpolated logit is formed once; the class-set tests (c < K,
+      // c == 0 || c >= K, 1 <= c < K) are wave-uniform 0 / 1 multipliers, classes past Ctot / K carry -1e30 (their
+      // exponentials are exact zeros, so no guards inside the unrolled loops); e_c = exp(z_c - max) is computed once and
+      // every later exponential is a ratio of it:  exp(z_c - LSE_S) = e_c / sum_S e.  (The first version re-evaluated
+      // ~120 exponentials and ~1700 vector instructions per pixel and was issue-bound, tools/prof_seglosses.sh: 980 ->
+      // 630 us at B = 24, 513^2.  227 VGPRs = two waves per SIMD; capping at three spills and is slower, 790 us.)
+      constexpr float kL2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f, kNegBig = -1e30f;
+      constexpr int KTA = KT > 0 ? KT : 1;
+      float zc[CTA], ec[CTA];
+      float mz = kNegBig;
+#pragma unroll
+      for (int c = 0; c < CTA; ++c) {
+        const float z = interp(s_log, Ctot, c);
+        zc[c] = c < Ctot ? z : kNegBig;
+        mz = fmaxf(mz, zc[c]);
+      }
+      const float mzl = mz * kL2e;
+      float s_all = 0.f, s_old = 0.f, s_bn = 0.f, z_lab = 0.f;
+#pragma unroll
+      for (int c = 0; c < CTA; ++c) {
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(zc[c], kL2e, -mzl));
+        ec[c] = e;
+        s_all += e;
+        s_old = __builtin_fmaf(e, c < K ? 1.f : 0.f, s_old);
+        s_bn = __builtin_fmaf(e, (c == 0 || c >= K) ? 1.f : 0.f, s_bn);
+        z_lab = c == lab ? zc[c] : z_lab;
+      }
+      const float den = mz + kLn2 * __builtin_amdgcn_logf(s_all);
+      const float lse_old = mz + kLn2 * __builtin_amdgcn_logf(s_old), lse_bn = mz + kLn2 * __builtin_amdgcn_logf(s_bn);
+      const float logp = lab == 0 ? lse_old - den : z_lab - den;
+      if (!ignored) ce_sum += -logp;
+      const float inv_all = 1.f / s_all, inv_old = 1.f / s_old, inv_bn = 1.f / s_bn;
+      // teacher soft-max
+      float te[KTA];
+      float inv_st = 0.f, q0 = 0.f, kd_pix = 0.f;
+      if (sem_t) {
+        float tcv[KTA];
+        float mt = kNegBig, st = 0.f;
+#pragma unroll
+        for (int c = 0; c < KTA; ++c) {
+          const float t = interp(t_log, K, c);
+          tcv[c] = c < K ? t : kNegBig;
+          mt = fmaxf(mt, tcv[c]);
+        }
+        const float mtl = mt * kL2e;
+#pragma unroll
+        for (int c = 0; c < KTA; ++c) {
+          te[c] = __builtin_amdgcn_exp2f(__builtin_fmaf(tcv[c], kL2e, -mtl));
+          st += te[c];
+        }
+        inv_st = 1.f / st;
+        q0 = te[0] * inv_st;
+        kd_pix = q0 * (lse_bn - den);
+      }
+      const float ce_w = ignored ? 0.f : ce_scale;
+      const float kdw = kd_scale * invK;
+      const bool lab0 = lab == 0;
+      const float q0bn = q0 * inv_bn;
+#pragma unroll
+      for (int c = 0; c < CTA; ++c) {
+        const float p = ec[c] * inv_all;
+        const float t_old = ec[c] * (c < K ? inv_old : 0.f);
+        const float t_hot = c == lab ? 1.f : 0.f;
+        float g = ce_w * (p - (lab0 ? t_old : t_hot));
+        if (sem_t) {
+          float qc = 0.f;
+          if (c >= 1 && c < KTA) {                      // compile-time; the 1 <= c < K test is the uniform multiplier
+            qc = te[c] * (c < K ? inv_st : 0.f);
+            kd_pix = __builtin_fmaf(qc, zc[c] - den, kd_pix);
+          }
+          const float bn = ec[c] * ((c == 0 || c >= K) ? q0bn : 0.f);
+          g = __builtin_fmaf(kdw, p - bn - qc, g);
+        }
+        acc0[c] = __builtin_fmaf(ly0, g, acc0[c]);
+        acc1[c] = __builtin_fmaf(ly1, g, acc1[c]);
+      }
+      kd_sum += -kd_pix * invK;
+      continue;
+    }
     // CT > 0: every interpolated logit is formed ONCE and kept in a register (the three passes below would otherwise
     // redo the 4 LDS reads + 6 flops of the interpolation three times per class: ~450 LDS reads per pixel)
     float zc[CTA], tc[CTA];
@@ -355,19 +435,24 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const int ny = (int)(kTileY * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
   const size_t lds = ((size_t)ny * nx * ((Ctot <= 24 ? 17 : 2) * Ctot + K) + 8) * sizeof(float);
   UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
-  UCD_TRY_LDS(seg_losses_kernel<24>, 150 * 1024);
-  UCD_TRY_LDS(seg_losses_kernel<0>, 150 * 1024);
+  UCD_TRY_LDS((seg_losses_kernel<24, 16>), 150 * 1024);
+  UCD_TRY_LDS((seg_losses_kernel<24, 24>), 150 * 1024);
+  UCD_TRY_LDS((seg_losses_kernel<0, 0>), 150 * 1024);
   hipError_t e = hipMemsetAsync(d_sem, 0, (size_t)B * h * w * ld_d * sizeof(float), s);
   if (e != hipSuccess) { set_error("%s: %s", fn, hipGetErrorString(e)); return (int)e; }
   const float inv_pix = 1.f / ((float)B * H * W);
   float* part = (float*)workspace;
   // torch computes the up-sampling scale as float(in) / out
-  if (Ctot <= 24)
-    seg_losses_kernel<24><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
+  if (Ctot <= 24 && K <= 16)
+    seg_losses_kernel<24, 16><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
+        sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
+        ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
+  else if (Ctot <= 24)
+    seg_losses_kernel<24, 24><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
         sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
         ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
   else
-    seg_losses_kernel<0><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
+    seg_losses_kernel<0, 0><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
         sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
         ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
   int rc = check_launch(fn);
