@@ -9,7 +9,7 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|window_\w+kernel|tile_stats_reduce_kernel)", r["Kernel_Name"])
+        m = re.search(r"(pixcon16p_\w+kernel|pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|window_\w+kernel|tile_stats_reduce_kernel)", r["Kernel_Name"])
         if m:
             agg[m.group(1)].append(float(r["Counter_Value"]))
     return agg
@@ -25,7 +25,7 @@ for k in sorted(set(fetch) | set(write)):
 out["kernels"] = kern
 calls = [k for k in kern if k.startswith("pixcon")]
 if calls:
-    n = max(1, min(kern[k]["dispatches_seen"] for k in calls if "neg" in k or "pos" in k))
+    n = max(1, min(kern[k]["dispatches_seen"] for k in calls if "neg" in k or "pos" in k or "plan" in k))
     out["ucd_pixcon_loss"] = {"global_batch": int(sys.argv[4]), "bytes_per_launch": sum(kern[k]["bytes"] * kern[k]["dispatches_seen"] / n for k in calls),
                               "kernels": calls}
 # HBM-stream calls: one dominant kernel each (the stage-2 reduce_bands launches move a few KB)
