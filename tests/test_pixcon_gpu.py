@@ -190,6 +190,47 @@ def test_fp16_performance_mode_vs_oracle(B, N, h, K, H, new_ids, max_label):
     assert (fn_d.grad.cpu() - ref_in.grad).abs().max().item() / scale < 2e-3
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16", "f16_split"])
+@pytest.mark.parametrize("case", ["no_anchor", "one_label", "single_anchor_block"])
+def test_degenerate_batches_every_precision(prec, case):
+    """Edge cases of the anchor / contrast sets through every loss path (the planned fp16 sweeps build their work lists on
+    the device from these counts): no anchor at all (all-background labels and a teacher that predicts background: zero
+    units, loss 0, zero gradient); every pixel carrying the same label (sweep 1 has nothing but the boundary / padding
+    tiles, every row is a positive of every anchor); fewer anchors than one 128-row block."""
+    from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare
+    B, N, h, K, H = 2, 256, 12, 16, 192
+    f_n, f_o, l_po, labels = synth.contrastive_case(31, B, N, h, h, K, H, H, list(range(16, 21)))
+    if case == "no_anchor":
+        labels = torch.zeros_like(labels)
+        l_po = l_po.clone(); l_po[:, 0] += 50.0                     # the teacher says background everywhere
+    elif case == "one_label":
+        labels = torch.full_like(labels, 17)
+    else:
+        labels = torch.zeros_like(labels); labels[0, :40, :40] = 18
+        l_po = l_po.clone(); l_po[:, 0] += 50.0
+    fn_d, fo_d, lpo_d, lab_d = _to_dev(f_n, f_o, l_po, labels)
+    pb = pixcon_prepare(fn_d.contiguous(memory_format=torch.channels_last), lab_d, lpo_d, fo_d, sort_by_label=True, fp16=prec != "f32")
+    loss_out, grad_a, stats = pixcon_loss_raw(pb, 0.07, True, True, need_grad=True, row_stats=True, precision=prec)
+    m = pb.meta_host()
+    assert torch.isfinite(loss_out).all() and torch.isfinite(grad_a[:max(m.A, 1)]).all()
+    if case == "no_anchor":
+        # (the reference itself stops here: min() of an empty tensor, utils/utils.py:353; the kernels define the loss as 0)
+        assert m.A == 0 and loss_out[0].item() == 0.0 and loss_out[1].item() == 0.0
+        return
+    prep = OC.pre_contrastive_pixel(f_n, labels, l_po, f_o)
+    ref = OC.pixcon_loss(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    _, da, neg, G, num = OC.pixcon_loss_backward(prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"], 0.07)
+    assert m.A == prep["a"].shape[0] and (case != "single_anchor_block" or m.A < 128)
+    tol = 1e-4 if prec == "f32" else 1e-3
+    assert abs(loss_out[0].item() - ref.item()) <= tol * abs(ref.item()) + 1e-5        # one_label: the loss is 0 up to rounding
+    if case == "one_label":
+        assert stats[0, :m.A].abs().max().item() == 0.0              # no negatives at all
+    scale = max(da.abs().max().item(), 1e-12)
+    # label-sorted rows -> the oracle's pixel order
+    got = grad_a[:m.A, :N].cpu().double()[torch.argsort(pb.anchor_pix[:m.A].cpu())]
+    assert (got - da).abs().max().item() / scale < (1e-4 if prec == "f32" else 3e-3)
+
+
 @pytest.mark.parametrize("T", [0.07, 0.05])
 def test_fp16_extreme_logit_range(T):
     """The widest logit range the fp16 sweep can meet: anchors whose first contrast tiles are far (cos ~ -1) and whose

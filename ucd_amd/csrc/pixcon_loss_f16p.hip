@@ -290,6 +290,19 @@ __device__ __forceinline__ void tile_step(f32x16 (&acc)[8], const f16x8 (&a16)[1
   if (MODE == 1 && self_tile) {   // the tile that holds this wave's own anchors (wave-uniform): the self pair is no positive
     lw_cur[0] |= self_patch[0]; lw_cur[1] |= self_patch[1]; lw_cur[2] |= self_patch[2]; lw_cur[3] |= self_patch[3];
   }
+  if (MODE == 0 && self_tile) {
+    // sweep 1 passes "the tile holds padding rows" here (the last tiles of either segment, wave-uniform): their label
+    // bytes (255) become the lane's own label, so the one compare of the epilogue masks them like positives.  (Subtracting
+    // their known contribution afterwards leaves a rounding residue in neg, and neg must be EXACTLY zero for an anchor
+    // without negatives: the positives' terms S' - log(exp S' + neg) cancel only then.)
+    const u32 la8 = (u32)rs.la & 0xffu;
+#pragma unroll
+    for (int wd = 0; wd < 4; ++wd)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (((lw_cur[wd] >> (8 * k)) & 0xffu) == (u32)kPadLabel)
+          lw_cur[wd] = (lw_cur[wd] & ~(0xffu << (8 * k))) | (la8 << (8 * k));
+  }
   const int crow = threadIdx.x >> 5, ccol = threadIdx.x & 31;
   _Float16* cdst = cs_new + crow * kPitchH + ccol * 8;
   float arg[16], wv[16], dv[16];
@@ -341,7 +354,6 @@ __device__ __forceinline__ void tile_step(f32x16 (&acc)[8], const f16x8 (&a16)[1
     } else {
       const u32 lc = label_byte(lw_cur, e);
       if (MODE == 0) {
-        // padding rows (label 255, zero features) pass as negatives with E = 2^-m_run exactly; the unit subtracts them
         const float ev = ((int)lc != rs.la) ? arg[e] : 0.f;
         rs.neg += ev;
         wv[e] = ev;
@@ -402,7 +414,7 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
   int* s_unit = reinterpret_cast<int*>(labs0 + kRing * 8);                            // [4]
   const int ppitch = 2 * KP16 + 8;
   _Float16* ps0 = reinterpret_cast<_Float16*>(s_unit + 4);                            // [kRing][32][ppitch] (PROB)
-  const int A = meta->A, min_new = meta->min_new;
+  const int A = meta->A, min_new = meta->min_new, Apad = meta->Apad, Cend = meta->Apad + meta->Co;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5;
   const int sbase = (lane & 31) * kPitchH + 8 * half;
   const int vbase = (4 * half + ((lane & 15) >> 2)) * kPitchH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -545,7 +557,8 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
       const int j0 = ul.at(v_begin + t) * kTJ;
       if (PROB && need_prob) pm = prob_tile_p(ps0 + B * kTJ * ppitch, ppitch, KP16, nk, pah, pal, lane);
       tile_step<MODE, PROB, B>(acc, a16, f, x_cur, x_next, w_prev, w_new, lw_cur, lw_next, rs, pm, cs0, labs0, ps0, sbase, vbase,
-                               half, j0 == i0w, self_patch, stage, src, j0_of(v_begin + t + 3));
+                               half, MODE == 1 ? j0 == i0w : ((j0 + kTJ > A && j0 < Apad) || j0 + kTJ > Cend), self_patch, stage,
+                               src, j0_of(v_begin + t + 3));
 #pragma unroll
       for (int q = 0; q < 8; ++q) asm volatile("" : "+a"(acc[q]));   // accumulators stay in the AGPR half
       asm volatile("" : "+v"(x_next));   // the scores are read by VALU instructions next step: keep them out of the AGPRs
@@ -567,23 +580,6 @@ __global__ __launch_bounds__(kThreads, 1) void pixcon16p_sweep_kernel(
     if (MODE == 0) {
       rs.neg += __shfl_xor(rs.neg, 32, 64);
       rs.mx = fmaxf(rs.mx, __shfl_xor(rs.mx, 32, 64));
-      // padding rows among the unit's tiles: rows [A, Apad) and [Apad + Co, Cpad); each added exp2(0 * k2 - m_run)
-      int npad = 0;
-      {
-        const int Apad = meta->Apad, Cend = Apad + meta->Co, Cpad = meta->Cpad;
-        const int ra[3] = {ul.a0, ul.a1, ul.a2}, rn[3] = {ul.n0, ul.n1, ul.n2};
-        int base = 0;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-          const int lo = max(v_begin, base), hi = min(v_end, base + rn[q]);   // list positions of range q inside the unit
-          if (hi > lo) {
-            const int r0 = (ra[q] + lo - base) * kTJ, r1 = (ra[q] + hi - base) * kTJ;
-            npad += max(0, min(r1, Apad) - max(r0, A)) + max(0, min(r1, Cpad) - max(r0, Cend));
-          }
-          base += rn[q];
-        }
-      }
-      rs.neg -= (float)npad * __builtin_amdgcn_exp2f(__builtin_fmaf(0.f, rs.k2, -rs.m_run));
     } else {
       rs.lossacc += __shfl_xor(rs.lossacc, 32, 64);
       rs.qsum += __shfl_xor(rs.qsum, 32, 64);
