@@ -160,6 +160,7 @@ def test_bf16_inputs_and_no_new_pixels():
     (3, 256, 33, 16, 513, list(range(16, 21)), 20),
     (2, 64, 12, 101, 192, list(range(101, 151)), 150),
     (2, 32, 9, 16, 129, [16], 20),
+    (2, 128, 16, 20, 256, [20], 20),          # 20 teacher classes: two 16-class steps of the probability products
 ])
 def test_fp16_performance_mode_vs_oracle(B, N, h, K, H, new_ids, max_label):
     """fp16-operand sweep (v_mfma_f32_32x32x16_f16, online negative-max rescale): loss within 1e-3 relative
@@ -191,12 +192,14 @@ def test_fp16_performance_mode_vs_oracle(B, N, h, K, H, new_ids, max_label):
 
 
 @pytest.mark.parametrize("prec", ["f32", "f16", "f16_split"])
-@pytest.mark.parametrize("case", ["no_anchor", "one_label", "single_anchor_block"])
+@pytest.mark.parametrize("case", ["no_anchor", "one_label", "single_anchor_block", "constant_features"])
 def test_degenerate_batches_every_precision(prec, case):
     """Edge cases of the anchor / contrast sets through every loss path (the planned fp16 sweeps build their work lists on
     the device from these counts): no anchor at all (all-background labels and a teacher that predicts background: zero
     units, loss 0, zero gradient); every pixel carrying the same label (sweep 1 has nothing but the boundary / padding
-    tiles, every row is a positive of every anchor); fewer anchors than one 128-row block."""
+    tiles, every row is a positive of every anchor); fewer anchors than one 128-row block; a constant student feature map
+    (every anchor row identical: each positive ties with the self pair for the row maximum, which the planned sweeps seed
+    with S_ii instead of visiting the positives)."""
     from ucd_amd.contrastive import pixcon_loss_raw, pixcon_prepare
     B, N, h, K, H = 2, 256, 12, 16, 192
     f_n, f_o, l_po, labels = synth.contrastive_case(31, B, N, h, h, K, H, H, list(range(16, 21)))
@@ -205,6 +208,8 @@ def test_degenerate_batches_every_precision(prec, case):
         l_po = l_po.clone(); l_po[:, 0] += 50.0                     # the teacher says background everywhere
     elif case == "one_label":
         labels = torch.full_like(labels, 17)
+    elif case == "constant_features":
+        f_n = f_n[:1, :, :1, :1].expand_as(f_n).contiguous()
     else:
         labels = torch.zeros_like(labels); labels[0, :40, :40] = 18
         l_po = l_po.clone(); l_po[:, 0] += 50.0
