@@ -177,6 +177,35 @@ for dtype in (torch.float32, torch.bfloat16):
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     for a, b in zip(*outs):
         assert (a - b).norm().item() <= tol * max(b.norm().item(), 1e-6), (dtype, (a - b).abs().max().item())
+# the conv + ABN nodes (1x1 wide / narrow, 3x3) on their SyncBN branch: statistics packed in the GEMM epilogue's finalize,
+# gathered over the communicator, combined by ucd_abn_sync_forward; backward sums all-reduced the same way
+from functools import partial
+from ucd_amd import blocks
+from ucd_amd.ddp import DistributedDataParallel
+assert blocks._gemm_node() is not None and hasattr(blocks._gemm_node(), "conv_abn_train")
+norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+for cin, chans, hw, B in ((1024, (256, 256, 1024), 33, 6), (256, (64, 64, 256), 65, 6), (512, (128, 128, 512), 33, 24)):
+    x0 = synth.t_normal(9, (B, cin, hw, hw), stream=1).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(10, (B, chans[2], hw, hw), stream=1).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for sync in (True, False):
+        abn._FORCE_SYNC = sync
+        blk = blocks.ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=1)
+        blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+        blk = blk.to(dev).to(memory_format=torch.channels_last).train()
+        mod = DistributedDataParallel(blk, bf16_weights=True)
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(x * 1.0)
+        assert "ConvABNTrainNode" in y.grad_fn.name(), y.grad_fn.name()
+        y.backward(dy)
+        mod.finish_grad_sync()
+        g = [p.grad.float().clone() for p in blk.parameters()]
+        outs.append([y.detach().float(), x.grad.float()] + g + [blk.convs.bn1.running_mean.clone(), blk.convs.bn2.running_var.clone(),
+                                                                 blk.convs.bn3.running_var.clone()])
+    for i, (a, b) in enumerate(zip(*outs)):
+        assert (a - b).norm().item() <= 2e-2 * max(b.norm().item(), 1e-6), (cin, i, (a - b).abs().max().item())
+abn._FORCE_SYNC = False
 print("DIRECT_RCCL_OK")
 dist.destroy_process_group()
 """
