@@ -28,8 +28,21 @@ for r in win:
 grp = collections.defaultdict(float)
 for k, (d, c) in agg.items():
     grp[k.split()[0]] += d / 2e6
+# GPU busy time = union of the kernel intervals (the teacher's stream overlaps the student's); idle = gaps between kernels
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in win)
+busy, cur_s, cur_e, gaps = 0, iv[0][0], iv[0][1], []
+for s_, e_ in iv[1:]:
+    if s_ > cur_e:
+        busy += cur_e - cur_s; gaps.append(s_ - cur_e); cur_s, cur_e = s_, e_
+    else:
+        cur_e = max(cur_e, e_)
+busy += cur_e - cur_s
+gaps.sort()
 with open(sys.argv[2], "w") as f:
     f.write("# %s\n" % (sys.argv[3] if len(sys.argv) > 3 else ""))
+    f.write("# GPU busy (union of kernel intervals) %.3f ms/step, idle between kernels %.3f ms/step in %d gaps (median %.1f us, "
+            "p90 %.1f us)\n" % (busy / 2e6, sum(gaps) / 2e6, len(gaps) // 2, gaps[len(gaps) // 2] / 1e3 if gaps else 0,
+                                gaps[int(len(gaps) * 0.9)] / 1e3 if gaps else 0))
     f.write("# last two timed steps: wall %.3f ms/step, sum of kernel durations %.3f ms/step, %d launches/step\n" %
             ((t1 - t0) / 2e6, sum(v[0] for v in agg.values()) / 2e6, len(win) // 2))
     f.write("# by group (ms/step): " + ", ".join("%s %.2f" % kv for kv in sorted(grp.items(), key=lambda kv: -kv[1])) + "\n")
