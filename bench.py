@@ -243,16 +243,16 @@ def main():
         ev_us = kernels.pop("_event_pair_overhead_us")
         for kname, kv in kernels.items():                    # per-call-type roofline fractions
             secs = max(kv["ms_total"] * 1e-3, 1e-12)
-            if kname.startswith("ucd_pixcon_loss"):
-                pk = PEAK_F16_MFMA_TF if "f16" in kname else PEAK_F32_MFMA_TF
+            if kname.startswith("ucd_pixcon_loss") or kname == "ucd_conv3x3":
+                pk = PEAK_F32_MFMA_TF if "f32" in kname else PEAK_F16_MFMA_TF      # bf16 and fp16 share the dense peak
                 kv.update(bound="mfma", achieved=kv["work"] / secs / 1e12, unit="TFLOP/s", frac=kv["work"] / secs / 1e12 / pk)
             else:
                 kv.update(bound="hbm", achieved=kv["work"] / secs / 1e9, unit="GB/s", frac=kv["work"] / secs / 1e9 / PEAK_HBM_GBS)
         name = max(kernels, key=lambda k: kernels[k]["ms_total"])
         k = kernels[name]
-        if name.startswith("ucd_pixcon_loss"):
+        if name.startswith("ucd_pixcon_loss") or name == "ucd_conv3x3":
             ach = k["work"] / (k["ms_total"] * 1e-3) / 1e12
-            peak = PEAK_F16_MFMA_TF if "f16" in name else PEAK_F32_MFMA_TF
+            peak = PEAK_F32_MFMA_TF if "f32" in name else PEAK_F16_MFMA_TF
             roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": ach / peak, "traffic": None}
         else:

@@ -11,7 +11,10 @@ def per_kernel(path, counter):
             continue
         m = re.search(r"(pixcon16p_\w+kernel|pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|window_\w+kernel|tile_stats_reduce_kernel)", r["Kernel_Name"])
         if m:
-            agg[m.group(1)].append(float(r["Counter_Value"]))
+            k = m.group(1)
+            if k == "conv1x1_kernel" and re.search(r"conv1x1_kernel<[^>]*true\s*>", r["Kernel_Name"]):
+                k = "conv3x3_kernel"          # the CONV3 instances of the same template: the 3x3 implicit GEMM
+            agg[k].append(float(r["Counter_Value"]))
     return agg
 
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
@@ -31,7 +34,7 @@ if calls:
 # HBM-stream calls: one dominant kernel each (the stage-2 reduce_bands launches move a few KB)
 for call, k in (("ucd_abn_apply", "abn_apply_kernel"), ("ucd_abn_stats", "abn_stats_kernel"),
                 ("ucd_abn_bwd_reduce", "abn_bwd_reduce_kernel"), ("ucd_abn_bwd_apply", "abn_bwd_apply_kernel"),
-                ("ucd_seg_losses", "seg_losses_kernel"), ("ucd_conv1x1", "conv1x1_kernel")):
+                ("ucd_seg_losses", "seg_losses_kernel"), ("ucd_conv1x1", "conv1x1_kernel"), ("ucd_conv3x3", "conv3x3_kernel")):
     if k in kern:
         out[call] = {"global_batch": int(sys.argv[4]), "bytes_per_launch": kern[k]["bytes"], "kernels": [k]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -524,7 +524,9 @@ def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, par
         d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
     d.partial = ptr(partial)
     d.accumulate = 1 if accumulate else 0
-    work = 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)))
+    # roofline work of the instrumented bench pass: algorithmic bytes for the 1x1 products (HBM-bound at the network's
+    # shapes), flop for the 3x3 implicit GEMM (9 K deep: MFMA-bound)
+    work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)))
     with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work):
         _check(lib.ucd_conv1x1(C.byref(d), stream()), "ucd_conv1x1")
     return y
