@@ -86,8 +86,14 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // free; W is the channels-last 4-D weight [N][kh][kw][K] read as 9 [N][K] slices (row pitch 9 K).
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-template <int BN, bool PRO, int OUT, bool CONV3 = false>
-__global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) void conv1x1_kernel(Args p) {
+// DB (3x3 only): two LDS stages.  The 3x3 products are 9 K deep and MFMA-bound, and their grids (N = 256: 410 workgroups)
+// give a CU one or two workgroups, not the four whose interleaving hides the fill latency of the single-stage form: the
+// fill of step k+1 is issued (LDS-DMA: no registers to carry) before the MFMAs of step k and waited for with a counted
+// vmcnt, so it lands under them.  64 KB of LDS, two workgroups per CU.
+template <int BN, bool PRO, int OUT, bool CONV3 = false, bool DB = false>
+__global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
+  static_assert(!DB || (CONV3 && !PRO), "the double-buffered form is built for the 3x3 implicit GEMM");
+  constexpr int kStage = (kBM + BN) * 128;   // bytes of one LDS stage (A tile + W tile)
   constexpr int WN = BN / 2;           // columns per wave
   constexpr int TN = WN / 32;          // 32-wide accumulator tiles per wave along N
   constexpr int CP = BN + 4;           // fp32 pitch of the (half) output tile in LDS
@@ -164,12 +170,46 @@ __global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) v
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i]);
   }
+  auto fill3 = [&](int kb, unsigned char* Ad, unsigned char* Bd) {   // LDS-DMA fill of step kb (3x3 form)
+    const int tap = kb / kpt;
+    const int k0 = (kb - tap * kpt) * kBK;
+    const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
+      const bf16* src = ok ? p.A + (size_t)(pimg[i] + yy * p.iW + xx) * p.lda + pslot[i] + k0
+                           : reinterpret_cast<const bf16*>(&g_zero16);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + tap * p.K + k0), (lptr_t)(Bd + (wave * CB + i) * 1024), 16, 0, 0);
+  };
+  if (DB) fill3(0, As, Bs);
   for (int kb = 0; kb < nk; ++kb) {
     const int tap = CONV3 ? kb / kpt : 0;
     const int k0 = (kb - tap * kpt) * kBK;
     const int wk0 = CONV3 ? tap * p.K + k0 : k0;       // column offset inside a weight row (pitch 9 K)
-    if (kb) __syncthreads();                           // the previous step's fragment reads are done
-    if (PRO) {
+    if (kb) {                                          // the previous step's fragment reads are done
+      if (DB) {   // raw barrier: __syncthreads() would wait for the fill in flight as well
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      } else {
+        __syncthreads();
+      }
+    }
+    const unsigned char* Ac = As + (DB ? (kb & 1) * kStage : 0);
+    const unsigned char* Bc = Bs + (DB ? (kb & 1) * kStage : 0);
+    if (DB) {
+      if (kb + 1 < nk) {
+        fill3(kb + 1, As + ((kb + 1) & 1) * kStage, Bs + ((kb + 1) & 1) * kStage);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB) : "memory");   // this step's fill; the next one stays in flight
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    } else if (PRO) {
 #pragma unroll
       for (int i = 0; i < CB; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + k0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
@@ -217,16 +257,18 @@ __global__ __launch_bounds__(kThreads, (PRO || OUT == 3) && BN == 128 ? 3 : 4) v
       for (int i = 0; i < CB; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + wk0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
     }
-    if (!PRO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of the A tile have landed
-    __builtin_amdgcn_s_barrier();                      // raw barrier: __syncthreads() would drain the A prefetch too
+    if (!DB) {
+      if (!PRO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of the A tile have landed
+      __builtin_amdgcn_s_barrier();                      // raw barrier: __syncthreads() would drain the A prefetch too
+    }
 #pragma unroll
     for (int kk = 0; kk < kBK / 16; ++kk) {
       bf16x8 af[2], bfr[TN];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(afrag + swz(wm * 64 + a * 32 + fr, 2 * kk + fh));
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * 64 + a * 32 + fr, 2 * kk + fh));
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(Bs + swz(wn * WN + b * 32 + fr, 2 * kk + fh));
+      for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WN + b * 32 + fr, 2 * kk + fh));
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -656,7 +698,11 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   const int BN = d->N % 128 == 0 ? 128 : 64;
   a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
   const int grid = ceil_div(a.tiles_m, 8) * 8 * a.tiles_n;
-  const size_t lds_main = (size_t)(kBM + BN) * 128, lds_out = (size_t)64 * (BN + 4) * 4;
+  // 3x3 with a grid that leaves a CU one or two workgroups (N = 256 at 33^2: 410; tools/conv3x3_probe.py): the
+  // double-buffered form (256->256 50.6 -> 47.3 us, the ASPP branches 338-356 -> 308-314); fuller grids are faster with
+  // the single stage and four workgroups per CU (512->512 170 vs 179, 128->128 at 65^2 48.7 vs 52.6)
+  const bool db = conv3 && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640;
+  const size_t lds_main = (size_t)(kBM + BN) * 128 * (db ? 2 : 1), lds_out = (size_t)64 * (BN + 4) * 4;
   size_t lds = lds_main > lds_out ? lds_main : lds_out;
   const size_t lds_red = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;       // statistics reduction scratch
   if (lds_red > lds) lds = lds_red;
@@ -678,9 +724,15 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   }
 #define UCD_C3_OUT(BNV)                                                                        \
   switch (d->out_mode) {                                                                       \
-    case 0: conv1x1_kernel<BNV, false, 0, true><<<grid, kThreads, lds, s>>>(a); break;         \
-    case 1: conv1x1_kernel<BNV, false, 1, true><<<grid, kThreads, lds, s>>>(a); break;         \
-    default: conv1x1_kernel<BNV, false, 2, true><<<grid, kThreads, lds, s>>>(a); break;        \
+    case 0: if (db) conv1x1_kernel<BNV, false, 0, true, true><<<grid, kThreads, lds, s>>>(a);  \
+            else conv1x1_kernel<BNV, false, 0, true, false><<<grid, kThreads, lds, s>>>(a);    \
+            break;                                                                             \
+    case 1: if (db) conv1x1_kernel<BNV, false, 1, true, true><<<grid, kThreads, lds, s>>>(a);  \
+            else conv1x1_kernel<BNV, false, 1, true, false><<<grid, kThreads, lds, s>>>(a);    \
+            break;                                                                             \
+    default: if (db) conv1x1_kernel<BNV, false, 2, true, true><<<grid, kThreads, lds, s>>>(a); \
+             else conv1x1_kernel<BNV, false, 2, true, false><<<grid, kThreads, lds, s>>>(a);   \
+             break;                                                                            \
   }
   if (conv3) {
     if (BN == 128) { UCD_C3_OUT(128) } else { UCD_C3_OUT(64) }
