@@ -278,9 +278,9 @@ def _own_gemm_with_stats(K, N):
 
 def _own_conv3x3(M, K, N):
     """The implicit-GEMM 3x3 (csrc/conv1x1.hip, taps = 9) instead of MIOpen: measured on MI355X (tools/conv3x3_probe.py,
-    B = 24): 256->256 at 33^2 52 vs 56 us, 128->128 at 65^2 49 vs 52, 64->64 at 129^2 58 vs 62, the ASPP branches 334-357 vs
-    377-384 - and the following ABN's statistics for +1 us instead of a separate pass; MIOpen keeps the 512->512 layers
-    (137 vs 168 us) and maps too small to give every CU a tile (3 images per GPU: 23 vs 36 us)."""
+    B = 24): 256->256 at 33^2 47-49 vs 56 us, 128->128 at 65^2 49 vs 47-52, 64->64 at 129^2 55 vs 63, the ASPP branches 303-315
+    vs 382-390 - and the following ABN's statistics for +1 us instead of a separate pass; MIOpen keeps the 512->512 layers
+    (135-142 vs 167 us) and maps too small to give every CU a tile (3 images per GPU: 23 vs 31 us)."""
     tiles = ((M + 127) // 128) * max(1, N // 128)
     return tiles >= 256 and not (K >= 512 and N >= 512)
 

@@ -86,13 +86,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // free; W is the channels-last 4-D weight [N][kh][kw][K] read as 9 [N][K] slices (row pitch 9 K).
 __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
-// DB (3x3 only): two LDS stages.  The 3x3 products are 9 K deep and MFMA-bound, and their grids (N = 256: 410 workgroups)
-// give a CU one or two workgroups, not the four whose interleaving hides the fill latency of the single-stage form: the
+// DB: two LDS stages, for grids that give a CU one or two workgroups (N = 256 at 33^2: 410 workgroups) instead of the four
+// whose interleaving hides the fill latency of the single-stage form - the 9 K deep, MFMA-bound 3x3 products most of all: the
 // fill of step k+1 is issued (LDS-DMA: no registers to carry) before the MFMAs of step k and waited for with a counted
 // vmcnt, so it lands under them.  64 KB of LDS, two workgroups per CU.
 template <int BN, bool PRO, int OUT, bool CONV3 = false, bool DB = false>
 __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
-  static_assert(!DB || (CONV3 && !PRO), "the double-buffered form is built for the 3x3 implicit GEMM");
+  static_assert(!DB || !PRO, "the double-buffered form has no input transform");
   constexpr int kStage = (kBM + BN) * 128;   // bytes of one LDS stage (A tile + W tile)
   constexpr int WN = BN / 2;           // columns per wave
   constexpr int TN = WN / 32;          // 32-wide accumulator tiles per wave along N
@@ -170,17 +170,23 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i]);
   }
-  auto fill3 = [&](int kb, unsigned char* Ad, unsigned char* Bd) {   // LDS-DMA fill of step kb (3x3 form)
-    const int tap = kb / kpt;
+  auto fill3 = [&](int kb, unsigned char* Ad, unsigned char* Bd) {   // LDS-DMA fill of step kb (double-buffered form)
+    const int tap = CONV3 ? kb / kpt : 0;
     const int k0 = (kb - tap * kpt) * kBK;
-    const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
+    if (CONV3) {
+      const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
 #pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      const int yy = py[i] + dy, xx = px[i] + dx;
-      const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
-      const bf16* src = ok ? p.A + (size_t)(pimg[i] + yy * p.iW + xx) * p.lda + pslot[i] + k0
-                           : reinterpret_cast<const bf16*>(&g_zero16);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < CA; ++i) {
+        const int yy = py[i] + dy, xx = px[i] + dx;
+        const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
+        const bf16* src = ok ? p.A + (size_t)(pimg[i] + yy * p.iW + xx) * p.lda + pslot[i] + k0
+                             : reinterpret_cast<const bf16*>(&g_zero16);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < CA; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + k0), (lptr_t)(Ad + (wave * CA + i) * 1024), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i)
@@ -701,7 +707,8 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   // 3x3 with a grid that leaves a CU one or two workgroups (N = 256 at 33^2: 410; tools/conv3x3_probe.py): the
   // double-buffered form (256->256 50.6 -> 47.3 us, the ASPP branches 338-356 -> 308-314); fuller grids are faster with
   // the single stage and four workgroups per CU (512->512 170 vs 179, 128->128 at 65^2 48.7 vs 52.6)
-  const bool db = conv3 && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640;
+  // (the 1x1 products of such grids gain too: 1024 -> 256 23.3 -> 21.7 us, with statistics 25.1 -> 23.6)
+  const bool db = (conv3 || (!d->in_scale && d->out_mode <= 2)) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640;
   const size_t lds_main = (size_t)(kBM + BN) * 128 * (db ? 2 : 1), lds_out = (size_t)64 * (BN + 4) * 4;
   size_t lds = lds_main > lds_out ? lds_main : lds_out;
   const size_t lds_red = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;       // statistics reduction scratch
@@ -713,7 +720,10 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
 #define UCD_C1_LAUNCH(BNV, PROV, OUTV)                                          \
   {                                                                             \
-    conv1x1_kernel<BNV, PROV, OUTV><<<grid, kThreads, lds, s>>>(a);             \
+    if (!PROV && OUTV <= 2 && db)                                               \
+      conv1x1_kernel<BNV, false, (OUTV <= 2 ? OUTV : 0), false, true><<<grid, kThreads, lds, s>>>(a);   \
+    else                                                                        \
+      conv1x1_kernel<BNV, PROV, OUTV><<<grid, kThreads, lds, s>>>(a);           \
   }
 #define UCD_C1_OUT(BNV, PROV)                                                   \
   switch (d->out_mode) {                                                        \
