@@ -12,7 +12,7 @@ def per_kernel(path, counter):
         m = re.search(r"(pixcon16p_\w+kernel|pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|window_\w+kernel|tile_stats_reduce_kernel)", r["Kernel_Name"])
         if m:
             k = m.group(1)
-            if k == "conv1x1_kernel" and re.search(r"conv1x1_kernel<[^>]*true\s*>", r["Kernel_Name"]):
+            if k == "conv1x1_kernel" and re.search(r"conv1x1_kernel<\d+, \w+, \d+, true", r["Kernel_Name"]):
                 k = "conv3x3_kernel"          # the CONV3 instances of the same template: the 3x3 implicit GEMM
             agg[k].append(float(r["Counter_Value"]))
     return agg
