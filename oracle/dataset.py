@@ -3,9 +3,11 @@
 ``filter_images`` (dataset/utils.py:19-42): an image is kept when it holds at least one of the step's labels and - in the
 disjoint setting - no label outside ``labels + labels_old + {0, 255}``;  ``target_transform`` (dataset/voc.py:176-203): the
 per-pixel lambda that maps stored labels to the ids the step sees (inverted order of ``[0] + labels_old + labels``, 255 kept,
-everything else -> the masking value).  PARITY: the reference's own dataset package needs torchvision (absent here) and real
-VOC files, so this restatement is pinned only by reading the cited lines; the label table itself is pinned by the goldens of
-tests/golden/make_datapipe_golden.py."""
+everything else -> the masking value).  PARITY: ``filter_images`` is pinned by index lists the reference's own function
+produced on the label maps of tests/test_dataset.py (tests/golden/make_dataset_golden.py, dataset_filter.npz: five task /
+step pairs, overlap and disjoint); the label table is pinned by the goldens of tests/golden/make_datapipe_golden.py (the
+reference's lambda executed on its own task tables).  The class ``VOCSegmentationIncremental`` itself needs torchvision and
+real VOC files and is followed by reading the cited lines."""
 import numpy as np
 
 

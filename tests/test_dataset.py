@@ -1,5 +1,6 @@
 """Incremental VOC dataset: listing, image filtering and index files on a synthetic VOC tree (CPU, against the
-oracle's restatement of dataset/utils.py:19-42 and dataset/voc.py:176-203); on the GPU the batch transform of the loader
+oracle's restatement of dataset/utils.py:19-42 and dataset/voc.py:176-203 and against index lists the reference's own
+filter_images produced for the same label maps); on the GPU the batch transform of the loader
 against the same stack run per sample with Pillow on the host, from the same `random` seed."""
 import os
 import random
@@ -8,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import load_golden
 from oracle import dataset as OD
 from ucd_amd import tasks
 from ucd_amd.dataset import DeviceBatcher, VOCSegmentation, VOCSegmentationIncremental, filter_images
@@ -54,6 +56,8 @@ def test_image_filter_matches_oracle(tmp_path, task, step, overlap):
     full = VOCSegmentation(str(tmp_path), "train")
     got = filter_images(full, labels, labels_old, overlap=overlap)
     assert got == OD.filter_images(maps, labels, labels_old, overlap=overlap)
+    # the reference's own filter_images on the same label maps (tests/golden/make_dataset_golden.py)
+    assert got == load_golden("dataset_filter.npz")[f"{task}::{step}::{int(overlap)}"].tolist()
     if task == "15-5" and step == 0:      # by hand: images holding any of 1..15 / of those, the ones without a future class 16..20
         assert got == ([0, 2, 4, 5, 6, 7, 9] if overlap else [0, 4, 7])
     if task == "15-5" and step == 1:
