@@ -441,7 +441,7 @@ typedef struct ucd_conv1x1_desc {
   int accumulate;
   /* taps = 9: a is the [B, H, W, K] map and the product is the 3x3 convolution with stride 1 and padding = dilation
    * (modules/residual.py:69 conv2, modules/deeplab.py:27-29 the ASPP branches) as an implicit GEMM over 9 K columns: w is
-   * the channels-last 4-D weight [N][kh][kw][K] (ldw >= 9 K), M = B*H*W; no input transform, out_mode 0..2.  The input
+   * the channels-last 4-D weight [N][kh][kw][K] (ldw >= 9 K), M = B*H*W; no input transform, every out_mode.  The input
    * gradient of such a layer is the same call on (dY, w.flip(2, 3).transpose(0, 1)) (ucd_flip_weights_batched).
    * taps = 0 or 1: the 1x1 product above. */
   int taps, H, W, dilation;

@@ -209,6 +209,10 @@ class Conv1x1(Conv2d):
         # it beats the library: short K (tools/conv1x1_probe.py: 256 -> 1024 22.8 vs 31.3 us, the narrow layers 25-41 vs 29-54)
         self.own_dgrad = (in_channels % 64 == 0 and out_channels % 64 == 0 and out_channels <= 512
                           and in_channels * out_channels <= (1 << 18))
+        # set by ResidualBlock for a layer whose input comes from a conv+ABN node that feeds nothing else: its input-gradient
+        # product then also does that ABN's backward reduction (out_mode 3, ``_conv_abn_train``) - worth the own kernel on the
+        # transposed weight even where the plain library product is a little faster
+        self.link_dgrad = False
 
     def forward(self, x):
         # bf16 activations only: in the fp32 parity mode (--opt_level O0) every convolution stays on one code
@@ -292,7 +296,7 @@ class _ConvABNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, fused, dilation=0,
-                wflip=None, own_dgrad=False, wgrad_conv=False):
+                wflip=None, own_dgrad=False, wgrad_conv=False, make_link=False, link=None):
         from . import hip
         B, K, H, W = x.shape
         N = w4.shape[0]
@@ -304,6 +308,9 @@ class _ConvABNFunction(torch.autograd.Function):
         conv3 = dilation > 0
         w2 = w4.permute(0, 2, 3, 1).reshape(N, 9 * K) if conv3 else w4.reshape(N, K)
         ctx.conv3 = (dilation, wflip, own_dgrad, wgrad_conv)
+        # backward link (see ConvABNTrainNode): link = the producer's (z, buf, bias, partial, flag, act, slope)
+        ctx.link = link
+        ctx.my_link = None
         if conv3 and not fused:
             z = F.conv2d(x, w4, None, 1, dilation, dilation).contiguous(memory_format=torch.channels_last)
             hip.abn_forward(z, N, y, N, residual, N if residual is not None else 0, M, N, None, HW, weight, bias, running_mean,
@@ -321,6 +328,10 @@ class _ConvABNFunction(torch.autograd.Function):
         needs_y = residual is not None and (act & hip.ACT_MASK) != hip.ACT_IDENTITY
         ctx.save_for_backward(x, w4, z, y if needs_y else None, weight, bias, buf)
         ctx.cfg = (act, slope, residual is not None)
+        if make_link and residual is None and bias is not None:
+            partial = torch.empty(hip.conv1x1_row_tiles(M), 2, N, dtype=torch.float32, device=x.device)
+            ctx.my_link = (partial, [0])
+            y._ucd_link = (z, buf, bias, partial, ctx.my_link[1], act, slope)
         return y
 
     @staticmethod
@@ -336,9 +347,26 @@ class _ConvABNFunction(torch.autograd.Function):
         dz = torch.empty_like(z)
         dres = torch.empty_like(z) if has_res else None
         sums = torch.empty(2 * N, dtype=torch.float32, device=x.device)
-        hip.abn_backward(z, N, dy, N, y, N if y is not None else 0, dz, N, dres, N if has_res else 0, M, N, None, HW,
-                         buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:], bias, weight, sums, float(M), True, True, act, slope)
+        if ctx.my_link is not None and ctx.my_link[1][0] == 1:
+            # the consumer's input-gradient product applied the activation derivative and left the sums as per-tile partials
+            ctx.my_link[1][0] = 0
+            part = ctx.my_link[0]
+            hip._check(hip.load().ucd_abn_reduce_partials(hip.ptr(part), part.shape[0], N, hip.ptr(sums), None, hip.ptr(weight),
+                                                          act & hip.NORM_ABS_GAMMA, hip.stream()), "ucd_abn_reduce_partials")
+            hip.abn_bwd_apply(z, N, dy, N, None, 0, dz, N, None, 0, M, N, None, HW, buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:],
+                              bias, weight, sums, float(M), 0, hip.ACT_IDENTITY | (act & hip.NORM_ABS_GAMMA), 0.0)
+        else:
+            hip.abn_backward(z, N, dy, N, y, N if y is not None else 0, dz, N, dres, N if has_res else 0, M, N, None, HW,
+                             buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:], bias, weight, sums, float(M), True, True, act, slope)
         dilation, wflip, own_dgrad, wgrad_conv = ctx.conv3
+        link = ctx.link
+
+        def link_args():       # out_mode 3 against the producer's statistics; marks the link as served
+            lz, lbuf, lbias, lpart, lflag, lact, lslope = link
+            C = lz.shape[1]
+            lflag[0] = 1
+            return dict(out_mode=3, out_norm=(lbuf[3 * C:4 * C], lbuf[5 * C:], lbias, lbuf[4 * C:5 * C], lact & hip.ACT_MASK, lslope),
+                        residual=rows(lz), partial=lpart)
         if dilation > 0:
             dx = dw = None
             if ctx.needs_input_grad[0]:
@@ -346,19 +374,20 @@ class _ConvABNFunction(torch.autograd.Function):
                     wflip = w4.flip(2, 3).transpose(0, 1).contiguous(memory_format=torch.channels_last)
                 if own_dgrad:
                     dx = torch.empty_like(x)
-                    hip.conv1x1(rows(dz), wflip.permute(0, 2, 3, 1).reshape(K, 9 * N), rows(dx), conv3=(H, W, dilation))
+                    hip.conv1x1(rows(dz), wflip.permute(0, 2, 3, 1).reshape(K, 9 * N), rows(dx), conv3=(H, W, dilation),
+                                **(link_args() if link is not None else {}))
                 else:
                     dx = F.conv2d(dz, wflip, None, 1, dilation, dilation)
             if ctx.needs_input_grad[1]:
                 dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [dilation, dilation], [dilation, dilation],
                                                          False, [0, 0], 1, [False, True, False])[1]
-            return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None, None, None
         w2 = w4.reshape(N, K)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if own_dgrad and wflip is not None:
-                hip.conv1x1(rows(dz), wflip.reshape(K, N), rows(dx))
+                hip.conv1x1(rows(dz), wflip.reshape(K, N), rows(dx), **(link_args() if link is not None else {}))
             else:
                 hip.gemm_bf16(1, rows(dz), w2, rows(dx))
         if ctx.needs_input_grad[1] and wgrad_conv:
@@ -369,15 +398,20 @@ class _ConvABNFunction(torch.autograd.Function):
             dzr, xr = rows(dz), rows(x)
             dw = (torch.bmm(dzr.view(S, M // S, N).transpose(1, 2), xr.view(S, M // S, K)).sum(0) if S > 1 else dzr.t() @ xr)
             dw = dw.as_strided(w4.shape, w4.stride())
-        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
-def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_param=None, with_skip=False):
+def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_param=None, with_skip=False, make_link=False):
     """``bn(conv(x) [, residual])`` of a wide 1x1 convolution and a training-mode HIP ABN as ONE autograd node
     (csrc/abn_node.cpp::ConvABNTrainNode): the ABN's batch statistics come out of the GEMM's epilogue.  Returns None when the
-    pair is not eligible (the caller then runs the modules one after the other), else ``y`` or ``(y, shortcut alias of x)``."""
+    pair is not eligible (the caller then runs the modules one after the other), else ``y`` or ``(y, shortcut alias of x)``.
+    ``make_link``: the caller promises that ``y`` feeds exactly one further ``_conv_abn_train`` call and nothing else; ``y`` then
+    carries the link (``y._ucd_link``) through which that consumer's input-gradient product does this ABN's backward reduction
+    in its epilogue (csrc/abn_node.cpp; single-process ABN only; ``UCD_BWD_LINK=0`` switches it off)."""
     if os.environ.get("UCD_FUSED_CONV1X1", "1") == "0":
         return None
+    link = getattr(x, "_ucd_link", None) if os.environ.get("UCD_BWD_LINK", "1") != "0" else None
+    make_link = make_link and os.environ.get("UCD_BWD_LINK", "1") != "0"
     is3 = isinstance(conv, Conv3x3)
     if not ((is3 or (isinstance(conv, Conv1x1) and conv.as_gemm)) and conv.bias is None and conv.weight.requires_grad
             and _is_fused_abn(bn) and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda
@@ -397,9 +431,12 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         wflip = conv._w16_flip if conv.working_weight() is not None else None
     else:
         fused = _own_gemm_with_stats(conv.in_channels, conv.out_channels)
-        wflip = conv._w16_flip if (conv.own_dgrad and conv.working_weight() is not None) else None
+        use_own = conv.own_dgrad or (link is not None and conv.link_dgrad and not with_skip)
+        wflip = conv._w16_flip if (use_own and conv.working_weight() is not None) else None
         own_dgrad = wflip is not None
         wgrad_conv = not conv.wide
+    if link is not None and (not own_dgrad or with_skip):
+        link = None                              # the consumer's input gradient does not run on the own kernel: no link
     from . import abn as _abn
     from . import hip
     node = _gemm_node()
@@ -416,7 +453,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         slope = bn.activation_param if activation_param is None else activation_param
         bn.__dict__.pop("_eval_cache", None)
         y = _ConvABNFunction.apply(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                   act, slope, fused, dilation, wflip, own_dgrad, wgrad_conv)
+                                   act, slope, fused, dilation, wflip, own_dgrad, wgrad_conv, bool(make_link), link)
         return (y, x) if with_skip else y
     if not node.dense_channels_last(x):
         return None
@@ -436,7 +473,12 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     bn.__dict__.pop("_eval_cache", None)
     out = node.conv_abn_train(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
                               slope, comm.handle if comm is not None else 0, world, _hip_stream(), bn._direct_grad_ptr(),
-                              bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad), bool(wgrad_conv))
+                              bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad), bool(wgrad_conv),
+                              bool(make_link and not sync), *((link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]))
+                                                              if (link is not None and not sync) else (None, None, None, None, None, 0, 0.0)))
+    k = 2 if with_skip else 1
+    if len(out) > k:                             # the node made a link: (z, buf, partial, flag) follow the regular outputs
+        out[0]._ucd_link = (out[k], out[k + 1], bn.bias, out[k + 2], out[k + 3], act, slope)
     return (out[0], out[1]) if with_skip else out[0]
 
 
@@ -488,6 +530,10 @@ class ResidualBlock(nn.Module):
         layers[-1][1].activation = "identity"
         self.convs = nn.Sequential(OrderedDict(layers))
         self._last_bn = f"bn{len(spec)}"
+        c3 = getattr(self.convs, "conv3", None)
+        if (isinstance(c3, Conv1x1) and isinstance(getattr(self.convs, "conv2", None), Conv3x3) and c3.in_channels % 64 == 0
+                and c3.out_channels % 64 == 0 and c3.out_channels <= 1024):
+            c3.link_dgrad = True          # conv2 + bn2 -> conv3: bn2's backward reduction rides on conv3's input gradient
 
         if stride != 1 or in_channels != channels[-1]:
             self.proj_conv = (Conv1x1(in_channels, channels[-1]) if stride == 1 else
@@ -588,10 +634,10 @@ class ResidualBlock(nn.Module):
             # wide bottleneck in training: every 1x1 convolution and its ABN are one node (statistics in the GEMM epilogue)
             c = self.convs
             skip = residual is x and x.requires_grad
-            first = _conv_abn_train(c.conv1, c.bn1, x, with_skip=skip)
+            first = _conv_abn_train(c.conv1, c.bn1, x, with_skip=skip, make_link=True)      # h1 feeds conv2 only
             if first is not None:
                 h1, res = first if skip else (first, residual)
-                h2 = _conv_abn_train(c.conv2, c.bn2, h1)      # 3x3 as implicit GEMM + statistics (stride-1 layers)
+                h2 = _conv_abn_train(c.conv2, c.bn2, h1, make_link=True)      # 3x3 as implicit GEMM + statistics; h2 feeds conv3 only
                 if h2 is None:
                     h2 = c.bn2(c.conv2(h1))
                 out = _conv_abn_train(c.conv3, c.bn3, h2, residual=res, activation=act, activation_param=slope)

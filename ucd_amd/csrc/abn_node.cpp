@@ -340,13 +340,35 @@ at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d, c10::optional<at:
 // with_skip: x is also the block's identity shortcut; the node returns (y, alias of x) so that x has one consumer and the
 // shortcut's gradient is folded into the input-gradient product (Gemm1x1SkipNode's trick).
 // Reference: conv1 -> bn1, conv3 -> bn3 (+ shortcut, activation), proj_conv -> proj_bn of modules/residual.py:57-97.
+// B side of the backward link: turn the input-gradient product into out_mode 3 against the producer's statistics
+static void link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& lk_z, const at::Tensor& lk_buf, const at::Tensor& lk_bias,
+                          const at::Tensor& lk_partial, const at::Tensor& lk_flag, int64_t C, AutogradContext* ctx) {
+  const float* b = lk_buf.data_ptr<float>();
+  d.out_mode = 3;
+  d.out_mean = b + 3 * C; d.out_invstd = b + 4 * C; d.out_scale = b + 5 * C;
+  d.out_shift = lk_bias.data_ptr<float>();
+  d.residual = lk_z.data_ptr(); d.ldr = (int)C;
+  d.out_act = (int)(ctx->saved_data["lk_act"].toInt() & UCD_ACT_MASK);
+  d.out_slope = (float)ctx->saved_data["lk_slope"].toDouble();
+  d.partial = lk_partial.data_ptr<float>();
+  lk_flag.data_ptr<int64_t>()[0] = 1;
+}
+
 class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
  public:
   static variable_list forward(AutogradContext* ctx, at::Tensor x, at::Tensor w4, at::Tensor weight, at::Tensor bias,
                                c10::optional<at::Tensor> residual_, at::Tensor running_mean, at::Tensor running_var,
                                double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
                                int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
-                               c10::optional<at::Tensor> wflip_, bool own_dgrad, bool wgrad_conv) {
+                               c10::optional<at::Tensor> wflip_, bool own_dgrad, bool wgrad_conv, bool make_link,
+                               c10::optional<at::Tensor> lk_z_, c10::optional<at::Tensor> lk_buf_,
+                               c10::optional<at::Tensor> lk_bias_, c10::optional<at::Tensor> lk_partial_,
+                               c10::optional<at::Tensor> lk_flag_, int64_t lk_act, double lk_slope) {
+    // Backward link between two nodes of a chain  A (conv + ABN) -> B (conv + ABN)  where A's output feeds B only:
+    // B's input-gradient product applies A's activation derivative and accumulates A's two backward sums in its epilogue
+    // (ucd_conv1x1 out_mode 3), so A's backward skips its reduction pass (ucd_abn_bwd_reduce: two reads of the map).
+    // make_link (A): also return (z, buf, partial, flag) - partial [row tiles][2][N] on the device, flag a CPU word B sets.
+    // lk_* (B): A's z, statistics buffer, bias, partial, flag, activation.  Single-process ABN only (no SyncBN exchange).
     // dilation = 0: 1x1 convolution; dilation >= 1: 3x3, stride 1, padding = dilation (implicit GEMM, taps = 9), weight in
     // channels-last memory order; wflip = w.flip(2, 3).transpose(0, 1) (channels-last; for a 1x1 layer the transposed
     // weight [Ci, Co]) for the input gradient through the own kernel (own_dgrad); wgrad_conv: weight gradient by MIOpen
@@ -426,7 +448,23 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
               "ucd_abn_forward");
     }
     const bool needs_y = has_res && (act & UCD_ACT_MASK) != UCD_ACT_IDENTITY;
-    ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf, wflip});
+    at::Tensor lk_z = lk_z_.has_value() ? *lk_z_ : at::Tensor(), lk_buf = lk_buf_.has_value() ? *lk_buf_ : at::Tensor();
+    at::Tensor lk_bias = lk_bias_.has_value() ? *lk_bias_ : at::Tensor();
+    at::Tensor lk_partial = lk_partial_.has_value() ? *lk_partial_ : at::Tensor();
+    at::Tensor lk_flag = lk_flag_.has_value() ? *lk_flag_ : at::Tensor();
+    const bool consume_link = lk_z.defined() && lk_buf.defined() && lk_bias.defined() && lk_partial.defined() && lk_flag.defined() && !sync;
+    at::Tensor my_partial, my_flag;
+    make_link = make_link && !sync && !has_res && bias.defined();
+    if (make_link) {
+      my_partial = at::empty({(int64_t)ucd_conv1x1_row_tiles((int)M), 2, N}, x.options().dtype(at::kFloat));
+      my_flag = at::zeros({1}, at::TensorOptions().dtype(at::kLong));
+    }
+    ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf, wflip,
+                            consume_link ? lk_z : at::Tensor(), consume_link ? lk_buf : at::Tensor(),
+                            consume_link ? lk_bias : at::Tensor(), consume_link ? lk_partial : at::Tensor(),
+                            consume_link ? lk_flag : at::Tensor(), my_partial, my_flag});
+    ctx->saved_data["lk_act"] = lk_act;
+    ctx->saved_data["lk_slope"] = lk_slope;
     ctx->saved_data["act"] = act;
     ctx->saved_data["slope"] = slope;
     ctx->saved_data["comm"] = comm;
@@ -438,6 +476,13 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     ctx->saved_data["dilation"] = dilation;
     ctx->saved_data["own_dgrad"] = own_dgrad;
     ctx->saved_data["wgrad_conv"] = wgrad_conv;
+    if (make_link) {   // outputs: y, [x], z, buf, partial, flag
+      // no zero-filled stand-ins for the gradients of the link tensors (the engine would launch a fill per output and step)
+      ctx->set_materialize_grads(false);
+      ctx->mark_non_differentiable({z, buf, my_partial, my_flag});
+      if (with_skip) return {y, x, z, buf, my_partial, my_flag};
+      return {y, z, buf, my_partial, my_flag};
+    }
     if (with_skip) return {y, x};
     return {y};
   }
@@ -446,6 +491,8 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     auto saved = ctx->get_saved_variables();
     at::Tensor x = saved[0], w4 = saved[1], z = saved[2], y = saved[3], weight = saved[4], bias = saved[5], buf = saved[6];
     at::Tensor wflip = saved[7];
+    at::Tensor lk_z = saved[8], lk_buf = saved[9], lk_bias = saved[10], lk_partial = saved[11], lk_flag = saved[12];
+    at::Tensor my_partial = saved[13], my_flag = saved[14];
     const int64_t dilation = ctx->saved_data["dilation"].toInt();
     const bool conv3 = dilation > 0, own_dgrad = ctx->saved_data["own_dgrad"].toBool();
     const int64_t act = ctx->saved_data["act"].toInt(), comm = ctx->saved_data["comm"].toInt();
@@ -472,7 +519,21 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)N);
       void* ws = workspace(x, ws_bytes, stream);
       const void* yp = y.defined() ? y.data_ptr() : nullptr;
-      if (sync) {
+      const bool linked = my_flag.defined() && my_flag.data_ptr<int64_t>()[0] == 1;
+      if (linked) {
+        // the consumer's input-gradient product already applied this layer's activation derivative and left the two sums
+        // as per-tile partials: combine them (fixed order) and go straight to the apply pass
+        my_flag.data_ptr<int64_t>()[0] = 0;
+        float* sm = param_grad ? param_grad : sums.data_ptr<float>();
+        check(ucd_abn_reduce_partials(my_partial.data_ptr<float>(), ucd_conv1x1_row_tiles((int)M), (int)N, sm, nullptr, fptr(weight),
+                                      (int)(act & UCD_NORM_ABS_GAMMA), (ucd_stream_t)stream),
+              "ucd_abn_reduce_partials");
+        check(ucd_abn_bwd_apply(z.data_ptr(), (int)N, dy.data_ptr(), (int)N, nullptr, 0, dz.data_ptr(), (int)N, nullptr, 0, UCD_BF16,
+                                (int)M, (int)N, nullptr, (int)HW, mean, invstd, scale, fptr(bias), fptr(weight), sm, (float)M, 0,
+                                (int)(UCD_ACT_IDENTITY | (act & UCD_NORM_ABS_GAMMA)), 0.f, (ucd_stream_t)stream),
+              "ucd_abn_bwd_apply");
+        if (!param_grad) { dbias = sums.narrow(0, 0, N); dweight = sums.narrow(0, N, N); }
+      } else if (sync) {
         check(ucd_abn_sync_backward_comm((ucd_comm_t)comm, (int)world, z.data_ptr(), (int)N, dy.data_ptr(), (int)N, yp, yp ? (int)N : 0,
                                          dz.data_ptr(), (int)N, has_res ? dres.data_ptr() : nullptr, has_res ? (int)N : 0, UCD_BF16,
                                          (int)M, (int)N, nullptr, (int)HW, mean, invstd, scale, fptr(bias), fptr(weight),
@@ -501,6 +562,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
           d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)(9 * N); d.y = dx.data_ptr(); d.ldy = (int)K;
           d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0;
           d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation;
+          if (lk_flag.defined()) link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
           check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
         } else {
           dx = at::conv2d(dz, wflip, {}, {1, 1}, {dilation, dilation}, {dilation, dilation}, 1);
@@ -510,7 +572,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {dilation, dilation}, {dilation, dilation}, false,
                                                   {0, 0}, 1, {false, true, false}));
       return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-              none, none, none, none};
+              none, none, none, none, none, none, none, none, none, none, none, none};
     }
     const size_t wsb = ucd_gemm_workspace_bytes();
     void* gws = workspace(x, wsb, stream, 1);
@@ -525,6 +587,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         memset(&d, 0, sizeof(d));
         d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)N; d.y = dx.data_ptr(); d.ldy = (int)K;
         d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0; d.accumulate = fold ? 1 : 0;
+        if (lk_flag.defined() && !fold && !dskip.defined()) link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
         check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
         if (!fold && dskip.defined()) dx = dx + dskip;
       } else if (fold) {
@@ -567,7 +630,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       dw = dw.as_strided(w4.sizes(), w4.strides());
     }
     return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -575,9 +638,13 @@ std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor w
                                        c10::optional<at::Tensor> residual, at::Tensor running_mean, at::Tensor running_var,
                                        double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
                                        int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
-                                       c10::optional<at::Tensor> wflip, bool own_dgrad, bool wgrad_conv) {
+                                       c10::optional<at::Tensor> wflip, bool own_dgrad, bool wgrad_conv, bool make_link,
+                                       c10::optional<at::Tensor> lk_z, c10::optional<at::Tensor> lk_buf,
+                                       c10::optional<at::Tensor> lk_bias, c10::optional<at::Tensor> lk_partial,
+                                       c10::optional<at::Tensor> lk_flag, int64_t lk_act, double lk_slope) {
   return ConvABNTrainNode::apply(x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world,
-                                 stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad, wgrad_conv);
+                                 stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad, wgrad_conv, make_link, lk_z,
+                                 lk_buf, lk_bias, lk_partial, lk_flag, lk_act, lk_slope);
 }
 
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,

@@ -676,8 +676,8 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   const bool conv3 = d->taps == 9;
   UCD_REQUIRE(d->taps == 0 || d->taps == 1 || conv3, UCD_EINVAL, "%s: taps must be 1 (1x1) or 9 (3x3)", fn);
   UCD_REQUIRE(!conv3 || (d->H > 0 && d->W > 0 && d->dilation >= 1 && (long long)d->M % ((long long)d->H * d->W) == 0 &&
-                         d->ldw >= 9 * d->K && !d->in_scale && d->out_mode <= 2),
-              UCD_EINVAL, "%s: 3x3 mode needs H, W, dilation, M = B*H*W, ldw >= 9 K, no input transform, out_mode <= 2", fn);
+                         d->ldw >= 9 * d->K && !d->in_scale),
+              UCD_EINVAL, "%s: 3x3 mode needs H, W, dilation, M = B*H*W, ldw >= 9 K, no input transform", fn);
   UCD_REQUIRE(aligned16(d->a) && aligned16(d->w) && aligned16(d->y) && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldy % 8 == 0 &&
                   d->lda >= d->K && d->ldw >= d->K && d->ldy >= d->N,
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
@@ -708,7 +708,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   // double-buffered form (256->256 50.6 -> 47.3 us, the ASPP branches 338-356 -> 308-314); fuller grids are faster with
   // the single stage and four workgroups per CU (512->512 170 vs 179, 128->128 at 65^2 48.7 vs 52.6)
   // (the 1x1 products of such grids gain too: 1024 -> 256 23.3 -> 21.7 us, with statistics 25.1 -> 23.6)
-  const bool db = (conv3 || (!d->in_scale && d->out_mode <= 2)) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640;
+  const bool db = (conv3 || !d->in_scale) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640;
   const size_t lds_main = (size_t)(kBM + BN) * 128 * (db ? 2 : 1), lds_out = (size_t)64 * (BN + 4) * 4;
   size_t lds = lds_main > lds_out ? lds_main : lds_out;
   const size_t lds_red = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;       // statistics reduction scratch
@@ -720,8 +720,8 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
 #define UCD_C1_LAUNCH(BNV, PROV, OUTV)                                          \
   {                                                                             \
-    if (!PROV && OUTV <= 2 && db)                                               \
-      conv1x1_kernel<BNV, false, (OUTV <= 2 ? OUTV : 0), false, true><<<grid, kThreads, lds, s>>>(a);   \
+    if (!PROV && db)                                                            \
+      conv1x1_kernel<BNV, false, OUTV, false, true><<<grid, kThreads, lds, s>>>(a);   \
     else                                                                        \
       conv1x1_kernel<BNV, PROV, OUTV><<<grid, kThreads, lds, s>>>(a);           \
   }
@@ -740,8 +740,11 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
     case 1: if (db) conv1x1_kernel<BNV, false, 1, true, true><<<grid, kThreads, lds, s>>>(a);  \
             else conv1x1_kernel<BNV, false, 1, true, false><<<grid, kThreads, lds, s>>>(a);    \
             break;                                                                             \
-    default: if (db) conv1x1_kernel<BNV, false, 2, true, true><<<grid, kThreads, lds, s>>>(a); \
-             else conv1x1_kernel<BNV, false, 2, true, false><<<grid, kThreads, lds, s>>>(a);   \
+    case 2: if (db) conv1x1_kernel<BNV, false, 2, true, true><<<grid, kThreads, lds, s>>>(a);  \
+            else conv1x1_kernel<BNV, false, 2, true, false><<<grid, kThreads, lds, s>>>(a);    \
+            break;                                                                             \
+    default: if (db) conv1x1_kernel<BNV, false, 3, true, true><<<grid, kThreads, lds, s>>>(a); \
+             else conv1x1_kernel<BNV, false, 3, true, false><<<grid, kThreads, lds, s>>>(a);   \
              break;                                                                            \
   }
   if (conv3) {

@@ -80,7 +80,7 @@ class Bf16Weights:
         if not self.trainable:
             return
         mods = [m for m in self.convs if isinstance(m, (Conv3x3, Conv1x1)) and m.weight.requires_grad and m.bias is None
-                and m.stride == (1, 1) and m.groups == 1 and not (isinstance(m, Conv1x1) and m.as_gemm and not m.own_dgrad)
+                and m.stride == (1, 1) and m.groups == 1 and not (isinstance(m, Conv1x1) and m.as_gemm and not (m.own_dgrad or m.link_dgrad))
                 and m.weight.is_contiguous(memory_format=torch.channels_last)]
         if not mods:
             return
