@@ -374,3 +374,60 @@ def test_residual_block_training_with_own_3x3(cin, chans, dil, hw):
     torch.testing.assert_close(rvf, rv32, rtol=5e-3, atol=1e-5)
     for n in gf:
         assert _rel(gf[n], g32[n]) < 1.5 * _rel(gp[n], g32[n]) + 1e-2, (n, _rel(gf[n], g32[n]), _rel(gp[n], g32[n]))
+
+
+@pytest.mark.parametrize("cin,chans,hw", [(1024, (256, 256, 1024), 33), (256, (64, 64, 256), 65)])
+def test_backward_link_moves_the_abn_reduction_into_the_input_gradient_product(cin, chans, hw):
+    """conv1 + bn1 -> conv2 + bn2 -> conv3 + bn3 of a bottleneck: with the backward link the input-gradient products of conv2
+    (3x3) and conv3 (1x1) run in out_mode 3 - activation derivative of the producer's ABN and its two sums in the epilogue -
+    and bn1 / bn2 skip their reduction pass.  Same gradients as without the link (UCD_BWD_LINK=0) up to bf16 rounding of one
+    intermediate map; the number of ucd_abn_bwd_reduce calls drops from 3 to 1 (counted on the Python twin, which issues the
+    same library calls as the C++ node)."""
+    from functools import partial
+    from ucd_amd import abn, blocks, hip
+    from ucd_amd.ddp import DistributedDataParallel
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    B = 24
+    x0 = synth.t_normal(9, (B, cin, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(10, (B, chans[2], hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    node = blocks._gemm_node()
+    res, counts = {}, {}
+    real_reduce = hip.abn_bwd_reduce
+    for use_node in (True, False):
+        for link in ("1", "0"):
+            calls = [0]
+
+            def counting(*a, **k):
+                calls[0] += 1
+                return real_reduce(*a, **k)
+            os.environ["UCD_BWD_LINK"] = link
+            blocks._node_cache[0] = node if use_node else None
+            hip.abn_bwd_reduce = counting
+            saved_timing = hip._timing
+            if not use_node:
+                hip._timing = {}                       # the twin's per-kernel path (what bench.py's instrumented pass runs)
+            try:
+                blk = blocks.ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=1)
+                blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+                blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
+                mod = DistributedDataParallel(blk, bf16_weights=True)
+                x = x0.clone().requires_grad_(True)
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    y = mod(x * 1.0)
+                y.backward(dy)
+                mod.finish_grad_sync()
+                res[(use_node, link)] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in blk.parameters()]
+                counts[(use_node, link)] = calls[0]
+            finally:
+                os.environ.pop("UCD_BWD_LINK", None)
+                blocks._node_cache[0] = node
+                hip.abn_bwd_reduce = real_reduce
+                hip._timing = saved_timing
+    assert counts[(False, "0")] == 3 and counts[(False, "1")] == 1, counts
+    for use_node in (True, False):
+        a, b = res[(use_node, "1")], res[(use_node, "0")]
+        assert torch.equal(a[0], b[0])                                   # the forward is untouched
+        for i in range(1, len(a)):
+            assert _rel(a[i], b[i]) < 3e-2, (use_node, i, _rel(a[i], b[i]))
+    for i, (a, b) in enumerate(zip(res[(True, "1")], res[(False, "1")])):
+        assert _rel(a, b) < 1e-2, i                                       # node and twin agree with the link on
