@@ -434,7 +434,7 @@ def test_aspp_eval_pooling_on_the_gpu_matches_reference_golden(tag):
 
 def test_bf16_step_bias_against_the_fp32_step_of_the_product():
     """What --opt_level O1 (bf16 activations, fp16 contrastive operands - the benchmarked mode) costs in accuracy, measured
-    on the product itself: the same step in O0 and O1 under deterministic solvers, at the benchmark's crop (2 x 513^2, so
+    on the product itself: the same step in O0 and O1, at the benchmark's crop (2 x 513^2, so
     the batch statistics see 2178+ values per channel like the real workload's, not the 162 of the 129^2 case)."""
     from ucd_amd.run import make_optimizer
     from ucd_amd.train import Trainer
@@ -442,17 +442,16 @@ def test_bf16_step_bias_against_the_fp32_step_of_the_product():
     img = synth.images(502, 2, 513)
     labels = synth.seg_labels(502, 2, 513, 513, range(16, 21))
     out = {}
-    torch.backends.cudnn.deterministic = True
-    try:
-        for lvl in ("O0", "O1"):
-            opts = _opts(["--opt_level", lvl])
-            model, model_old, classes = _build(opts, dev)
-            trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
-            optim = make_optimizer(opts, model)
-            model.train()
-            out[lvl] = {k: v.item() for k, v in trainer.train_step(img, labels, optim, None).items()}
-    finally:
-        torch.backends.cudnn.deterministic = False
+    # MIOpen's default solvers (its deterministic-only mode returned miopenStatusBadParm for one backward problem of this
+    # 513^2 step when the test ran late in the full suite on two boxes of the pool - a library state issue, not reproducible
+    # in isolation; the bounds below cover the solver noise of the default mode anyway)
+    for lvl in ("O0", "O1"):
+        opts = _opts(["--opt_level", lvl])
+        model, model_old, classes = _build(opts, dev)
+        trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+        optim = make_optimizer(opts, model)
+        model.train()
+        out[lvl] = {k: v.item() for k, v in trainer.train_step(img, labels, optim, None).items()}
     g = load_golden("ucd_step_513.npz")
     rel = {k: abs(out["O1"][k] - out["O0"][k]) / abs(out["O0"][k]) for k in ("ce", "con", "lkd", "loss")}
     print("bf16-vs-fp32 relative differences of the product:", rel, out)

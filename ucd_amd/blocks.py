@@ -431,9 +431,9 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         wflip = conv._w16_flip if conv.working_weight() is not None else None
     else:
         fused = _own_gemm_with_stats(conv.in_channels, conv.out_channels)
-        use_own = conv.own_dgrad or (link is not None and conv.link_dgrad and not with_skip)
-        wflip = conv._w16_flip if (use_own and conv.working_weight() is not None) else None
-        own_dgrad = wflip is not None
+        own_dgrad = conv.own_dgrad or (link is not None and conv.link_dgrad and not with_skip)
+        # the transposed weight: cached with the bf16 working copies, else made per call below (same kernels either way)
+        wflip = conv._w16_flip if (own_dgrad and conv.working_weight() is not None) else None
         wgrad_conv = not conv.wide
     if link is not None and (not own_dgrad or with_skip):
         link = None                              # the consumer's input gradient does not run on the own kernel: no link
@@ -449,6 +449,8 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         w16 = conv.working_weight()
         if w16 is None:
             w16 = conv.weight.to(x.dtype)
+        if own_dgrad and not is3 and wflip is None:
+            wflip = w16.reshape(conv.out_channels, conv.in_channels).t().contiguous().view(conv.in_channels, conv.out_channels, 1, 1)
         act = _abn._act_code(bn.activation if activation is None else activation) | (hip.NORM_ABS_GAMMA if bn._abs_gamma else 0)
         slope = bn.activation_param if activation_param is None else activation_param
         bn.__dict__.pop("_eval_cache", None)
@@ -468,6 +470,8 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     w16 = conv.working_weight()
     if w16 is None:
         w16 = conv.weight.to(x.dtype)
+    if own_dgrad and not is3 and wflip is None:
+        wflip = w16.reshape(conv.out_channels, conv.in_channels).t().contiguous().view(conv.in_channels, conv.out_channels, 1, 1)
     act = _abn._act_code(bn.activation if activation is None else activation) | (hip.NORM_ABS_GAMMA if bn._abs_gamma else 0)
     slope = bn.activation_param if activation_param is None else activation_param
     bn.__dict__.pop("_eval_cache", None)
