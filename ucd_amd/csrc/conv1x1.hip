@@ -22,13 +22,18 @@
 //   The input gradient of the layer is the same kernel on (dY, W^T); the weight gradient is conv1x1_wgrad below.
 //
 // Tiling: a workgroup of 4 waves owns a 128 x BN tile (BN = 128, or 64 for the 64-channel layers), each wave a
-// 64 x BN/2 sub-tile as 2 x (BN/64) accumulators of 32 x 32; K is walked in steps of 64 through two LDS buffers, the
-// next step's global loads in flight under the current step's MFMAs (register staging: the input transform and the
-// row mask of the last tile need the values in registers anyway).  LDS rows are padded to 144 bytes, which makes the
-// ds_read_b128 fragment reads conflict-free for every 16-lane group.  Two workgroups are resident per CU.  The output
-// tile goes through LDS (fp32) so that global stores, residual loads and the per-channel reductions are row-contiguous
-// 16-byte accesses.  blockIdx -> tile: the column tiles of one row strip sit on the same XCD (ids congruent mod 8 share
-// an L2), so a strip of A is fetched from HBM once.
+// 64 x BN/2 sub-tile as 2 x (BN/64) accumulators of 32 x 32; K is walked in steps of 64.  Both operand tiles are filled by
+// LDS-DMA (global_load_lds_dwordx4: no registers, no ds_write); its destination is lane-linear, so the bank-conflict
+// swizzle sits on the SOURCE address (slot s of row r lives at s ^ ((r >> 1) & 7): every 16-lane group of a ds_read_b128
+// hits 16 different 16-byte slots without padding).  Two forms of the K loop:
+//   single stage, four workgroups per CU (34 KB LDS, <= 128 VGPRs): {fill; vmcnt(0); barrier; 16 ds_read_b128 + 16 MFMA;
+//     barrier} - the fill latency of one workgroup is covered by the MFMAs of the other three;
+//   DB, two stages, two workgroups per CU: the fill of step k+1 is issued before the MFMAs of step k and waited for with
+//     a counted vmcnt - for grids that give a CU only one or two workgroups (chosen by the host per launch).
+// Only the fused input transform (PRO) stages A through registers (it has to touch the values).  Rows past M are clamped,
+// never branched around and never stored.  The output tile goes through LDS (fp32, two 64-row halves) so that global
+// stores, residual loads and the per-channel reductions are row-contiguous 16-byte accesses.  blockIdx -> tile: the
+// column tiles of one row strip sit on the same XCD (ids congruent mod 8 share an L2), so a strip of A leaves HBM once.
 #include "common.h"
 #include "abn_finalize.h"
 
