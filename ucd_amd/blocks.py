@@ -191,12 +191,13 @@ class Conv3x3(Conv2d):
 
 
 class Conv1x1(Conv2d):
-    """1x1 stride-1 convolution with the reference's parameter shape ([Cout, Cin, 1, 1]).  On the GPU, for
-    the wide layers of the network (mod4 / mod5 / ASPP at the stride-16 resolution), it runs as ONE plain
-    GEMM on the channels-last row matrix [B*H*W, Cin] x [Cin, Cout] (hipBLASLt) instead of an MIOpen
-    implicit-GEMM convolution: measured on MI355X (tools/gemm_vs_conv_probe.py, bf16, forward+backward,
-    B=24 at 33x33) 1.2x faster at 1024<->256, 1.5-1.7x at 2048<->512, 2.4x at 1024->2048; the narrow early
-    layers (<= 512 channels at 65x65 / 129x129) stay with MIOpen, which wins there."""
+    """1x1 stride-1 convolution with the reference's parameter shape ([Cout, Cin, 1, 1]).  On the GPU every layer with
+    64-aligned channel counts runs as a product on the channels-last row matrix [B*H*W, Cin] x [Cin, Cout] instead of an
+    MIOpen implicit-GEMM convolution: inside ``_conv_abn_train`` / the teacher's fused blocks on the own kernel
+    (csrc/conv1x1.hip) with the ABN work in its epilogue, called on its own through the tuned library GEMM (measured on
+    MI355X, tools/gemm_vs_conv_probe.py / conv1x1_probe.py, bf16, B = 24: the library 1.2x faster than MIOpen at 1024<->256,
+    1.5-1.7x at 2048<->512, 2.4x at 1024->2048; the own kernel 1.4-2.1x faster than MIOpen on the narrow layers).  Layers
+    off the 64 grid (the classifier heads) stay with MIOpen."""
 
     def __init__(self, in_channels, out_channels, bias=False):
         super().__init__(in_channels, out_channels, 1, stride=1, padding=0, bias=bias)

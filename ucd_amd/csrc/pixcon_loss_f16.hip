@@ -1,4 +1,8 @@
-// PixelConLossV2 streaming kernels, fp16-operand path (the performance mode).
+// PixelConLossV2 streaming kernels, fp16-operand path, FIXED-SPLIT form: every anchor block sweeps all contrast tiles in
+// `nsplit` equal column ranges.  UCD_PIXCON_F16 runs the planned form (pixcon_loss_f16p.hip: device-built unit lists,
+// pure-positive tiles skipped, pinned MFMA / LDS / VALU interleave) where it applies - T >= 0.06, at most 32 teacher
+// classes, fewer than 1024 anchor blocks - and falls back to this file otherwise; UCD_PIXCON_F16_SPLIT selects this
+// file explicitly (the A/B reference of the tests).
 //
 // Same two-sweep structure and the same math as pixcon_loss.hip (see the derivation there); what changes
 // is the arithmetic of the two GEMM pairs: v_mfma_f32_32x32x16_f16 (16x the fp32-MFMA rate) with fp32
