@@ -408,7 +408,8 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     pair is not eligible (the caller then runs the modules one after the other), else ``y`` or ``(y, shortcut alias of x)``.
     ``make_link``: the caller promises that ``y`` feeds exactly one further ``_conv_abn_train`` call and nothing else; ``y`` then
     carries the link (``y._ucd_link``) through which that consumer's input-gradient product does this ABN's backward reduction
-    in its epilogue (csrc/abn_node.cpp; single-process ABN only; ``UCD_BWD_LINK=0`` switches it off)."""
+    in its epilogue (csrc/abn_node.cpp; under SyncBN the producer all-reduces the combined sums; ``UCD_BWD_LINK=0`` switches it
+    off)."""
     if os.environ.get("UCD_FUSED_CONV1X1", "1") == "0":
         return None
     link = getattr(x, "_ucd_link", None) if os.environ.get("UCD_BWD_LINK", "1") != "0" else None
@@ -479,8 +480,8 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     out = node.conv_abn_train(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
                               slope, comm.handle if comm is not None else 0, world, _hip_stream(), bn._direct_grad_ptr(),
                               bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad), bool(wgrad_conv),
-                              bool(make_link and not sync), *((link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]))
-                                                              if (link is not None and not sync) else (None, None, None, None, None, 0, 0.0)))
+                              bool(make_link), *((link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]))
+                                                 if link is not None else (None, None, None, None, None, 0, 0.0)))
     k = 2 if with_skip else 1
     if len(out) > k:                             # the node made a link: (z, buf, partial, flag) follow the regular outputs
         out[0]._ucd_link = (out[k], out[k + 1], bn.bias, out[k + 2], out[k + 3], act, slope)

@@ -368,7 +368,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     // B's input-gradient product applies A's activation derivative and accumulates A's two backward sums in its epilogue
     // (ucd_conv1x1 out_mode 3), so A's backward skips its reduction pass (ucd_abn_bwd_reduce: two reads of the map).
     // make_link (A): also return (z, buf, partial, flag) - partial [row tiles][2][N] on the device, flag a CPU word B sets.
-    // lk_* (B): A's z, statistics buffer, bias, partial, flag, activation.  Single-process ABN only (no SyncBN exchange).
+    // lk_* (B): A's z, statistics buffer, bias, partial, flag, activation.  Under SyncBN the producer all-reduces the sums.
     // dilation = 0: 1x1 convolution; dilation >= 1: 3x3, stride 1, padding = dilation (implicit GEMM, taps = 9), weight in
     // channels-last memory order; wflip = w.flip(2, 3).transpose(0, 1) (channels-last; for a 1x1 layer the transposed
     // weight [Ci, Co]) for the input gradient through the own kernel (own_dgrad); wgrad_conv: weight gradient by MIOpen
@@ -452,9 +452,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     at::Tensor lk_bias = lk_bias_.has_value() ? *lk_bias_ : at::Tensor();
     at::Tensor lk_partial = lk_partial_.has_value() ? *lk_partial_ : at::Tensor();
     at::Tensor lk_flag = lk_flag_.has_value() ? *lk_flag_ : at::Tensor();
-    const bool consume_link = lk_z.defined() && lk_buf.defined() && lk_bias.defined() && lk_partial.defined() && lk_flag.defined() && !sync;
+    const bool consume_link = lk_z.defined() && lk_buf.defined() && lk_bias.defined() && lk_partial.defined() && lk_flag.defined();
     at::Tensor my_partial, my_flag;
-    make_link = make_link && !sync && !has_res && bias.defined();
+    make_link = make_link && !has_res && bias.defined();
     if (make_link) {
       my_partial = at::empty({(int64_t)ucd_conv1x1_row_tiles((int)M), 2, N}, x.options().dtype(at::kFloat));
       my_flag = at::zeros({1}, at::TensorOptions().dtype(at::kLong));
@@ -524,15 +524,24 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         // the consumer's input-gradient product already applied this layer's activation derivative and left the two sums
         // as per-tile partials: combine them (fixed order) and go straight to the apply pass
         my_flag.data_ptr<int64_t>()[0] = 0;
-        float* sm = param_grad ? param_grad : sums.data_ptr<float>();
-        check(ucd_abn_reduce_partials(my_partial.data_ptr<float>(), ucd_conv1x1_row_tiles((int)M), (int)N, sm, nullptr, fptr(weight),
-                                      (int)(act & UCD_NORM_ABS_GAMMA), (ucd_stream_t)stream),
+        // single process: the sums are the parameter gradients and the constants of the apply pass.  SyncBN: the apply
+        // pass needs the sums over all ranks (all-reduce, like ucd_abn_sync_backward_comm), the parameter gradients stay
+        // this rank's (the DDP wrapper averages them).
+        float* local = param_grad ? param_grad : sums.data_ptr<float>() + (sync ? 2 * N : 0);
+        float* global = sync ? sums.data_ptr<float>() : local;
+        check(ucd_abn_reduce_partials(my_partial.data_ptr<float>(), ucd_conv1x1_row_tiles((int)M), (int)N, global,
+                                      sync ? local : nullptr, fptr(weight), (int)(act & UCD_NORM_ABS_GAMMA), (ucd_stream_t)stream),
               "ucd_abn_reduce_partials");
+        if (sync) check(ucd_comm_all_reduce_sum((ucd_comm_t)comm, global, (size_t)2 * N, (ucd_stream_t)stream), "ucd_comm_all_reduce_sum");
         check(ucd_abn_bwd_apply(z.data_ptr(), (int)N, dy.data_ptr(), (int)N, nullptr, 0, dz.data_ptr(), (int)N, nullptr, 0, UCD_BF16,
-                                (int)M, (int)N, nullptr, (int)HW, mean, invstd, scale, fptr(bias), fptr(weight), sm, (float)M, 0,
-                                (int)(UCD_ACT_IDENTITY | (act & UCD_NORM_ABS_GAMMA)), 0.f, (ucd_stream_t)stream),
+                                (int)M, (int)N, nullptr, (int)HW, mean, invstd, scale, fptr(bias), fptr(weight), global,
+                                (float)M * (sync ? (float)world : 1.f), 0, (int)(UCD_ACT_IDENTITY | (act & UCD_NORM_ABS_GAMMA)), 0.f,
+                                (ucd_stream_t)stream),
               "ucd_abn_bwd_apply");
-        if (!param_grad) { dbias = sums.narrow(0, 0, N); dweight = sums.narrow(0, N, N); }
+        if (!param_grad) {
+          dbias = sums.narrow(0, sync ? 2 * N : 0, N);
+          dweight = sums.narrow(0, sync ? 3 * N : N, N);
+        }
       } else if (sync) {
         check(ucd_abn_sync_backward_comm((ucd_comm_t)comm, (int)world, z.data_ptr(), (int)N, dy.data_ptr(), (int)N, yp, yp ? (int)N : 0,
                                          dz.data_ptr(), (int)N, has_res ? dres.data_ptr() : nullptr, has_res ? (int)N : 0, UCD_BF16,
