@@ -64,15 +64,17 @@ def test_cpp_gemm_node_equals_python_function():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("ci,co,hw,d", [(256, 256, 33, 1), (512, 512, 33, 2), (2048, 256, 33, 12), (64, 64, 65, 1)])
-def test_conv3x3_input_gradient_on_the_forward_solver(ci, co, hw, d):
+@pytest.mark.parametrize("ci,co,hw,d,B", [(256, 256, 33, 1, 8), (512, 512, 33, 2, 8), (2048, 256, 33, 12, 8), (64, 64, 65, 1, 8),
+                                           (2048, 256, 33, 12, 24), (256, 256, 33, 1, 24)])
+def test_conv3x3_input_gradient_on_the_forward_solver(ci, co, hw, d, B):
     """ucd_amd/blocks.py::Conv3x3 computes dx with the forward solver on the flipped / transposed weight: the same
     arithmetic as conv2d's own backward (reference: nn.Conv2d(k=3, padding=dilation), modules/residual.py:69,
     modules/deeplab.py:27-29), compared in fp32 on bf16-rounded operands."""
     from ucd_amd.blocks import Conv3x3
     dev = torch.device("cuda:0")
     torch.manual_seed(ci + co + d)
-    B = 8
+    # B = 24: maps large enough for the own implicit-GEMM kernel (forward and input gradient of the stand-alone layer: the
+    # ASPP branches); B = 8: MIOpen's forward solver for both
     conv = Conv3x3(ci, co, 3, stride=1, padding=d, dilation=d, bias=False).to(dev).to(memory_format=torch.channels_last)
     x32 = torch.randn(B, ci, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)
     dy32 = torch.randn(B, co, hw, hw, device=dev).contiguous(memory_format=torch.channels_last)

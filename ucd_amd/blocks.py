@@ -142,10 +142,13 @@ class _StrideOneConvFn(torch.autograd.Function):
     (256->64 at 129^2 / 512->128 at 65^2 / 256->128 at 129^2)."""
 
     @staticmethod
-    def forward(ctx, x, w, d, wt=None):
+    def forward(ctx, x, w, d, wt=None, own_fwd=False, own_dgrad=False):
         ctx.d = d
         ctx.wt = wt          # w.flip(2, 3).transpose(0, 1), channels-last, when the caller keeps it cached (ucd_amd/master.py)
+        ctx.own_dgrad = own_dgrad
         ctx.save_for_backward(x, w)
+        if own_fwd:
+            return _own3x3(x, w, d)
         return F.conv2d(x, w, None, 1, d * (w.shape[2] // 2), d)
 
     @staticmethod
@@ -159,20 +162,43 @@ class _StrideOneConvFn(torch.autograd.Function):
             if wt is None:
                 wt = (w.transpose(0, 1) if w.shape[2] == 1 else w.flip(2, 3).transpose(0, 1)).contiguous(
                     memory_format=torch.channels_last)
-            dx = F.conv2d(dy, wt, None, 1, pad, d)
+            if ctx.own_dgrad and dy.dtype == torch.bfloat16:
+                dx = _own3x3(dy.contiguous(memory_format=torch.channels_last), wt, d)
+            else:
+                dx = F.conv2d(dy, wt, None, 1, pad, d)
         if ctx.needs_input_grad[1]:
             dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [pad, pad], [d, d], False, [0, 0], 1,
                                                      [False, True, False])[1]
-        return dx, dw, None, None
+        return dx, dw, None, None, None, None
 
 
-def _stride_one_conv(x, w, d, wt=None):
-    """The C++ autograd node when built (no Python in the backward), else the Python Function: same ATen calls."""
+def _own3x3(x, w, d):
+    """3x3 convolution (stride 1, padding = dilation d) of a dense channels-last bf16 map on the implicit-GEMM kernel; ``w``
+    [N, K, 3, 3] in channels-last memory order."""
+    from . import hip
+    B, K, H, W = x.shape
+    N = w.shape[0]
+    y = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0] * t.shape[2] * t.shape[3], t.shape[1])
+    hip.conv1x1(rows(x), w.permute(0, 2, 3, 1).reshape(N, 9 * K), rows(y), conv3=(H, W, d))
+    return y
+
+
+def _own3x3_ok(conv, x):
+    """Can this stand-alone 3x3 layer (the ASPP branches) run on the own kernel at all (layout / alignment)?"""
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.bias is None and conv.stride == (1, 1)
+            and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.groups == 1
+            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[2] > 1 and x.shape[3] > 1
+            and x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("UCD_FUSED_CONV1X1", "1") != "0")
+
+
+def _stride_one_conv(x, w, d, wt=None, own_fwd=False, own_dgrad=False):
+    """The C++ autograd node when built (no Python in the backward), else the Python Function: same library calls."""
     from . import abn
     node = abn._abn_node()
     if node is not None and hasattr(node, "conv_stride1"):
-        return node.conv_stride1(x, w, d, wt)
-    return _StrideOneConvFn.apply(x, w, d, wt)
+        return node.conv_stride1(x, w, d, wt, bool(own_fwd), bool(own_dgrad), _hip_stream())
+    return _StrideOneConvFn.apply(x, w, d, wt, bool(own_fwd), bool(own_dgrad))
 
 
 class Conv3x3(Conv2d):
@@ -180,13 +206,24 @@ class Conv3x3(Conv2d):
     modules/deeplab.py:27-29).  Same parameters and state_dict keys as nn.Conv2d."""
 
     def forward(self, x):
+        M = x.shape[0] * x.shape[2] * x.shape[3] if x.dim() == 4 else 0
+        own = _own3x3_ok(self, x) and self.weight.is_contiguous(memory_format=torch.channels_last)
         if (x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is None
-                and x.dtype == torch.bfloat16 and x.shape[0] * x.shape[2] * x.shape[3] >= 8192
-                and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
+                and x.dtype == torch.bfloat16 and M >= 8192 and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
+            own_fwd = own and _own_conv3x3(M, self.in_channels, self.out_channels)
+            own_dgrad = own and _own_conv3x3(M, self.out_channels, self.in_channels)
             w = self.working_weight()
             if w is None:
-                return _stride_one_conv(x, self.weight.to(x.dtype), self.dilation[0])
-            return _stride_one_conv(x, w, self.dilation[0], self._w16_flip)
+                w = self.weight.to(x.dtype)
+                return _stride_one_conv(x, w, self.dilation[0], None, own_fwd and w.is_contiguous(memory_format=torch.channels_last),
+                                        own_dgrad)
+            return _stride_one_conv(x, w, self.dilation[0], self._w16_flip, own_fwd, own_dgrad)
+        if own and not torch.is_grad_enabled() and _own_conv3x3(M, self.in_channels, self.out_channels):
+            w = self.working_weight()                      # the frozen teacher's ASPP branches
+            if w is None:
+                w = self.weight.to(x.dtype)
+            if w.is_contiguous(memory_format=torch.channels_last):
+                return _own3x3(x, w, self.dilation[0])
         return super().forward(x)
 
 

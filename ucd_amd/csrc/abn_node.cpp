@@ -299,12 +299,30 @@ std::vector<at::Tensor> gemm1x1_skip(at::Tensor rows, at::Tensor w4, int64_t str
 // the Python twin.
 class StrideOneConvNode : public torch::autograd::Function<StrideOneConvNode> {
  public:
-  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt_) {
+  // own_fwd / own_dgrad (3x3 only, dense channels-last bf16, 64-aligned channels): the implicit-GEMM kernel
+  // (ucd_conv1x1, taps = 9) instead of MIOpen where it is the faster one (the ASPP branches: 303-315 vs 382-390 us)
+  static at::Tensor own3x3(const at::Tensor& a, const at::Tensor& w, int64_t d, int64_t stream) {
+    const int64_t B = a.size(0), K = a.size(1), H = a.size(2), W = a.size(3), N = w.size(0);
+    at::Tensor y = at::empty({B, N, H, W}, a.options().memory_format(at::MemoryFormat::ChannelsLast));
+    ucd_conv1x1_desc dsc;
+    memset(&dsc, 0, sizeof(dsc));
+    dsc.a = a.data_ptr(); dsc.lda = (int)K; dsc.w = w.data_ptr(); dsc.ldw = (int)(9 * K); dsc.y = y.data_ptr(); dsc.ldy = (int)N;
+    dsc.M = (int)(B * H * W); dsc.N = (int)N; dsc.K = (int)K; dsc.out_mode = 0;
+    dsc.taps = 9; dsc.H = (int)H; dsc.W = (int)W; dsc.dilation = (int)d;
+    check(ucd_conv1x1(&dsc, (ucd_stream_t)stream), "ucd_conv1x1");
+    return y;
+  }
+
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt_,
+                            bool own_fwd, bool own_dgrad, int64_t stream) {
     const int64_t pad = d * (w.size(2) / 2);
     // wt = w.flip(2, 3).transpose(0, 1) in channels-last order when the caller keeps it cached (ucd_amd/master.py: one
     // batched kernel per optimiser step instead of a flip + copy per layer and step)
     ctx->save_for_backward({x, w, wt_.has_value() ? *wt_ : at::Tensor()});
     ctx->saved_data["d"] = d;
+    ctx->saved_data["own_dgrad"] = own_dgrad;
+    ctx->saved_data["stream"] = stream;
+    if (own_fwd) return own3x3(x, w, d, stream);
     return at::conv2d(x, w, {}, {1, 1}, {pad, pad}, {d, d}, 1);
   }
 
@@ -316,18 +334,24 @@ class StrideOneConvNode : public torch::autograd::Function<StrideOneConvNode> {
     if (ctx->needs_input_grad(0)) {
       if (!wt.defined())
         wt = (w.size(2) == 1 ? w.transpose(0, 1) : w.flip({2, 3}).transpose(0, 1)).contiguous(at::MemoryFormat::ChannelsLast);
-      dx = at::conv2d(dy, wt, {}, {1, 1}, {pad, pad}, {d, d}, 1);
+      if (ctx->saved_data["own_dgrad"].toBool() && dy.scalar_type() == at::kBFloat16) {
+        if (!dense_channels_last(dy)) dy = dy.contiguous(at::MemoryFormat::ChannelsLast);
+        dx = own3x3(dy, wt, d, ctx->saved_data["stream"].toInt());
+      } else {
+        dx = at::conv2d(dy, wt, {}, {1, 1}, {pad, pad}, {d, d}, 1);
+      }
     }
     if (ctx->needs_input_grad(1)) {
       dw = std::get<1>(at::convolution_backward(dy, x, w, c10::nullopt, {1, 1}, {pad, pad}, {d, d}, false, {0, 0}, 1,
                                                 {false, true, false}));
     }
-    return {dx, dw, at::Tensor(), at::Tensor()};
+    return {dx, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
-at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt) {
-  return StrideOneConvNode::apply(x, w, d, wt);
+at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt, bool own_fwd, bool own_dgrad,
+                        int64_t stream) {
+  return StrideOneConvNode::apply(x, w, d, wt, own_fwd, own_dgrad, stream);
 }
 
 // ---- 1x1 convolution + training-mode ABN as ONE node ------------------------------------------------------
