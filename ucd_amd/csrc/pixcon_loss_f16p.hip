@@ -657,7 +657,10 @@ struct LayoutP {
 LayoutP make_layout_p(int BHW) {
   LayoutP L;
   L.nbmax = ceil_div(BHW, kBI);
-  L.umax = kTargetUnits + L.nbmax + 1;
+  // units of a sweep <= sum_b ceil(n_b / CH) <= T / CH + blocks with CH >= max(kMinChunk, T / kTargetUnits), T <= blocks x tiles
+  const long long tiles_max = (2ll * BHW + 2 * kPixTile) / kTJ + 1;
+  const long long by_chunk = ((long long)L.nbmax * tiles_max + kMinChunk - 1) / kMinChunk;
+  L.umax = (int)(by_chunk < kTargetUnits ? by_chunk : kTargetUnits) + L.nbmax + 1;
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes, 256); return at; };
   L.off_hdr = take(sizeof(PlanHdr));
