@@ -1,7 +1,7 @@
 """Data-pipeline pixel work for one batch (24 VOC-sized images -> 513x513): device path vs the reference's host path
 (Pillow crop/resize/flip + torch ToTensor/Normalize + the per-pixel label lambda), same random parameters."""
 import os, sys, time, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from oracle import datapipe as OD
 from ucd_amd import tasks

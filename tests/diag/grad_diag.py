@@ -1,8 +1,8 @@
 """GPU diagnostic (not part of the product): per-parameter gradient comparison of the product's fp32 UCD
 step against the CPU oracle on identical inputs, in backward order, to localise a divergence."""
 import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
 from ucd_amd import argparser, synth, tasks
 from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer

@@ -1,7 +1,7 @@
 """GPU diagnostic: forward activations and activation gradients of the product's fp32 student (train mode)
 vs the CPU oracle at the body / head / logits boundaries, plus the head's internal tensors."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, torch.nn.functional as F
 from ucd_amd import argparser, synth
 from ucd_amd.run import build_models, load_step_checkpoint

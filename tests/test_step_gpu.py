@@ -3,7 +3,7 @@ fp32 against the golden captured from the reference's own classes.
 Bar: losses and logits within 1e-3 relative (north_star).  Parameter GRADIENTS of the composed 100-layer
 network are compared statistically (abs-sum within 10 %, post-step parameters within 1e-3): the
 forward activations of two fp32 implementations (CPU oneDNN vs GPU MIOpen + HIP) differ by ~3e-4
-relative at the head (measured, tools/layer_diag.py), which flips the sign of ~0.1 % of the leaky-ReLU
+relative at the head (measured, tests/diag/layer_diag.py), which flips the sign of ~0.1 % of the leaky-ReLU
 pre-activations per layer; each flip changes that element's gradient by 99 %, so activation gradients
 differ by sqrt(p) ~ 3 % per layer although every individual kernel matches its reference to 1e-5 on
 identical inputs (tests/test_abn_gpu.py, tests/test_pixcon_gpu.py, tests/test_seglosses_gpu.py)."""

@@ -11,7 +11,7 @@ re-ordering - split where the hardware wants it:
   the flip coin: same ``random`` draws in the same order as ``dataset/transform.py``) and runs crop + Pillow-exact resize + flip
   + ToTensor + Normalize (images) and crop + NEAREST resize + flip + the step's label re-mapping (labels) on the GPU
   (``ucd_amd.datapipe``: bit-exact against Pillow / the reference's per-pixel lambda).  The reference does all of it per sample
-  on the host with ``num_workers=0`` (37 img/s measured against 142 846 on the device, tools/datapipe_bench.py).
+  on the host with ``num_workers=0`` (37 img/s measured against 142 846 on the device, tests/diag/datapipe_bench.py).
 
 Validation with ``--crop_val`` (``Resize`` + ``CenterCrop``, run.py:58-65) resizes on the host with Pillow (exact by
 construction) and normalises on the device.  ADE20K / Cityscapes have the same structure (dataset/ade.py, cityscape.py) and
