@@ -8,7 +8,7 @@
 //     (the usual case: 68 % of the pairs on the benchmark step) that was 2/3 of sweep 1 wasted.  Here a PLAN kernel
 //     (one workgroup, device-side: the host never sees the label distribution) builds per anchor block the tile list of
 //     each sweep - sweep 1 = everything except the tiles lying wholly inside the block's own label, sweep 2 = the
-//     same-label ranges - cuts the lists into work units of CH tiles (CH chosen so that either sweep has ~1024 units)
+//     same-label ranges - cuts the lists into work units of CH tiles (CH chosen so that either sweep has ~512 units)
 //     and writes the units in chunk-major order (all blocks' chunk 0, then chunk 1, ...: concurrently running units
 //     stream the same contrast tiles, which therefore come out of each XCD's L2).  The sweeps are persistent kernels,
 //     one workgroup per CU, that draw unit numbers from a counter; results go to the unit's own slot, so the order in
@@ -39,7 +39,9 @@ constexpr int kRing = 4;                       // LDS tile buffers
 constexpr int kBufHalfs = kTJ * kPitchH;       // halfs per buffer
 constexpr int kPlanThreads = 1024;             // = the largest number of anchor blocks the plan handles
 constexpr int kMaxChunks = 256;                // units per anchor block and sweep
-constexpr int kTargetUnits = 1024;             // units per sweep the chunk length aims at
+// units per sweep the chunk length aims at: two per CU.  Measured (tools/pixcon_bench.py f16 dom, B = 24 at 513^2): 256 units
+// 1.95 ms, 384 1.63, 512 1.52, 1024 1.55, 2048 1.67 - fewer units balance worse, more units write and re-read more partials
+constexpr int kTargetUnits = 512;
 constexpr int kMinChunk = 8;
 
 struct PlanHdr {
