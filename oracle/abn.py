@@ -20,7 +20,6 @@ sign(w); torch uses 0 at w = 0 where the wheel uses +1 - a measure-zero differen
 """
 from __future__ import annotations
 
-import torch
 import torch.nn.functional as F
 
 

@@ -4,8 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ucd_amd import argparser, synth, tasks
-from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+from ucd_amd import argparser, synth
+from ucd_amd.run import build_models, load_step_checkpoint
 from ucd_amd.train import Trainer
 from oracle import step as OS, model as OM
 from oracle.params import template_state

@@ -3,12 +3,10 @@ product of the same bf16 operands on the device (hipBLASLt / MIOpen are the A/B 
 module paths built on it against the layer-by-layer path and the reference goldens."""
 import os
 
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden
 from ucd_amd import synth
 
 pytestmark = pytest.mark.gpu

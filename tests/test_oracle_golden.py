@@ -6,11 +6,9 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_matches_compact, load_golden, sample_idx
+from conftest import assert_matches_compact, load_golden
 from oracle import contrastive as OC
 from oracle import losses as OL
-from oracle import model as OM
-from oracle import step as OS
 from ucd_amd import synth
 
 PIXCON = ["voc_15_5", "city_13_6", "voc_15_5s_step2", "voc_19_1_odd"]

@@ -9,7 +9,6 @@ from conftest import load_golden, sample_idx
 from oracle import model as OM
 from oracle import step as OS
 from ucd_amd import synth
-from ucd_amd.backbone import net_resnet101
 from ucd_amd.blocks import DeeplabV3, ResidualBlock
 from oracle_shims import ShimABN, build_cpu_net
 

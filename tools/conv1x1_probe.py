@@ -3,7 +3,6 @@ against the tuned hipBLASLt entry point it replaces, on the layer shapes of the 
 usage: python tools/conv1x1_probe.py [--quick]"""
 import os
 import sys
-import time
 
 import torch
 import torch.nn.functional as F

@@ -1,7 +1,7 @@
 """GPU micro-benchmark of the contrastive loss kernels at the SURVEY 8-d micro-shapes.
 usage: python tools/pixcon_bench.py [f16|f16_split|f32] [dom]   (cfg2: BHW=26136; "dom": one teacher class dominates, like the
 benchmark step / a trained teacher - 2/3 of the pairs are positives)"""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ucd_amd import synth

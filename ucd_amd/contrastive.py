@@ -15,7 +15,6 @@ allocates worst-case buffers (A <= BHW, C <= 2 BHW) - there is no ``.cpu()`` rou
 """
 from __future__ import annotations
 
-import ctypes as C
 import weakref
 
 import torch
