@@ -481,6 +481,28 @@ int ucd_flip_weights_batched(const void* src_flat, void* dst_flat, const int* bl
 /* dst[cols, rows] = src[rows, cols]^T (bf16): the [K, N] weight of the input-gradient product. */
 int ucd_transpose_bf16(const void* src, int rows, int cols, void* dst, ucd_stream_t stream);
 
+/* ---- optimiser step -------------------------------------------------------------------------------------------------
+ * Replaces `optim.step()` (train.py:147) of the reference's torch.optim.SGD(params, lr, momentum=0.9, nesterov=True) with
+ * per-group weight decay (run.py:175-186) by ONE launch over every parameter tensor; the bf16 working copy of a
+ * convolution weight (apex AMP O1's per-call cast, run.py:199-200) is written in the same pass.
+ *   g' = g + wd p;  m' = mu m + g';  d = g' + mu m' (nesterov) | m';  p' = p - lr d;  w16 = bf16(p')
+ * (double intermediates like torch's fused kernel; dampening 0; a zero-initialised m makes the first step torch's
+ * "momentum buffer = clone of the gradient").  table [n] (device): one entry per tensor - p, g, m fp32 with identical
+ * dense layouts of n elements, m NULL for momentum 0, w16 NULL or the bf16 copy of the same layout, group = index into
+ * the hyper-parameter arrays.  blocks [n_blocks][2] (device, int32) = {table entry, chunk of ucd_sgd_chunk() elements}. */
+#define UCD_SGD_MAX_GROUPS 8
+typedef struct ucd_sgd_tensor {
+  float* p;  const float* g;  float* m;  void* w16;
+  long long n;
+  int group;  int pad;
+} ucd_sgd_tensor;
+typedef struct ucd_sgd_hyper {
+  double lr[UCD_SGD_MAX_GROUPS], momentum[UCD_SGD_MAX_GROUPS], weight_decay[UCD_SGD_MAX_GROUPS];
+  int nesterov[UCD_SGD_MAX_GROUPS];
+} ucd_sgd_hyper;
+int ucd_sgd_chunk(void);
+int ucd_sgd_step(const ucd_sgd_tensor* table, const int* blocks, int n_blocks, const ucd_sgd_hyper* hyper, ucd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

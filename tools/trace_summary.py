@@ -11,7 +11,7 @@ def short(n):
     if "ucd" in n and ("N_1" in n or "ucd::" in n):
         m = re.search(r"(pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|plane_sum_kernel|prep_\w+kernel|"
                       r"gather_normalize_kernel|scatter_grad_kernel|seg_losses\w*kernel|attmap\w+|conv1x1_kernel<[^>]*>|conv1x1_wgrad_kernel|"
-                      r"tile_stats_reduce_kernel|window_\w+kernel|flip_weights_kernel|transpose_bf16_kernel|wgrad_reduce_kernel)", n)
+                      r"tile_stats_reduce_kernel|window_\w+kernel|flip_weights_kernel|transpose_bf16_kernel|wgrad_reduce_kernel|sgd_step_kernel)", n)
         t = "<bf16>" if "bfloat16" in n else ("<f32>" if "<float" in n or "IfE" in n else "")
         return "UCD   " + (m.group(1) if m else n[:60]) + t
     if "at::native" in n:

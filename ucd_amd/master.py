@@ -17,9 +17,23 @@ import weakref
 
 import torch
 from torch.optim.optimizer import register_optimizer_step_post_hook
+from torch.utils.weak import WeakTensorKeyDictionary
 
 from .blocks import Conv2d
 from .ddp import _view_like
+
+
+# fp32 master parameter -> (bf16 working copy, weakref to the Bf16Weights that owns it): how the one-launch optimiser step
+# (ucd_amd/optim.py) finds the copy it writes together with the master
+_WORKING = WeakTensorKeyDictionary()       # keyed by identity (a plain WeakKeyDictionary would compare tensors with ==)
+
+
+def working_copy(param):
+    """(bf16 working copy, weakref to its owner) of a trainable master weight, or (None, None)."""
+    hit = _WORKING.get(param)
+    if hit is None or hit[1]() is None:
+        return None, None
+    return hit
 
 
 class Bf16Weights:
@@ -48,17 +62,24 @@ class Bf16Weights:
                     s.requires_grad_(True)
                 m._w16 = s
                 self.shadow_of[w] = s
+                if trainable:
+                    _WORKING[w] = (s, weakref.ref(self))
                 off += n
         self._build_flip_table()
         self._seen = None
         self._dirty = True
+        self._flips_dirty = False
         # fused optimisers update the weights without bumping their version counters, so any optimiser step marks
         # the working copies stale; plain in-place writes (load_state_dict, broadcast) are seen through the versions
         ref = weakref.ref(self)
 
         def _after_step(optimizer, args, kwargs):
             me = ref()
-            if me is not None:
+            if me is None:
+                return
+            if any(o is me for o in getattr(optimizer, "refreshed_working_sets", ())):
+                me._flips_dirty = True      # ucd_amd.optim.SGD wrote the bf16 copies in its own pass: only the flipped set is stale
+            else:
                 me._dirty = True
         # frozen copies (the teacher) are not touched by any optimiser: no hook, the version counters (load_state_dict,
         # copy_) and mark_stale() are what invalidates them - otherwise every student step would re-cast the teacher
@@ -131,3 +152,8 @@ class Bf16Weights:
                 self._refresh_flips()
             self._seen = v
             self._dirty = False
+            self._flips_dirty = False
+        elif self._flips_dirty:
+            with torch.no_grad():
+                self._refresh_flips()
+            self._flips_dirty = False

@@ -42,6 +42,11 @@ def make_optimizer(opts, model):
         groups.append({"params": [p for p in net.body.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
     groups.append({"params": [p for p in net.head.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
     groups.append({"params": [p for p in net.cls.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
+    if next(net.parameters()).is_cuda and os.environ.get("UCD_SGD", "torch") == "hip":
+        # the same class surface, the step as one launch (csrc/sgd.hip).  Opt-in for now: its kernel and the bf16 hand-over
+        # are parity-tested (tests/test_optim.py), the whole GPU suite has not yet run with it as the default
+        from .optim import SGD
+        return SGD(groups, lr=opts.lr, momentum=0.9, nesterov=True)
     kw = {"fused": True} if next(net.parameters()).is_cuda else {}
     return torch.optim.SGD(groups, lr=opts.lr, momentum=0.9, nesterov=True, **kw)
 
