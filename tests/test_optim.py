@@ -47,6 +47,27 @@ def test_no_cpu_path():
         optim.SGD([p], lr=0.1, maximize=True)
 
 
+def test_float64_rule_is_torch_sgd():
+    """The rule the kernel is held to bit-exactly (``_reference_step`` below) IS torch.optim.SGD's update (the optimiser of
+    run.py:175-186) up to fp32 rounding of intermediates - checked on the CPU over several steps, groups and a PolyLR-like lr."""
+    torch.manual_seed(0)
+    for mu, nesterov, wd in ((0.9, True, 1e-4), (0.9, False, 0.0), (0.0, False, 5e-4)):
+        p = torch.randn(3000)
+        m = torch.zeros(3000)
+        q = torch.nn.Parameter(p.clone())
+        opt = torch.optim.SGD([q], lr=0.05, momentum=mu, nesterov=nesterov, weight_decay=wd)
+        for step in range(5):
+            lr = 0.05 * (1 - step / 10) ** 0.9
+            opt.param_groups[0]["lr"] = lr
+            g = torch.randn(3000)
+            q.grad = g.clone()
+            opt.step()
+            p, m = _reference_step(p, g, m, lr, mu, wd, nesterov)
+            torch.testing.assert_close(p, q.detach(), rtol=2e-6, atol=2e-6)
+            if mu != 0:
+                torch.testing.assert_close(m, opt.state[q]["momentum_buffer"], rtol=2e-6, atol=2e-6)
+
+
 # ---- GPU -------------------------------------------------------------------------------------------------------------
 
 def _params(dev, seed=0):
