@@ -166,7 +166,6 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 
     // visible after the first barrier of the K loop (the A commit that reads them comes after the global loads)
     __syncthreads();
   }
-  const unsigned char* afrag = As + 0;                 // fragment bases resolved per read (swizzled)
   const int fr = lane & 31, fh = lane >> 5;
   const int kpt = p.K / kBK;                           // K steps per tap
   const int nk = CONV3 ? 9 * kpt : kpt;
