@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle.optim import poly_lr, sgd_step as _reference_step
 from ucd_amd import hip, optim
 
 
@@ -48,7 +49,7 @@ def test_no_cpu_path():
 
 
 def test_float64_rule_is_torch_sgd():
-    """The rule the kernel is held to bit-exactly (``_reference_step`` below) IS torch.optim.SGD's update (the optimiser of
+    """The rule the kernel is held to bit-exactly (``oracle.optim.sgd_step``) IS torch.optim.SGD's update (the optimiser of
     run.py:175-186) up to fp32 rounding of intermediates - checked on the CPU over several steps, groups and a PolyLR-like lr."""
     torch.manual_seed(0)
     for mu, nesterov, wd in ((0.9, True, 1e-4), (0.9, False, 0.0), (0.0, False, 5e-4)):
@@ -57,7 +58,7 @@ def test_float64_rule_is_torch_sgd():
         q = torch.nn.Parameter(p.clone())
         opt = torch.optim.SGD([q], lr=0.05, momentum=mu, nesterov=nesterov, weight_decay=wd)
         for step in range(5):
-            lr = 0.05 * (1 - step / 10) ** 0.9
+            lr = poly_lr(0.05, step, 10)
             opt.param_groups[0]["lr"] = lr
             g = torch.randn(3000)
             q.grad = g.clone()
@@ -66,6 +67,17 @@ def test_float64_rule_is_torch_sgd():
             torch.testing.assert_close(p, q.detach(), rtol=2e-6, atol=2e-6)
             if mu != 0:
                 torch.testing.assert_close(m, opt.state[q]["momentum_buffer"], rtol=2e-6, atol=2e-6)
+
+
+def test_poly_lr_restatement_is_the_scheduler():
+    from ucd_amd.scheduler import PolyLR
+    q = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([q], lr=0.01)
+    sched = PolyLR(opt, max_iters=30, power=0.9)
+    for it in range(1, 30):
+        opt.step()
+        sched.step()
+        assert opt.param_groups[0]["lr"] == pytest.approx(poly_lr(0.01, it, 30), rel=1e-12)
 
 
 # ---- GPU -------------------------------------------------------------------------------------------------------------
@@ -89,18 +101,6 @@ def _odd_views(flat):
     return [flat[1:101], flat[101:104], flat[105:105 + 4099]]
 
 
-def _reference_step(p, g, m, lr, mu, wd, nesterov):
-    """The update rule in float64 with the kernel's rounding points (csrc/sgd.hip)."""
-    g1 = (g.double() + wd * p.double()).float() if wd != 0 else g
-    if mu != 0:
-        mb = mu * m.double() + g1.double()
-        m_new = mb.float()
-        g2 = (g1.double() + mu * mb).float() if nesterov else m_new
-    else:
-        m_new, g2 = m, g1
-    return (p.double() - lr * g2.double()).float(), m_new
-
-
 @pytest.mark.gpu
 def test_step_is_bit_exact_against_the_float64_rule_and_close_to_torch():
     dev = torch.device("cuda:0")
@@ -122,7 +122,7 @@ def test_step_is_bit_exact_against_the_float64_rule_and_close_to_torch():
     state_m = [[torch.zeros_like(t) for t in part] for part in mine_p]
     gen = torch.Generator(device="cpu").manual_seed(1)
     for step in range(4):
-        lr = 0.05 * (1 - step / 10) ** 0.9
+        lr = poly_lr(0.05, step, 10)
         for opt in (mine, ref):
             for grp in opt.param_groups:
                 grp["lr"] = lr
