@@ -4,6 +4,8 @@ cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/gputests.log
 python bench.py --steps 20 --warmup 5 > $O/bench_final.json 2> $O/bench_final.err
 for gb in 12 6 3; do python bench.py --steps 10 --warmup 3 --global_batch $gb --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('global_batch', $gb, 'ms_per_step', round(d['ms_per_step'],2), 'img/s', round(d['value'],1))"; done > $O/small_batch.txt 2>&1
+# optimiser step A/B on this box: torch's fused step vs the one-launch step (csrc/sgd.hip), benchmark batch and the 8-GPU per-rank batch
+(for mode in torch hip; do for gb in 24 3; do UCD_SGD=$mode timeout 120 python bench.py --steps 12 --warmup 4 --global_batch $gb --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('UCD_SGD=$mode', 'global_batch', $gb, 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))"; done; done) > $O/sgd_ab.txt 2>&1
 timeout 300 python tools/conv1x1_probe.py > $O/conv1x1_probe.txt 2>&1
 timeout 300 python tools/conv3x3_probe.py > $O/conv3x3_probe.txt 2>&1
 timeout 120 python tools/pixcon_pairs.py > $O/pixcon_pairs.txt 2>&1
@@ -51,4 +53,5 @@ for name, cs in agg.items():
         print("   mfma busy / (4 * wave quad-cycles) = %.3f   lds conflict / lds active = %.3f" % (m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4 * m["SQ_WAVE_CYCLES"]), m.get("SQ_LDS_BANK_CONFLICT", 0) / max(1.0, m.get("SQ_LDS_IDX_ACTIVE", 1))))
 PY
 done
-cd $R; cat $O/gputests.log; cut -c1-250 $O/bench_final.json; cat $O/small_batch.txt; head -8 $O/step_kernel_summary_final.txt; head -5 $O/step_kernel_summary_b3.txt; cat $O/pmc_bench.txt | head -30; cat $O/pixcon_sq.txt | head -40
+python tools/kernel_resources.py > $O/kernel_resources.txt 2>&1
+cd $R; cat $O/gputests.log; cat $O/sgd_ab.txt; cut -c1-250 $O/bench_final.json; cat $O/small_batch.txt; head -8 $O/step_kernel_summary_final.txt; head -5 $O/step_kernel_summary_b3.txt; cat $O/pmc_bench.txt | head -30; cat $O/pixcon_sq.txt | head -40
