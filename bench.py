@@ -32,15 +32,18 @@ def _seed_miopen_user_db():
     src = os.path.join(ROOT, "ucd_amd", "tuning", "miopen")
     if not os.path.isdir(src):
         return
+    import atexit
     import shutil
     import tempfile
     dst = tempfile.mkdtemp(prefix="ucd_miopen_db_")
     for name in os.listdir(src):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
     os.environ["MIOPEN_USER_DB_PATH"] = dst
+    atexit.register(shutil.rmtree, dst, True)      # a private copy per process (ranks must not share a writable db): removed at exit
 
 
-_seed_miopen_user_db()          # before torch / MIOpen load
+if __name__ == "__main__" or os.environ.get("UCD_MIOPEN_SEED"):
+    _seed_miopen_user_db()      # before torch / MIOpen load; the tools that import this module keep their own environment
 
 import torch
 import torch.distributed as dist

@@ -204,14 +204,14 @@ def test_step_writes_the_bf16_working_copies():
 
 
 @pytest.mark.gpu
-def test_launcher_selects_the_hip_step_on_request(monkeypatch):
+def test_launcher_builds_the_hip_step_by_default(monkeypatch):
     from ucd_amd import argparser, tasks
     from ucd_amd.run import build_models, make_optimizer
     opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
         ["--method", "UCD", "--task", "15-5", "--step", "0", "--no_pretrained"]))
     model = build_models(opts, torch.device("cuda:0"), tasks.get_per_task_classes("voc", "15-5", 0))[0]
-    monkeypatch.setenv("UCD_SGD", "hip")
-    opt = make_optimizer(opts, model)
-    assert isinstance(opt, optim.SGD) and len(opt.param_groups) == 3
     monkeypatch.delenv("UCD_SGD", raising=False)
-    assert type(make_optimizer(opts, model)) is torch.optim.SGD
+    opt = make_optimizer(opts, model)
+    assert isinstance(opt, optim.SGD) and len(opt.param_groups) == 3       # the one-launch step is what run.py:175-186 builds
+    monkeypatch.setenv("UCD_SGD", "torch")
+    assert type(make_optimizer(opts, model)) is torch.optim.SGD             # the A/B reference

@@ -368,7 +368,7 @@ class _ConvABNFunction(torch.autograd.Function):
         ctx.cfg = (act, slope, residual is not None)
         if make_link and residual is None and bias is not None:
             partial = torch.empty(hip.conv1x1_row_tiles(M), 2, N, dtype=torch.float32, device=x.device)
-            ctx.my_link = (partial, [0])
+            ctx.my_link = (partial, [0, 0])      # {served, address of the consumer's dx} (see ConvABNTrainNode::backward)
             y._ucd_link = (z, buf, bias, partial, ctx.my_link[1], act, slope)
         return y
 
@@ -381,6 +381,11 @@ class _ConvABNFunction(torch.autograd.Function):
         N = w4.shape[0]
         M, HW = B * H * W, H * W
         rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0] * t.shape[2] * t.shape[3], t.shape[1])
+        if ctx.my_link is not None and ctx.my_link[1][0] == 1 and dy.data_ptr() != ctx.my_link[1][1]:
+            ctx.my_link[1][0] = 0
+            raise RuntimeError("ucd conv+abn node: the backward link was served but the gradient that arrived is not the consumer's "
+                               "input gradient - the linked map has a second consumer (hook, ret_intermediate tap, retain_graph "
+                               "replay).  Run with UCD_BWD_LINK=0.")
         dy, _, _, _, _ = hip.rows_view(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         dz = torch.empty_like(z)
         dres = torch.empty_like(z) if has_res else None
@@ -399,10 +404,11 @@ class _ConvABNFunction(torch.autograd.Function):
         dilation, wflip, own_dgrad, wgrad_conv = ctx.conv3
         link = ctx.link
 
-        def link_args():       # out_mode 3 against the producer's statistics; marks the link as served
+        def link_args(dx):     # out_mode 3 against the producer's statistics; marks the link as served (for THIS dx)
             lz, lbuf, lbias, lpart, lflag, lact, lslope = link
             C = lz.shape[1]
             lflag[0] = 1
+            lflag[1] = dx.data_ptr()
             return dict(out_mode=3, out_norm=(lbuf[3 * C:4 * C], lbuf[5 * C:], lbias, lbuf[4 * C:5 * C], lact & hip.ACT_MASK, lslope),
                         residual=rows(lz), partial=lpart)
         if dilation > 0:
@@ -413,7 +419,7 @@ class _ConvABNFunction(torch.autograd.Function):
                 if own_dgrad:
                     dx = torch.empty_like(x)
                     hip.conv1x1(rows(dz), wflip.permute(0, 2, 3, 1).reshape(K, 9 * N), rows(dx), conv3=(H, W, dilation),
-                                **(link_args() if link is not None else {}))
+                                **(link_args(dx) if link is not None else {}))
                 else:
                     dx = F.conv2d(dz, wflip, None, 1, dilation, dilation)
             if ctx.needs_input_grad[1]:
@@ -425,7 +431,7 @@ class _ConvABNFunction(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             if own_dgrad and wflip is not None:
-                hip.conv1x1(rows(dz), wflip.reshape(K, N), rows(dx), **(link_args() if link is not None else {}))
+                hip.conv1x1(rows(dz), wflip.reshape(K, N), rows(dx), **(link_args(dx) if link is not None else {}))
             else:
                 hip.gemm_bf16(1, rows(dz), w2, rows(dx))
         if ctx.needs_input_grad[1] and wgrad_conv:

@@ -375,7 +375,11 @@ static void link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& lk_z, const at:
   d.out_act = (int)(ctx->saved_data["lk_act"].toInt() & UCD_ACT_MASK);
   d.out_slope = (float)ctx->saved_data["lk_slope"].toDouble();
   d.partial = lk_partial.data_ptr<float>();
+  // served: the producer's backward may skip its reduction pass - but ONLY for the gradient this product writes.  The address
+  // of that tensor is recorded so the producer can tell "dy is exactly the consumer's dx" from "autograd summed several
+  // contributions" (a second consumer of the producer's output: the derivative would be applied to a part of dy only).
   lk_flag.data_ptr<int64_t>()[0] = 1;
+  lk_flag.data_ptr<int64_t>()[1] = (int64_t)reinterpret_cast<intptr_t>(d.y);
 }
 
 class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
@@ -481,7 +485,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     make_link = make_link && !has_res && bias.defined();
     if (make_link) {
       my_partial = at::empty({(int64_t)ucd_conv1x1_row_tiles((int)M), 2, N}, x.options().dtype(at::kFloat));
-      my_flag = at::zeros({1}, at::TensorOptions().dtype(at::kLong));
+      my_flag = at::zeros({2}, at::TensorOptions().dtype(at::kLong));   // {served, address of the consumer's dx}
     }
     ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf, wflip,
                             consume_link ? lk_z : at::Tensor(), consume_link ? lk_buf : at::Tensor(),
@@ -530,6 +534,19 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     at::Tensor none;
     at::Tensor dx, dw, dweight, dbias, dres;
     at::Tensor dz;   // gradient w.r.t. the convolution output z
+    if (my_flag.defined() && my_flag.data_ptr<int64_t>()[0] == 1) {
+      // the link's promise (one consumer of y) is checked, not trusted: the incoming gradient must be the very tensor the
+      // consumer's input-gradient product wrote.  Anything else (a sum made by the engine, a hook's copy, a stale flag from
+      // a backward pass that stopped short of this node) carries a derivative on part of dy only - wrong gradients, silently.
+      const int64_t want = my_flag.data_ptr<int64_t>()[1];
+      const bool same = dy.defined() && (int64_t)reinterpret_cast<intptr_t>(dy.data_ptr()) == want;
+      if (!same) {
+        my_flag.data_ptr<int64_t>()[0] = 0;
+        TORCH_CHECK(false, "ucd conv+abn node: the backward link was served but the gradient that arrived is not the consumer's "
+                           "input gradient - the linked map has a second consumer (hook, ret_intermediate tap, retain_graph "
+                           "replay).  Run with UCD_BWD_LINK=0.");
+      }
+    }
     if (dy.defined()) {
       if (dy.scalar_type() != at::kBFloat16) dy = dy.to(at::kBFloat16);
       if (!dense_channels_last(dy)) dy = dy.contiguous(at::MemoryFormat::ChannelsLast);

@@ -84,6 +84,16 @@ def filter_images(dataset, labels, labels_old=None, overlap=True):
     return idxs
 
 
+def _save_index_file(path, idxs):
+    """Write an index file atomically: the other ranks of a first multi-rank run test ``os.path.exists`` and ``np.load`` the same
+    path while rank 0 writes it (dataset/voc.py:160-166 has that race); with a temporary file + ``os.replace`` they see either
+    no file (and filter themselves: same list) or the complete one."""
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    tmp = f"{path}.tmp{os.getpid()}.npy"
+    np.save(tmp, np.array(idxs, dtype=int))
+    os.replace(tmp, path)
+
+
 class VOCSegmentationIncremental(data.Dataset):
     """``VOCSegmentationIncremental(root, train, transform, labels, labels_old, idxs_path, masking, overlap, data_masking,
     test_on_val)`` of the reference (dataset/voc.py:124-216).  ``transform`` is accepted and ignored: the transform of a batch
@@ -106,8 +116,7 @@ class VOCSegmentationIncremental(data.Dataset):
             else:
                 idxs = filter_images(full_voc, labels, labels_old, overlap=overlap)
                 if idxs_path is not None and (not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0):
-                    os.makedirs(os.path.dirname(idxs_path) or ".", exist_ok=True)
-                    np.save(idxs_path, np.array(idxs, dtype=int))
+                    _save_index_file(idxs_path, idxs)
             if test_on_val:
                 rnd = np.random.RandomState(1)
                 rnd.shuffle(idxs)

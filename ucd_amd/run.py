@@ -4,8 +4,8 @@ semantics (run.py:175-189) and checkpoint layout (run.py:32-43: ``checkpoints/st
 {name}_{step}.pth`` with keys epoch, model_state [``module.``-prefixed], optimizer_state, scheduler_state,
 best_score, trainer_state).  Data: with a VOC tree under ``--data_root`` (``splits/``, ``JPEGImages/``,
 ``SegmentationClassAug/``) the reference's incremental dataset is used - host decode, batch transform on the device
-(``ucd_amd/dataset.py``); ``--data_root synthetic`` (or a missing data directory) trains on the
-closed-form synthetic batches the benchmark uses.
+(``ucd_amd/dataset.py``); ``--data_root synthetic`` - and only that - trains on the closed-form
+synthetic batches the benchmark uses; a data root without ``splits/`` raises like the reference's dataset classes do.
 """
 from __future__ import annotations
 
@@ -42,9 +42,10 @@ def make_optimizer(opts, model):
         groups.append({"params": [p for p in net.body.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
     groups.append({"params": [p for p in net.head.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
     groups.append({"params": [p for p in net.cls.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
-    if next(net.parameters()).is_cuda and os.environ.get("UCD_SGD", "torch") == "hip":
-        # the same class surface, the step as one launch (csrc/sgd.hip).  Opt-in for now: its kernel and the bf16 hand-over
-        # are parity-tested (tests/test_optim.py), the whole GPU suite has not yet run with it as the default
+    if next(net.parameters()).is_cuda and os.environ.get("UCD_SGD", "hip") != "torch":
+        # a torch.optim.SGD subclass (same groups, state_dict, hooks, schedulers) whose step is ONE launch (csrc/sgd.hip) that
+        # also writes the bf16 working weights; bit-exact against the rule in float64 (tests/test_optim.py).  UCD_SGD=torch
+        # selects torch's fused step (the A/B reference of the tests).
         from .optim import SGD
         return SGD(groups, lr=opts.lr, momentum=0.9, nesterov=True)
     kw = {"fused": True} if next(net.parameters()).is_cuda else {}
@@ -118,7 +119,11 @@ def main(opts):
 
     classes = tasks.get_per_task_classes(opts.dataset, opts.task, opts.step)
     labels, labels_old, _ = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
-    real = opts.data_root != "synthetic" and os.path.isdir(os.path.join(opts.data_root, "splits"))
+    real = opts.data_root != "synthetic"
+    if real and not os.path.isdir(os.path.join(opts.data_root, "splits")):
+        # dataset/voc.py:58-59: a mistyped or unmounted root must not train (and checkpoint) on synthetic batches
+        raise RuntimeError(f"Dataset not found or corrupted. at location = {opts.data_root} (no splits/ directory; pass "
+                           "--data_root synthetic for the closed-form synthetic batches)")
     if real and opts.dataset != "voc":
         raise NotImplementedError("real-data loading is wired for --dataset voc (ucd_amd/dataset.py); ADE20K and Cityscapes "
                                   "share its structure and are not wired - use --data_root synthetic")
