@@ -93,7 +93,7 @@ def build(args, device, per_rank_batch, rank):
     model, model_old = build_models(opts, device, classes)
     # fake step-(k-1) checkpoint: deterministic weights, keys prefixed like a DDP-saved file (run.py:37)
     state = {"module." + k: v for k, v in synth.fill_state_dict(
-        {k: v.cpu() for k, v in model_old.state_dict().items()}, 42).items()}
+        {k: v.cpu() for k, v in model_old.state_dict().items()}, 42, calibrated=True).items()}
     optimizer = make_optimizer(opts, model)
     scheduler = PolyLR(optimizer, max_iters=30 * 2145 // max(1, args.global_batch), power=opts.lr_power)
     model = DistributedDataParallel(model, delay_allreduce=True,

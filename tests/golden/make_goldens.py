@@ -254,8 +254,14 @@ def gold_model():
         out_old, feat_old = teacher(img)
     opt.zero_grad()
     outp, feat = student(img)
-    a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
-                                                     f_o=feat_old["pre_logits"])
+    if max_label is None:
+        a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
+                                                         f_o=feat_old["pre_logits"])
+    else:
+        from oracle import contrastive as OC
+        prep = OC.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), feat_old["sem"], feat_old["pre_logits"],
+                                        max_label=max_label)
+        a, c, la, lc, P = prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"]
     ce = ref_loss.UnbiasedCrossEntropy(old_cl=16, ignore_index=255, reduction="none")(outp, labels.clone()).mean()
     con = ref_loss.PixelConLossV2(temperature=0.07)(a, c, la, lc, P)
     loss = ce + con / 100
@@ -305,7 +311,7 @@ def gold_cfg0():
          **grads, **upd)
 
 
-def _build_pair(models, modules, segm, classes, seed=42):
+def _build_pair(models, modules, segm, classes, seed=42, calibrated=False):
     norm = partial(ShimInPlaceABN, activation="leaky_relu", activation_param=0.01)
 
     def build(cls):
@@ -314,7 +320,7 @@ def _build_pair(models, modules, segm, classes, seed=42):
         return segm.IncrementalSegmentationModule(body, head, 256, classes=cls)
 
     student, teacher = build(classes), build(classes[:-1])
-    sd = synth.fill_state_dict(teacher.state_dict(), seed)
+    sd = synth.fill_state_dict(teacher.state_dict(), seed, calibrated=calibrated)
     teacher.load_state_dict(sd)
     student.load_state_dict(sd, strict=False)
     with torch.no_grad():
@@ -329,8 +335,12 @@ STEP_NAMES = ["body.mod1.conv1.weight", "body.mod3.block2.convs.bn2.weight", "bo
               "head.map_convs.2.weight", "head.red_bn.bias", "head.global_pooling_bn.weight"]
 
 
-def _ucd_step(student, teacher, img, labels, old_cl, extra_names):
-    """train.py:95-151 as intended, through the reference's own classes; returns the golden dict."""
+def _ucd_step(student, teacher, img, labels, old_cl, extra_names, max_label=None):
+    """train.py:95-151 as intended, through the reference's own classes; returns the golden dict.
+    ``max_label``: ADE20K only - the reference's pre_contrastive_pixel zeroes every down-sampled label above the VOC bound 20
+    (utils/utils.py:267-268), so with ADE's new ids 101..150 it has no new pixel and stops at ``min`` of an empty tensor; the
+    prep then comes from oracle/contrastive.py (pinned to the reference's function on the four pixcon_*.npz cases) with the
+    bound generalised, everything else stays the reference's own classes."""
     groups = [{"params": [p for p in m.parameters() if p.requires_grad], "weight_decay": 1e-4}
               for m in (student.body, student.head, student.cls)]
     opt = torch.optim.SGD(groups, lr=1e-3, momentum=0.9, nesterov=True)
@@ -338,8 +348,14 @@ def _ucd_step(student, teacher, img, labels, old_cl, extra_names):
         out_old, feat_old = teacher(img)
     opt.zero_grad()
     outp, feat = student(img)
-    a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
-                                                     f_o=feat_old["pre_logits"])
+    if max_label is None:
+        a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
+                                                         f_o=feat_old["pre_logits"])
+    else:
+        from oracle import contrastive as OC
+        prep = OC.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), feat_old["sem"], feat_old["pre_logits"],
+                                        max_label=max_label)
+        a, c, la, lc, P = prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"]
     ce = ref_loss.UnbiasedCrossEntropy(old_cl=old_cl, ignore_index=255, reduction="none")(outp, labels.clone()).mean()
     con = ref_loss.PixelConLossV2(temperature=0.07)(a, c, la, lc, P)
     loss = ce + con / 100
@@ -373,6 +389,40 @@ def gold_step513():
     save("ucd_step_513.npz", cfg=np.array([502, 2, 513]), **out)
 
 
+def gold_step513_cal():
+    """configs[1] at its real crop with the CALIBRATED synthetic checkpoint (synth.fill_state_dict(calibrated=True): teacher
+    logits of order 10 instead of 1e5) - the golden the bf16 (--opt_level O1, the benchmarked mode) tests are held against."""
+    models, modules, segm = import_reference_model()
+    student, teacher = _build_pair(models, modules, segm, [16, 5], calibrated=True)
+    img = synth.images(502, 2, 513)
+    labels = synth.seg_labels(502, 2, 513, 513, range(16, 21))
+    out = _ucd_step(student, teacher, img, labels, 16, ["cls.1.weight", "cls.1.bias"])
+    save("ucd_step_513_cal.npz", cfg=np.array([502, 2, 513]), **out)
+
+
+def gold_cfg3_ade():
+    """BASELINE.json configs[3] at its PER-RANK shape: ADE20K 100-50 step 1, 3 x 512^2 (24 images on 8 GPUs), 151-class student,
+    K = 101 teacher classes, new ids 101..150; calibrated checkpoint.  See _ucd_step for the one piece the reference cannot run."""
+    models, modules, segm = import_reference_model()
+    student, teacher = _build_pair(models, modules, segm, [101, 50], calibrated=True)
+    img = synth.images(504, 3, 512)
+    labels = synth.seg_labels(504, 3, 512, 512, range(101, 151))
+    out = _ucd_step(student, teacher, img, labels, 101, ["cls.1.weight", "cls.1.bias"], max_label=150)
+    save("ucd_step_ade_512.npz", cfg=np.array([504, 3, 512]), **out)
+
+
+def gold_cfg4_city():
+    """BASELINE.json configs[4] at its PER-RANK shape: Cityscapes 13-6 step 1, 2 x 768^2 (16 images on 8 GPUs), 20-class student,
+    K = 14, new ids 14..19 (within the reference's hard-coded label bound: its own pre_contrastive_pixel runs); the 48 x 48 map
+    exceeds --pooling 32, so the teacher's image pooling slides; calibrated checkpoint."""
+    models, modules, segm = import_reference_model()
+    student, teacher = _build_pair(models, modules, segm, [14, 6], calibrated=True)
+    img = synth.images(505, 2, 768)
+    labels = synth.seg_labels(505, 2, 768, 768, range(14, 20))
+    out = _ucd_step(student, teacher, img, labels, 14, ["cls.1.weight", "cls.1.bias"])
+    save("ucd_step_city_768.npz", cfg=np.array([505, 2, 768]), **out)
+
+
 def gold_heads():
     """BASELINE.json configs[2], a later overlapped step: VOC 15-5s step 3 -> student heads [16, 1, 1, 1], teacher
     [16, 1, 1] (tasks.py:16-29), new class id 18, 2 x 129^2."""
@@ -403,7 +453,8 @@ def gold_aspp_eval():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["pixcon", "logit", "v1", "model", "cfg0", "step513", "heads", "aspp_eval"]
+    which = sys.argv[1:] or ["pixcon", "logit", "v1", "model", "cfg0", "step513", "heads", "aspp_eval", "step513_cal", "cfg3_ade",
+                             "cfg4_city"]
     if "cfg0" in which:
         gold_cfg0()
     if "pixcon" in which:
@@ -418,5 +469,11 @@ if __name__ == "__main__":
         gold_step513()
     if "heads" in which:
         gold_heads()
+    if "step513_cal" in which:
+        gold_step513_cal()
+    if "cfg3_ade" in which:
+        gold_cfg3_ade()
+    if "cfg4_city" in which:
+        gold_cfg4_city()
     if "aspp_eval" in which:
         gold_aspp_eval()

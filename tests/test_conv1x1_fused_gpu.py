@@ -429,3 +429,269 @@ def test_backward_link_moves_the_abn_reduction_into_the_input_gradient_product(c
             assert _rel(a[i], b[i]) < 3e-2, (use_node, i, _rel(a[i], b[i]))
     for i, (a, b) in enumerate(zip(res[(True, "1")], res[(False, "1")])):
         assert _rel(a, b) < 1e-2, i                                       # node and twin agree with the link on
+
+
+@pytest.mark.parametrize("use_node", [True, False])
+def test_backward_link_refuses_a_second_consumer(use_node):
+    """The link's promise - the linked map feeds exactly ONE consumer - is checked at backward time: when the producer's output
+    is read by anything besides the consumer whose input-gradient product served the link, the gradient that arrives is a sum
+    made by the autograd engine, not the consumer's dx, and the producer raises instead of applying a half-activated gradient
+    (hooks, attention taps, retain_graph replays).  C++ node and Python twin."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    from ucd_amd.ddp import DistributedDataParallel
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    node = blocks._gemm_node()
+    if use_node and node is None:
+        pytest.skip("C++ node not built")
+    blk = blocks.ResidualBlock(1024, (256, 256, 1024), norm_act=norm, stride=1, dilation=1)
+    blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+    blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
+    mod = DistributedDataParallel(blk, bf16_weights=True)
+    x = synth.t_normal(9, (24, 1024, 33, 33), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    c = blk.convs
+    blocks._node_cache[0] = node if use_node else None
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h1 = blocks._conv_abn_train(c.conv1, c.bn1, x * 1.0, make_link=True)
+            assert getattr(h1, "_ucd_link", None) is not None
+            h2 = blocks._conv_abn_train(c.conv2, c.bn2, h1, make_link=True)
+            good = h2.float().sum()
+            bad = h2.float().sum() + h1.float().mean()            # h1 gains a second consumer
+        with pytest.raises(RuntimeError, match="second consumer"):
+            bad.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        # the flag was cleared with the error: the same graph without the extra reader is fine afterwards
+        x.grad = None
+        good.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(x.grad.float()).all()
+    finally:
+        blocks._node_cache[0] = node
+        mod.finish_grad_sync()
+
+
+def test_backward_link_parity_through_the_model_with_intermediate_features_read():
+    """UCD_BWD_LINK=0/1 through the whole student with --loss_de on (ret_intermediate: features["body"] and ["pre_logits"] are
+    read by a second loss, train.py:118-121): the link only ever spans maps that stay inside a bottleneck, so the extra readers
+    of the block OUTPUTS do not touch it - same losses, same gradients up to bf16 rounding of one intermediate map."""
+    from ucd_amd import argparser, tasks
+    from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+    from ucd_amd.train import Trainer
+    img = synth.images(511, 2, 257)
+    labels = synth.seg_labels(511, 2, 257, 257, range(16, 21))
+    res = {}
+    torch.backends.cudnn.deterministic = True
+    try:
+        for link in ("1", "0"):
+            os.environ["UCD_BWD_LINK"] = link
+            opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
+                ["--method", "UCD", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained", "--norm_act", "iabn_sync",
+                 "--opt_level", "O1", "--loss_de", "1"]))
+            classes = tasks.get_per_task_classes("voc", "15-5", 1)
+            dev = torch.device(DEV)
+            model, model_old = build_models(opts, dev, classes)
+            state = synth.fill_state_dict({k: v.cpu() for k, v in model_old.state_dict().items()}, 42, calibrated=True)
+            load_step_checkpoint(opts, model, model_old, state, dev)
+            trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+            optim = make_optimizer(opts, model)
+            model.train()
+            r = trainer.train_step(img, labels, optim, None)
+            torch.cuda.synchronize()
+            res[link] = ({k: v.item() for k, v in r.items()},
+                         {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        os.environ.pop("UCD_BWD_LINK", None)
+        torch.backends.cudnn.deterministic = False
+    (la, ga), (lb, gb) = res["1"], res["0"]
+    assert la["lde"] > 0
+    for k in la:
+        assert la[k] == pytest.approx(lb[k], rel=1e-6), k                 # the forward is untouched by the link
+    worst = max(_rel(ga[n], gb[n]) for n in ga if gb[n].abs().max() > 0)
+    assert worst < 5e-2, worst
+
+
+# ---- the benchmark's own layer shapes (B = 24 at 513^2): M = 399 384 (129^2), 101 400 (65^2), 26 136 (33^2) ----------------------
+BENCH_LAYERS = [
+    # M, K, N, (H, W, dilation) or None
+    (399384, 64, 256, None), (399384, 256, 64, None), (399384, 64, 64, (129, 129, 1)),          # mod2: 3121 row tiles
+    (101400, 512, 128, None), (101400, 128, 512, None), (101400, 128, 128, (65, 65, 1)),        # mod3
+    (26136, 1024, 256, None), (26136, 256, 1024, None), (26136, 256, 256, (33, 33, 1)),         # mod4
+    (26136, 2048, 512, None), (26136, 512, 512, (33, 33, 2)), (26136, 2048, 256, (33, 33, 12)),  # mod5, an ASPP branch
+]
+
+
+def _conv3x3_rows_fp32(a, w9, B, H, W, d):
+    """Exact fp32 reference of the 3x3 (padding = dilation d) on a row matrix: nine shifted products (plain matmuls only: no
+    library convolution whose transform might not be exact on integers).  ``w9`` [N, 9 K] in (kh, kw, k) order."""
+    M, K = a.shape
+    N = w9.shape[0]
+    x = a.float().view(B, H, W, K)
+    xp = F.pad(x, (0, 0, d, d, d, d))
+    out = torch.zeros(M, N, device=a.device)
+    for kh in range(3):
+        for kw in range(3):
+            sl = xp[:, kh * d:kh * d + H, kw * d:kw * d + W, :].reshape(M, K)
+            out += sl @ w9[:, (kh * 3 + kw) * K:(kh * 3 + kw + 1) * K].float().t()
+    return out
+
+
+@pytest.mark.parametrize("M,K,N,sp", BENCH_LAYERS)
+def test_bench_shape_products_are_exact_on_integers_and_statistics_hold(M, K, N, sp):
+    """Every product form the benchmark step launches, AT the benchmark's row counts (the XCD-aware tile mapping with 3121 /
+    793 / 205 row tiles, the clamped last tile, the double-buffered and single-stage forms the host picks per grid): sparse
+    small-integer operands make every output an exactly representable integer, so the comparison is bit-exact; then the
+    statistics epilogue + finalize and the activation-backward epilogue + partial reduction against torch on the stored map."""
+    from ucd_amd import hip
+    g = torch.Generator(DEV).manual_seed(M + K + N)
+    taps = 9 if sp else 1
+    dens = min(0.5, 24.0 / (K * taps))                      # ~24 non-zero products per output: |sum| stays far below 256
+    ai = (torch.randint(-1, 2, (M, K), device=DEV, generator=g) * (torch.rand(M, K, device=DEV, generator=g) < dens ** 0.5)).bfloat16()
+    wi = (torch.randint(-2, 3, (N, taps * K), device=DEV, generator=g) * (torch.rand(N, taps * K, device=DEV, generator=g) < dens ** 0.5)).bfloat16()
+    y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    if sp:
+        H, W, d = sp
+        B = M // (H * W)
+        hip.conv1x1(ai, wi, y, conv3=(H, W, d))
+        exact = _conv3x3_rows_fp32(ai, wi, B, H, W, d)
+    else:
+        hip.conv1x1(ai, wi, y)
+        exact = ai.float() @ wi.float().t()
+    assert exact.abs().max().item() <= 256
+    assert torch.equal(y.float(), exact)
+    # statistics epilogue (out_mode 2) on real-valued operands: the stored map's mean / variance
+    a = (torch.randn(M, K, device=DEV, generator=g) * 1.3 + 0.2).bfloat16()
+    w = (torch.randn(N, taps * K, device=DEV, generator=g) * (2.0 / (K * taps)) ** 0.5).bfloat16()
+    part = hip.conv1x1_stats_partial(M, N, DEV).fill_(float("nan"))
+    hip.conv1x1(a, w, y, out_mode=2, partial=part, conv3=sp)
+    ref = _conv3x3_rows_fp32(a, w, M // (sp[0] * sp[1]), *sp) if sp else a.float() @ w.float().t()
+    assert _rel(y, ref) < 3e-3
+    buf = torch.zeros(6 * N, device=DEV)
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    gamma = torch.rand(N, device=DEV, generator=g) + 0.5
+    hip._check(hip.load().ucd_conv1x1_stats_finalize(hip.ptr(part), M, N, hip.ptr(gamma), hip.ptr(rm), hip.ptr(rv), 0.1, 1e-5,
+                                                     hip.ptr(buf), None, hip.NORM_ABS_GAMMA, hip.stream()), "finalize")
+    yf = y.double()
+    mean, var = yf.mean(0), yf.var(0, unbiased=False)
+    torch.testing.assert_close(buf[3 * N:4 * N].double(), mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(buf[4 * N:5 * N].double(), 1 / torch.sqrt(var + 1e-5), rtol=1e-4, atol=1e-6)
+    # activation-backward epilogue (out_mode 3) + partial reduction: dz and its two sums
+    r = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    om, osc, osh, oinv = (torch.randn(N, device=DEV, generator=g) * 0.3, torch.rand(N, device=DEV, generator=g) + 0.5,
+                          torch.randn(N, device=DEV, generator=g) * 0.2, torch.rand(N, device=DEV, generator=g) + 0.5)
+    tiles = hip.load().ucd_conv1x1_row_tiles(M)
+    part2 = torch.full((tiles, 2, N), float("nan"), device=DEV)
+    hip.conv1x1(a, w, y, out_mode=3, out_norm=(om, osc, osh, oinv, hip.ACT_LEAKY_RELU, 0.01), residual=r, partial=part2, conv3=sp)
+    z = (r.float() - om) * osc + osh
+    assert _rel(y, ref * torch.where(z > 0, 1.0, 0.01)) < 3e-3
+    sums = torch.zeros(2 * N, device=DEV)
+    hip._check(hip.load().ucd_abn_reduce_partials(hip.ptr(part2), tiles, N, hip.ptr(sums), None, hip.ptr(gamma),
+                                                  hip.NORM_ABS_GAMMA, hip.stream()), "reduce")
+    dz = y.double()
+    torch.testing.assert_close(sums[:N].double(), dz.sum(0), rtol=2e-4, atol=2e-2)
+    torch.testing.assert_close(sums[N:].double(), (dz * ((r.double() - om) * oinv)).sum(0), rtol=2e-4, atol=5e-2)
+
+
+def _worst_param_grad(gf, g32):
+    """Largest relative L2 over the parameter gradients that ARE gradients: behind a batch-statistics norm the gradient of a
+    per-channel shift is zero in exact arithmetic (bn1 / bn2 biases in an identity-activation chain), and a relative error on
+    rounding noise says nothing - parameters whose fp32 gradient is below 1e-3 of the largest (rms) are left out."""
+    rms = {n: g32[n].pow(2).mean().sqrt().item() for n in g32}
+    top = max(rms.values())
+    return max(_rel(gf[n], g32[n]) for n in gf if rms[n] > 1e-3 * top)
+
+
+@pytest.mark.parametrize("slope", [1.0, 0.01])
+@pytest.mark.parametrize("cin,chans,dil,hw", [(256, (64, 64, 256), 1, 129), (512, (128, 128, 512), 1, 65), (1024, (256, 256, 1024), 1, 33),
+                                              (2048, (512, 512, 2048), 2, 33)])
+def test_bench_shape_block_chain_fused_against_fp32_layer_by_layer(cin, chans, dil, hw, slope):
+    """One identity-shortcut bottleneck of mod2 / mod3 / mod4 / mod5 at the benchmark's batch (B = 24: M = 399 384 / 101 400 /
+    26 136) as the chain of conv+ABN nodes the benchmark step runs (statistics epilogues, backward links, shortcut fold, weight
+    gradients) against the SAME block run layer by layer in fp32 - held directly, not relative to another bf16 path.
+    slope = 1 (leaky_relu(1.0) = identity through the same kernels): the arithmetic of the chain alone - output, input gradient
+    and every parameter gradient within 1e-2 / 2.5e-2 in relative L2 (each stored map carries one bf16 rounding, 2^-9).
+    slope = 0.01 (the network's): a stored map's rounding flips the leaky-ReLU branch of the elements nearest zero - a fraction
+    p ~ 0.8 * 2^-9 = 1.6e-3 of them per activation, each with a 99 % error on its gradient, i.e. sqrt(3 p) ~ 7 % in relative L2
+    on the input gradient of a three-activation block for ANY bf16 implementation (measured 7.0-7.1 % on all four shapes, the
+    library-kernel path the same).  Asserted: L2 below 0.1 - the slope-1 run is what holds the kernels' arithmetic tightly."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    from ucd_amd.ddp import DistributedDataParallel
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=slope)
+    B = 24
+    x0 = synth.t_normal(9, (B, cin, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(10, (B, chans[2], hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for mode in ("fused", "fp32"):
+        blk = blocks.ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=dil)
+        blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
+        blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
+        if mode == "fp32":
+            x = x0.float().clone().requires_grad_(True)
+            y = blk(x * 1.0)
+            y.backward(dy.float())
+        else:
+            mod = DistributedDataParallel(blk, bf16_weights=True)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = mod(x * 1.0)
+            y.backward(dy)
+            mod.finish_grad_sync()
+        outs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in blk.named_parameters()},
+                     blk.convs.bn2.running_var.clone(), blk.convs.bn3.running_mean.clone()))
+        del blk, x, y
+        torch.cuda.empty_cache()
+    (yf, gxf, gf, rvf, rmf), (y32, gx32, g32, rv32, rm32) = outs
+    worst = _worst_param_grad(gf, g32)
+    l2 = _rel(gxf, gx32)
+    print("bench-shape chain", cin, chans, hw, "slope", slope, "y", _rel(yf, y32), "dx", l2, "worst param grad", worst)
+    assert _rel(yf, y32) < 1e-2
+    torch.testing.assert_close(rvf, rv32, rtol=5e-3, atol=1e-5)
+    torch.testing.assert_close(rmf, rm32, rtol=5e-3, atol=2e-3)
+    if slope == 1.0:
+        assert l2 < 1e-2
+        assert worst < 2.5e-2, worst          # measured 1.0-2.0e-2 (the largest on a norm scale's gradient: a sum of M = 4e5 products)
+    else:
+        assert l2 < 0.1, l2
+        assert worst < 0.13, worst
+
+
+@pytest.mark.parametrize("slope", [1.0, 0.01])
+def test_bench_shape_aspp_head_fused_against_fp32(slope):
+    """DeeplabV3 in training mode at the benchmark's shape (B = 24, 2048 x 33 x 33): four branches on the own kernels (1x1 and
+    three dilated 3x3 implicit GEMMs), map_bn over channel slices, red_conv + statistics, the pooled branch as a plane bias -
+    against the fp32 run of the same module; slopes as in the block test (two activations here: sqrt(2 p) ~ 6 %)."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    from ucd_amd.ddp import DistributedDataParallel
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=slope)
+    B, C, hw = 24, 2048, 33
+    x0 = synth.t_normal(19, (B, C, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(20, (B, 256, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    outs = []
+    for mode in ("fused", "fp32"):
+        head = blocks.DeeplabV3(C, 256, 256, norm_act=norm, out_stride=16, pooling_size=32)
+        head.load_state_dict(synth.fill_state_dict(head.state_dict(), 21))
+        head = head.to(DEV).to(memory_format=torch.channels_last).train()
+        if mode == "fp32":
+            x = x0.float().clone().requires_grad_(True)
+            y = head(x * 1.0)
+            y.backward(dy.float())
+        else:
+            mod = DistributedDataParallel(head, bf16_weights=True)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = mod(x * 1.0)
+            y.backward(dy)
+            mod.finish_grad_sync()
+        outs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in head.named_parameters()}))
+    (yf, gxf, gf), (y32, gx32, g32) = outs
+    worst = _worst_param_grad(gf, g32)
+    l2 = _rel(gxf, gx32)
+    print("bench-shape ASPP slope", slope, "y", _rel(yf, y32), "dx", l2, "worst param grad", worst)
+    assert _rel(yf, y32) < 1e-2
+    if slope == 1.0:
+        assert l2 < 1e-2 and worst < 1.5e-2, (l2, worst)
+    else:
+        assert l2 < 0.1 and worst < 0.1, (l2, worst)

@@ -36,11 +36,11 @@ def test_blocks_and_head_match_reference():
     np.testing.assert_allclose(OM.deeplab_head(xh, Ph, False, pooling_size=4).numpy(), g["head_eval"], rtol=1e-5, atol=1e-5)
 
 
-def _student_teacher_params(seed=42, classes=(16, 5)):
+def _student_teacher_params(seed=42, classes=(16, 5), calibrated=False):
     classes = list(classes)
     teacher = build_cpu_net(classes[:-1])
     student = build_cpu_net(classes)
-    sd = synth.fill_state_dict(teacher.state_dict(), seed)
+    sd = synth.fill_state_dict(teacher.state_dict(), seed, calibrated=calibrated)
     Pt = OS.make_params(sd, requires_grad=False)
     st = {k: v.clone() for k, v in student.state_dict().items()}
     st.update({k: v.clone() for k, v in sd.items()})
@@ -150,6 +150,23 @@ def test_ucd_step_multi_head_15_5s_step3_matches_reference():
     img = synth.images(503, 2, 129)
     labels = synth.seg_labels(503, 2, 129, 129, [18])
     r = OS.ucd_losses(Ps, Pt, img, labels, [16, 1, 1, 1])
+    _check_step_golden(g, r, Ps)
+
+
+@pytest.mark.parametrize("gname,classes,new_ids,max_label", [
+    ("ucd_step_513_cal.npz", (16, 5), range(16, 21), 20),            # configs[1], calibrated checkpoint (the bf16 tests' golden)
+    ("ucd_step_ade_512.npz", (101, 50), range(101, 151), 150),       # configs[3] per-rank shape: 3 x 512^2, 151 classes, K = 101
+    ("ucd_step_city_768.npz", (14, 6), range(14, 20), 20)])          # configs[4] per-rank shape: 2 x 768^2, 48 x 48 maps
+def test_whole_steps_of_the_other_configs_match_reference(gname, classes, new_ids, max_label):
+    """The oracle's whole UCD step against goldens captured through the reference's classes at the per-rank shapes of the 8-GPU
+    configurations, from the calibrated synthetic checkpoint (tests/golden/make_goldens.py::gold_step513_cal / gold_cfg3_ade /
+    gold_cfg4_city)."""
+    g = load_golden(gname)
+    seed, B, S = [int(v) for v in g["cfg"]]
+    Ps, Pt = _student_teacher_params(classes=classes, calibrated=True)
+    img = synth.images(seed, B, S)
+    labels = synth.seg_labels(seed, B, S, S, new_ids)
+    r = OS.ucd_losses(Ps, Pt, img, labels, list(classes), max_label=max_label)
     _check_step_golden(g, r, Ps)
 
 

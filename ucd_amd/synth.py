@@ -96,11 +96,21 @@ def images(seed: int, B: int, S: int) -> torch.Tensor:
     return t_normal(seed, (B, 3, S, S), stream=5)
 
 
-def fill_state_dict(state: dict, seed: int = 42) -> dict:
+CAL_BN3 = 0.1       # see fill_state_dict(calibrated=True)
+CAL_CLS = 1.0
+
+
+def fill_state_dict(state: dict, seed: int = 42, calibrated: bool = False) -> dict:
     """Deterministic stand-in for a trained checkpoint (there is no network for the real
     ``pretrained/resnet101_iabn_sync.pth.tar``): He-scaled conv weights, norm scales near 1 (positive,
     as in the pretrained ABN files), small biases / running means, running variances near 1.  Values
-    depend only on (seed, key name, shape) - not on which other keys are present."""
+    depend only on (seed, key name, shape) - not on which other keys are present.
+
+    ``calibrated``: the same values with the scale of every block's LAST norm (``convs.bn3.weight``: the one in front of the
+    residual sum) multiplied by ``CAL_BN3`` and the classifier rows by ``CAL_CLS``.  With unit scales everywhere the residual stream of the frozen,
+    evaluation-mode teacher doubles its variance in each of the 33 blocks - logits of 1e5 that turn every rounding difference
+    into percent on the losses - whereas a trained ``iabn_sync`` checkpoint keeps evaluation activations O(1).
+    The calibrated fill has teacher logits of order 10 and is what the bf16 (--opt_level O1) tests are held against."""
     import zlib
     out = {}
     for k in sorted(state):
@@ -117,8 +127,12 @@ def fill_state_dict(state: dict, seed: int = 42) -> dict:
             z = 0.1 * z
         elif v.dim() == 4:                       # conv weight [out, in, kh, kw]
             z = z * (2.0 / (shp[1] * shp[2] * shp[3])) ** 0.5
+            if calibrated and ".cls." in "." + k:
+                z = z * CAL_CLS
         elif k.endswith("weight"):               # norm scale
             z = 1.0 + 0.1 * z
+            if calibrated and k.endswith("convs.bn3.weight"):
+                z = z * CAL_BN3
         else:                                    # biases
             z = 0.1 * z
         out[k] = torch.from_numpy(np.asarray(z, dtype=np.float32)).to(v.dtype)
