@@ -421,6 +421,12 @@ int ucd_image_path(const uint8_t* const* src, const int* desc, int B, int S, int
  *               x = residual[m, n] (its pre-norm input), z = (x - out_mean) * out_scale + out_shift:
  *               y = dz = acc * act_out'(z) and partial[t][0..1][n] = (sum dz, sum dz * (x - out_mean) * out_invstd): input
  *               of ucd_abn_reduce_partials (that ABN's backward reduction)
+ *            4  (1x1 only) acc (+ y when accumulate != 0: the identity shortcut's gradient) is the gradient w.r.t. the
+ *               OUTPUT out = act(norm(z) + shortcut) of the residual block in front (modules/residual.py:84-97): with
+ *               residual = out (the sign of the activation) and side2 = z: y = d pre = (acc + y) * act_out'(out) and
+ *               partial[t][0..1][n] = (sum d pre, sum d pre * (z - out_mean) * out_invstd) - the backward sums of the
+ *               block's last norm; its backward is then ucd_abn_reduce_partials + ucd_abn_bwd_apply (identity activation)
+ *               on d pre, and the shortcut's gradient is d pre itself
  * act_in / act_out: UCD_ACT_LEAKY_RELU or UCD_ACT_IDENTITY (elu layers keep the separate ucd_abn_* kernels); modes 1 and 3
  * need out_mean, out_scale and out_shift (pass zeros / ones for a missing term).
  * Shapes: K and N multiples of 64, any M; pointers 16-byte aligned, leading dimensions (elements) multiples of 8.
@@ -445,6 +451,8 @@ typedef struct ucd_conv1x1_desc {
    * gradient of such a layer is the same call on (dY, w.flip(2, 3).transpose(0, 1)) (ucd_flip_weights_batched).
    * taps = 0 or 1: the 1x1 product above. */
   int taps, H, W, dilation;
+  /* out_mode 4 only: the conv output z of the residual block whose OUTPUT is `residual` (x-hat of its last norm's sums) */
+  const void* side2;  int ld2;
 } ucd_conv1x1_desc;
 
 int ucd_conv1x1_row_tiles(int M);

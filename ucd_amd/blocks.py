@@ -334,7 +334,7 @@ class _ConvABNFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, fused, dilation=0,
-                wflip=None, own_dgrad=False, wgrad_conv=False, make_link=False, link=None):
+                wflip=None, own_dgrad=False, wgrad_conv=False, make_link=False, link=None, with_skip=False, blink=None):
         from . import hip
         B, K, H, W = x.shape
         N = w4.shape[0]
@@ -348,6 +348,8 @@ class _ConvABNFunction(torch.autograd.Function):
         ctx.conv3 = (dilation, wflip, own_dgrad, wgrad_conv)
         # backward link (see ConvABNTrainNode): link = the producer's (z, buf, bias, partial, flag, act, slope)
         ctx.link = link
+        ctx.blink = blink if with_skip else None        # block link (kind 3): (z, buf, partial, flag, slope) of the block in front
+        ctx.with_skip = with_skip
         ctx.my_link = None
         if conv3 and not fused:
             z = F.conv2d(x, w4, None, 1, dilation, dilation).contiguous(memory_format=torch.channels_last)
@@ -366,14 +368,19 @@ class _ConvABNFunction(torch.autograd.Function):
         needs_y = residual is not None and (act & hip.ACT_MASK) != hip.ACT_IDENTITY
         ctx.save_for_backward(x, w4, z, y if needs_y else None, weight, bias, buf)
         ctx.cfg = (act, slope, residual is not None)
-        if make_link and residual is None and bias is not None:
+        if make_link and bias is not None and (act & hip.ACT_MASK) != hip.ACT_ELU and (residual is None or needs_y):
             partial = torch.empty(hip.conv1x1_row_tiles(M), 2, N, dtype=torch.float32, device=x.device)
             ctx.my_link = (partial, [0, 0])      # {served, address of the consumer's dx} (see ConvABNTrainNode::backward)
-            y._ucd_link = (z, buf, bias, partial, ctx.my_link[1], act, slope)
+            if residual is None:
+                y._ucd_link = (z, buf, bias, partial, ctx.my_link[1], act, slope)
+            else:                                # the block's last node: the NEXT block's conv1 + shortcut node may serve it
+                y._ucd_blink = (z, buf, partial, ctx.my_link[1], slope)
+        if with_skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dskip=None):
         from . import hip
         x, w4, z, y, weight, bias, buf = ctx.saved_tensors
         act, slope, has_res = ctx.cfg
@@ -386,11 +393,13 @@ class _ConvABNFunction(torch.autograd.Function):
             raise RuntimeError("ucd conv+abn node: the backward link was served but the gradient that arrived is not the consumer's "
                                "input gradient - the linked map has a second consumer (hook, ret_intermediate tap, retain_graph "
                                "replay).  Run with UCD_BWD_LINK=0.")
+        dy_in = dy
         dy, _, _, _, _ = hip.rows_view(dy if dy.dtype == x.dtype else dy.to(x.dtype))
         dz = torch.empty_like(z)
-        dres = torch.empty_like(z) if has_res else None
+        linked = ctx.my_link is not None and ctx.my_link[1][0] == 1
+        dres = torch.empty_like(z) if (has_res and not linked) else None
         sums = torch.empty(2 * N, dtype=torch.float32, device=x.device)
-        if ctx.my_link is not None and ctx.my_link[1][0] == 1:
+        if linked:
             # the consumer's input-gradient product applied the activation derivative and left the sums as per-tile partials
             ctx.my_link[1][0] = 0
             part = ctx.my_link[0]
@@ -398,6 +407,8 @@ class _ConvABNFunction(torch.autograd.Function):
                                                           act & hip.NORM_ABS_GAMMA, hip.stream()), "ucd_abn_reduce_partials")
             hip.abn_bwd_apply(z, N, dy, N, None, 0, dz, N, None, 0, M, N, None, HW, buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:],
                               bias, weight, sums, float(M), 0, hip.ACT_IDENTITY | (act & hip.NORM_ABS_GAMMA), 0.0)
+            if has_res:
+                dres = dy_in            # block link: dy IS d pre, and so is the shortcut's gradient
         else:
             hip.abn_backward(z, N, dy, N, y, N if y is not None else 0, dz, N, dres, N if has_res else 0, M, N, None, HW,
                              buf[3 * N:4 * N], buf[4 * N:5 * N], buf[5 * N:], bias, weight, sums, float(M), True, True, act, slope)
@@ -425,15 +436,27 @@ class _ConvABNFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [dilation, dilation], [dilation, dilation],
                                                          False, [0, 0], 1, [False, True, False])[1]
-            return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None, None, None
+            return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
         w2 = w4.reshape(N, K)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            fold = (dskip is not None and dskip.dtype == x.dtype
+                    and dskip.is_contiguous(memory_format=torch.channels_last) and own_dgrad and wflip is not None)
+            dx = dskip if fold else torch.empty_like(x)
             if own_dgrad and wflip is not None:
-                hip.conv1x1(rows(dz), wflip.reshape(K, N), rows(dx), **(link_args(dx) if link is not None else {}))
+                extra = {}
+                if ctx.blink is not None and (fold or dskip is None):
+                    bz, bbuf, bpart, bflag, bslope = ctx.blink            # block link: out_mode 4 against the block in front
+                    bflag[0], bflag[1] = 1, dx.data_ptr()
+                    extra = dict(out_mode=4, out_norm=(bbuf[3 * K:4 * K], None, None, bbuf[4 * K:5 * K], hip.ACT_LEAKY_RELU, bslope),
+                                 residual=rows(x), side2=rows(bz), partial=bpart)
+                elif link is not None and dskip is None:
+                    extra = link_args(dx)
+                hip.conv1x1(rows(dz), wflip.reshape(K, N), rows(dx), accumulate=fold, **extra)
             else:
                 hip.gemm_bf16(1, rows(dz), w2, rows(dx))
+            if dskip is not None and not fold:
+                dx = dx + dskip
         if ctx.needs_input_grad[1] and wgrad_conv:
             dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                      [False, True, False])[1]
@@ -442,7 +465,7 @@ class _ConvABNFunction(torch.autograd.Function):
             dzr, xr = rows(dz), rows(x)
             dw = (torch.bmm(dzr.view(S, M // S, N).transpose(1, 2), xr.view(S, M // S, K)).sum(0) if S > 1 else dzr.t() @ xr)
             dw = dw.as_strided(w4.shape, w4.stride())
-        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_param=None, with_skip=False, make_link=False):
@@ -456,7 +479,13 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     if os.environ.get("UCD_FUSED_CONV1X1", "1") == "0":
         return None
     link = getattr(x, "_ucd_link", None) if os.environ.get("UCD_BWD_LINK", "1") != "0" else None
+    # block link (csrc/abn_node.cpp: block_link_epilogue): x is the output of a residual block whose last node offers its
+    # backward reduction to the first convolution of THIS identity-shortcut block (UCD_BLOCK_LINK=0 switches only this kind off)
+    blink = (getattr(x, "_ucd_blink", None) if (with_skip and os.environ.get("UCD_BWD_LINK", "1") != "0"
+                                                and os.environ.get("UCD_BLOCK_LINK", "1") != "0") else None)
     make_link = make_link and os.environ.get("UCD_BWD_LINK", "1") != "0"
+    if residual is not None and os.environ.get("UCD_BLOCK_LINK", "1") == "0":
+        make_link = False
     is3 = isinstance(conv, Conv3x3)
     if not ((is3 or (isinstance(conv, Conv1x1) and conv.as_gemm)) and conv.bias is None and conv.weight.requires_grad
             and _is_fused_abn(bn) and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda
@@ -476,12 +505,14 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         wflip = conv._w16_flip if conv.working_weight() is not None else None
     else:
         fused = _own_gemm_with_stats(conv.in_channels, conv.out_channels)
-        own_dgrad = conv.own_dgrad or (link is not None and conv.link_dgrad and not with_skip)
+        own_dgrad = conv.own_dgrad or (link is not None and conv.link_dgrad and not with_skip) or (blink is not None and conv.link_dgrad)
         # the transposed weight: cached with the bf16 working copies, else made per call below (same kernels either way)
         wflip = conv._w16_flip if (own_dgrad and conv.working_weight() is not None) else None
         wgrad_conv = not conv.wide
     if link is not None and (not own_dgrad or with_skip):
         link = None                              # the consumer's input gradient does not run on the own kernel: no link
+    if blink is not None and (not own_dgrad or is3):
+        blink = None
     from . import abn as _abn
     from . import hip
     node = _gemm_node()
@@ -499,9 +530,9 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         act = _abn._act_code(bn.activation if activation is None else activation) | (hip.NORM_ABS_GAMMA if bn._abs_gamma else 0)
         slope = bn.activation_param if activation_param is None else activation_param
         bn.__dict__.pop("_eval_cache", None)
-        y = _ConvABNFunction.apply(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
-                                   act, slope, fused, dilation, wflip, own_dgrad, wgrad_conv, bool(make_link), link)
-        return (y, x) if with_skip else y
+        return _ConvABNFunction.apply(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps,
+                                      act, slope, fused, dilation, wflip, own_dgrad, wgrad_conv, bool(make_link), link,
+                                      bool(with_skip), blink)
     if not node.dense_channels_last(x):
         return None
     if residual is not None and not (residual.dtype == x.dtype and node.dense_channels_last(residual)):
@@ -523,11 +554,16 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     out = node.conv_abn_train(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
                               slope, comm.handle if comm is not None else 0, world, _hip_stream(), bn._direct_grad_ptr(),
                               bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad), bool(wgrad_conv),
-                              bool(make_link), *((link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]))
-                                                 if link is not None else (None, None, None, None, None, 0, 0.0)))
+                              bool(make_link),
+                              *((blink[0], blink[1], None, blink[2], blink[3], 0, float(blink[4]), 3) if blink is not None else
+                                (link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]), 1) if link is not None
+                                else (None, None, None, None, None, 0, 0.0, 0)))
     k = 2 if with_skip else 1
     if len(out) > k:                             # the node made a link: (z, buf, partial, flag) follow the regular outputs
-        out[0]._ucd_link = (out[k], out[k + 1], bn.bias, out[k + 2], out[k + 3], act, slope)
+        if residual is None:
+            out[0]._ucd_link = (out[k], out[k + 1], bn.bias, out[k + 2], out[k + 3], act, slope)
+        else:
+            out[0]._ucd_blink = (out[k], out[k + 1], out[k + 2], out[k + 3], slope)
     return (out[0], out[1]) if with_skip else out[0]
 
 
@@ -583,6 +619,14 @@ class ResidualBlock(nn.Module):
         if (isinstance(c3, Conv1x1) and isinstance(getattr(self.convs, "conv2", None), Conv3x3) and c3.in_channels % 64 == 0
                 and c3.out_channels % 64 == 0 and c3.out_channels <= 1024):
             c3.link_dgrad = True          # conv2 + bn2 -> conv3: bn2's backward reduction rides on conv3's input gradient
+
+        c1 = getattr(self.convs, "conv1", None)
+        if (stride == 1 and in_channels == channels[-1] and isinstance(c1, Conv1x1) and len(channels) == 3
+                and c1.in_channels % 64 == 0 and c1.out_channels % 64 == 0):
+            # identity shortcut: conv1's input-gradient product (with the shortcut's gradient folded in) forms the gradient
+            # w.r.t. the previous block's output - the block link has it do that block's bn3 backward reduction too, which
+            # needs the own kernel on the cached transposed weight
+            c1.link_dgrad = True
 
         if stride != 1 or in_channels != channels[-1]:
             self.proj_conv = (Conv1x1(in_channels, channels[-1]) if stride == 1 else
@@ -689,7 +733,7 @@ class ResidualBlock(nn.Module):
                 h2 = _conv_abn_train(c.conv2, c.bn2, h1, make_link=True)      # 3x3 as implicit GEMM + statistics; h2 feeds conv3 only
                 if h2 is None:
                     h2 = c.bn2(c.conv2(h1))
-                out = _conv_abn_train(c.conv3, c.bn3, h2, residual=res, activation=act, activation_param=slope)
+                out = _conv_abn_train(c.conv3, c.bn3, h2, residual=res, activation=act, activation_param=slope, make_link=True)
                 if out is None:
                     out = c.bn3(c.conv3(h2), residual=res, activation=act, activation_param=slope)
                 return out

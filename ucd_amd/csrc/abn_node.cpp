@@ -382,6 +382,25 @@ static void link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& lk_z, const at:
   lk_flag.data_ptr<int64_t>()[1] = (int64_t)reinterpret_cast<intptr_t>(d.y);
 }
 
+// Block link (kind 3): the producer is the LAST node of a residual block, out = act(norm(z) + shortcut), and this product is
+// the input gradient of the next block's first convolution with the identity shortcut's gradient folded in (accumulate): what
+// it computes is d out, so its epilogue (out_mode 4) applies the block activation's derivative (sign of out = this node's own
+// input x) and accumulates the two backward sums of the producer's norm against x-hat(z).  The producer then runs
+// reduce-partials + apply on d pre and hands d pre on as the shortcut's gradient (no second tensor).
+static void block_link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& out, const at::Tensor& lk_z, const at::Tensor& lk_buf,
+                                const at::Tensor& lk_partial, const at::Tensor& lk_flag, int64_t C, AutogradContext* ctx) {
+  const float* b = lk_buf.data_ptr<float>();
+  d.out_mode = 4;
+  d.out_mean = b + 3 * C; d.out_invstd = b + 4 * C;
+  d.residual = out.data_ptr(); d.ldr = (int)C;
+  d.side2 = lk_z.data_ptr(); d.ld2 = (int)C;
+  d.out_act = UCD_ACT_LEAKY_RELU;
+  d.out_slope = (float)ctx->saved_data["lk_slope"].toDouble();
+  d.partial = lk_partial.data_ptr<float>();
+  lk_flag.data_ptr<int64_t>()[0] = 1;
+  lk_flag.data_ptr<int64_t>()[1] = (int64_t)reinterpret_cast<intptr_t>(d.y);
+}
+
 class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
  public:
   static variable_list forward(AutogradContext* ctx, at::Tensor x, at::Tensor w4, at::Tensor weight, at::Tensor bias,
@@ -391,12 +410,14 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                c10::optional<at::Tensor> wflip_, bool own_dgrad, bool wgrad_conv, bool make_link,
                                c10::optional<at::Tensor> lk_z_, c10::optional<at::Tensor> lk_buf_,
                                c10::optional<at::Tensor> lk_bias_, c10::optional<at::Tensor> lk_partial_,
-                               c10::optional<at::Tensor> lk_flag_, int64_t lk_act, double lk_slope) {
+                               c10::optional<at::Tensor> lk_flag_, int64_t lk_act, double lk_slope, int64_t lk_kind) {
     // Backward link between two nodes of a chain  A (conv + ABN) -> B (conv + ABN)  where A's output feeds B only:
     // B's input-gradient product applies A's activation derivative and accumulates A's two backward sums in its epilogue
     // (ucd_conv1x1 out_mode 3), so A's backward skips its reduction pass (ucd_abn_bwd_reduce: two reads of the map).
     // make_link (A): also return (z, buf, partial, flag) - partial [row tiles][2][N] on the device, flag a CPU word B sets.
     // lk_* (B): A's z, statistics buffer, bias, partial, flag, activation.  Under SyncBN the producer all-reduces the sums.
+    // lk_kind 3 (block link, block_link_epilogue above): A is the previous block's conv3 + bn3 + shortcut + activation node
+    // (make_link with a residual), B the first convolution of an identity-shortcut block (with_skip); lk_bias is unused.
     // dilation = 0: 1x1 convolution; dilation >= 1: 3x3, stride 1, padding = dilation (implicit GEMM, taps = 9), weight in
     // channels-last memory order; wflip = w.flip(2, 3).transpose(0, 1) (channels-last; for a 1x1 layer the transposed
     // weight [Ci, Co]) for the input gradient through the own kernel (own_dgrad); wgrad_conv: weight gradient by MIOpen
@@ -480,9 +501,12 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     at::Tensor lk_bias = lk_bias_.has_value() ? *lk_bias_ : at::Tensor();
     at::Tensor lk_partial = lk_partial_.has_value() ? *lk_partial_ : at::Tensor();
     at::Tensor lk_flag = lk_flag_.has_value() ? *lk_flag_ : at::Tensor();
-    const bool consume_link = lk_z.defined() && lk_buf.defined() && lk_bias.defined() && lk_partial.defined() && lk_flag.defined();
+    const bool consume_link = lk_z.defined() && lk_buf.defined() && (lk_bias.defined() || lk_kind == 3) && lk_partial.defined() &&
+                              lk_flag.defined() && (lk_kind != 3 || with_skip);
     at::Tensor my_partial, my_flag;
-    make_link = make_link && !has_res && bias.defined();
+    // a link needs leaky_relu / identity (the fused epilogues' activations); with a residual it is the block link, whose
+    // consumer reads the sign from y - so y must be among the saved tensors (needs_y: leaky_relu with a residual)
+    make_link = make_link && bias.defined() && (act & UCD_ACT_MASK) != UCD_ACT_ELU && (!has_res || needs_y);
     if (make_link) {
       my_partial = at::empty({(int64_t)ucd_conv1x1_row_tiles((int)M), 2, N}, x.options().dtype(at::kFloat));
       my_flag = at::zeros({2}, at::TensorOptions().dtype(at::kLong));   // {served, address of the consumer's dx}
@@ -493,6 +517,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                             consume_link ? lk_flag : at::Tensor(), my_partial, my_flag});
     ctx->saved_data["lk_act"] = lk_act;
     ctx->saved_data["lk_slope"] = lk_slope;
+    ctx->saved_data["lk_kind"] = lk_kind;
     ctx->saved_data["act"] = act;
     ctx->saved_data["slope"] = slope;
     ctx->saved_data["comm"] = comm;
@@ -551,7 +576,8 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       if (dy.scalar_type() != at::kBFloat16) dy = dy.to(at::kBFloat16);
       if (!dense_channels_last(dy)) dy = dy.contiguous(at::MemoryFormat::ChannelsLast);
       dz = at::empty_like(z);
-      if (has_res) dres = at::empty_like(z);
+      const bool linked_now = my_flag.defined() && my_flag.data_ptr<int64_t>()[0] == 1;
+      if (has_res && !linked_now) dres = at::empty_like(z);
       const bool sync = comm != 0;
       at::Tensor sums;
       if (sync || !param_grad) sums = at::empty({(sync && !param_grad ? 4 : 2) * N}, x.options().dtype(at::kFloat));
@@ -579,6 +605,8 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                 (float)M * (sync ? (float)world : 1.f), 0, (int)(UCD_ACT_IDENTITY | (act & UCD_NORM_ABS_GAMMA)), 0.f,
                                 (ucd_stream_t)stream),
               "ucd_abn_bwd_apply");
+        // block link: dy already IS d pre = d out * act'(out); the shortcut's gradient is that same tensor (no copy, no write)
+        if (has_res) dres = dy;
         if (!param_grad) {
           dbias = sums.narrow(0, sync ? 2 * N : 0, N);
           dweight = sums.narrow(0, sync ? 3 * N : N, N);
@@ -612,7 +640,8 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
           d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)(9 * N); d.y = dx.data_ptr(); d.ldy = (int)K;
           d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0;
           d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation;
-          if (lk_flag.defined()) link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
+          if (lk_flag.defined() && ctx->saved_data["lk_kind"].toInt() != 3)
+            link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
           check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
         } else {
           dx = at::conv2d(dz, wflip, {}, {1, 1}, {dilation, dilation}, {dilation, dilation}, 1);
@@ -622,7 +651,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {dilation, dilation}, {dilation, dilation}, false,
                                                   {0, 0}, 1, {false, true, false}));
       return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-              none, none, none, none, none, none, none, none, none, none, none, none};
+              none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
     const size_t wsb = ucd_gemm_workspace_bytes();
     void* gws = workspace(x, wsb, stream, 1);
@@ -637,7 +666,12 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         memset(&d, 0, sizeof(d));
         d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)N; d.y = dx.data_ptr(); d.ldy = (int)K;
         d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0; d.accumulate = fold ? 1 : 0;
-        if (lk_flag.defined() && !fold && !dskip.defined()) link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
+        const bool block_link = lk_flag.defined() && ctx->saved_data["lk_kind"].toInt() == 3;
+        if (block_link) {
+          if (with_skip && (fold || !dskip.defined())) block_link_epilogue(d, x, lk_z, lk_buf, lk_partial, lk_flag, K, ctx);
+        } else if (lk_flag.defined() && !fold && !dskip.defined()) {
+          link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
+        }
         check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
         if (!fold && dskip.defined()) dx = dx + dskip;
       } else if (fold) {
@@ -680,7 +714,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       dw = dw.as_strided(w4.sizes(), w4.strides());
     }
     return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -691,10 +725,10 @@ std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor w
                                        c10::optional<at::Tensor> wflip, bool own_dgrad, bool wgrad_conv, bool make_link,
                                        c10::optional<at::Tensor> lk_z, c10::optional<at::Tensor> lk_buf,
                                        c10::optional<at::Tensor> lk_bias, c10::optional<at::Tensor> lk_partial,
-                                       c10::optional<at::Tensor> lk_flag, int64_t lk_act, double lk_slope) {
+                                       c10::optional<at::Tensor> lk_flag, int64_t lk_act, double lk_slope, int64_t lk_kind) {
   return ConvABNTrainNode::apply(x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world,
                                  stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad, wgrad_conv, make_link, lk_z,
-                                 lk_buf, lk_bias, lk_partial, lk_flag, lk_act, lk_slope);
+                                 lk_buf, lk_bias, lk_partial, lk_flag, lk_act, lk_slope, lk_kind);
 }
 
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,

@@ -57,6 +57,7 @@ struct Args {
   const float *in_mean, *in_scale, *in_shift; int in_act; float in_slope;
   const float *out_mean, *out_scale, *out_shift, *out_invstd;
   const bf16* R; int ldr;
+  const bf16* Z; int ldz;       // OUT == 4: the producer's pre-norm input (x-hat of its two backward sums)
   int out_act; float out_slope;
   float* partial;
   int accumulate;
@@ -79,7 +80,11 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slo
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// OUT: 0 plain (+accumulate), 1 affine + residual + activation, 2 plain + statistics partials, 3 activation backward + sums
+// OUT: 0 plain (+accumulate), 1 affine + residual + activation, 2 plain + statistics partials, 3 activation backward + sums,
+//      4 block-output backward: acc (+ the shortcut's gradient already in y) is the gradient w.r.t. the OUTPUT of a residual
+//        block act(norm(z) + shortcut); with its output R (the sign) and its conv3 output Z: y = d pre = (acc + y) * act'(R) and
+//        the two backward sums of the block's last norm (sum d pre, sum d pre * xhat(Z)) - that norm then needs neither its
+//        reduction pass nor a separate shortcut gradient (d shortcut = d pre, the same tensor).
 //
 // Structure: one LDS stage per workgroup and FOUR workgroups per CU (<= 128 VGPRs, 34 KB of LDS): a K step is
 // {fill the stage: global_load_lds for W (and for A when it needs no transform), registers + transform for A otherwise;
@@ -96,7 +101,7 @@ __device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 // fill of step k+1 is issued (LDS-DMA: no registers to carry) before the MFMAs of step k and waited for with a counted
 // vmcnt, so it lands under them.  64 KB of LDS, two workgroups per CU.
 template <int BN, bool PRO, int OUT, bool CONV3 = false, bool DB = false>
-__global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
+__global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
   static_assert(!DB || !PRO, "the double-buffered form has no input transform");
   constexpr int kStage = (kBM + BN) * 128;   // bytes of one LDS stage (A tile + W tile)
   constexpr int WN = BN / 2;           // columns per wave
@@ -302,20 +307,36 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 
       ei[e] = (OUT == 3) ? p.out_invstd[ncol + e] : 0.f;
     }
   }
+  if (OUT == 4) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      em[e] = p.out_mean[ncol + e];
+      ei[e] = p.out_invstd[ncol + e];
+      es[e] = 0.f; eb[e] = 0.f;
+    }
+  }
   float kshift[8], s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { kshift[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
-  const bool has_side = (OUT == 0 && p.accumulate) || (OUT == 1 && p.R != nullptr) || OUT == 3;
-  const bf16* sp = OUT == 0 ? p.Y : p.R;
-  const int lds_ = OUT == 0 ? p.ldy : p.ldr;
+  const bool has_side = ((OUT == 0 || OUT == 4) && p.accumulate) || (OUT == 1 && p.R != nullptr) || OUT == 3;
+  const bf16* sp = (OUT == 0 || OUT == 4) ? p.Y : p.R;
+  const int lds_ = (OUT == 0 || OUT == 4) ? p.ldy : p.ldr;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
     // side input (residual / old y / x) of this half's rows: requested before the LDS round trip, rows past M clamped
-    uint4 side[RPT];
+    uint4 side[RPT], side_y[OUT == 4 ? RPT : 1], side_z[OUT == 4 ? RPT : 1];
     if (has_side) {
 #pragma unroll
       for (int i = 0; i < RPT; ++i)
         side[i] = *reinterpret_cast<const uint4*>(sp + (size_t)min(m0 + half * 64 + r0 + RSTEP * i, p.M - 1) * lds_ + ncol);
+    }
+    if (OUT == 4) {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) {
+        const size_t row = (size_t)min(m0 + half * 64 + r0 + RSTEP * i, p.M - 1);
+        side_y[i] = *reinterpret_cast<const uint4*>(p.R + row * p.ldr + ncol);
+        side_z[i] = *reinterpret_cast<const uint4*>(p.Z + row * p.ldz + ncol);
+      }
     }
     __syncthreads();                                  // main loop reads / previous half's reads are done
     if (wm == half) {
@@ -367,7 +388,7 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 
           s1[e] += d;
           s2[e] += d * d;
         }
-      } else {  // OUT == 3: v = d a', x = the fused layer's pre-norm input
+      } else if (OUT == 3) {  // v = d a', x = the fused layer's pre-norm input
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float xc = sv.get(e) - em[e];
@@ -377,11 +398,25 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT == 3) && BN == 128 
           s1[e] += dzr;
           s2[e] += dzr * (xc * ei[e]);
         }
+      } else {  // OUT == 4: v (+ the shortcut's gradient) = d out of a residual block; sign from its output, x-hat from its z
+        Vec<bf16> yv, zv;
+        yv.raw = side_y[OUT == 4 ? i : 0];
+        zv.raw = side_z[OUT == 4 ? i : 0];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float g = v[e];
+          if (p.accumulate) g += sv.get(e);
+          const float dz = g * act_grad_rt(yv.get(e), p.out_slope);
+          o.set(e, dz);
+          const float dzr = live ? o.get(e) : 0.f;
+          s1[e] += dzr;
+          s2[e] += dzr * ((zv.get(e) - em[e]) * ei[e]);
+        }
       }
       if (live) o.store(p.Y + (size_t)grow * p.ldy + ncol);
     }
   }
-  if (OUT == 2 || OUT == 3) {
+  if (OUT >= 2) {
     // reduce over the RSTEP threads that share a column chunk: through LDS (the output tile is consumed)
     __syncthreads();
     float* red = Cs;                                  // [RSTEP][2][BN]
@@ -685,8 +720,11 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   UCD_REQUIRE(aligned16(d->a) && aligned16(d->w) && aligned16(d->y) && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldy % 8 == 0 &&
                   d->lda >= d->K && d->ldw >= d->K && d->ldy >= d->N,
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
-  UCD_REQUIRE(d->out_mode >= 0 && d->out_mode <= 3, UCD_EINVAL, "%s: unknown out_mode %d", fn, d->out_mode);
-  UCD_REQUIRE(d->out_mode != 2 && d->out_mode != 3 ? true : d->partial != nullptr, UCD_EINVAL, "%s: partial is NULL", fn);
+  UCD_REQUIRE(d->out_mode >= 0 && d->out_mode <= 4, UCD_EINVAL, "%s: unknown out_mode %d", fn, d->out_mode);
+  UCD_REQUIRE(d->out_mode < 2 ? true : d->partial != nullptr, UCD_EINVAL, "%s: partial is NULL", fn);
+  UCD_REQUIRE(d->out_mode != 4 || (d->residual && d->side2 && d->out_mean && d->out_invstd && !conv3 && !d->in_scale &&
+                                   aligned16(d->side2) && d->ld2 % 8 == 0 && d->ld2 >= d->N),
+              UCD_EINVAL, "%s: out_mode 4 (1x1 only) needs the block output (residual), its conv output (side2), out_mean and out_invstd", fn);
   UCD_REQUIRE((d->out_mode != 1 && d->out_mode != 3) || (d->out_mean && d->out_scale && d->out_shift), UCD_EINVAL,
               "%s: out_mode %d needs out_mean, out_scale and out_shift", fn, d->out_mode);
   UCD_REQUIRE(d->out_mode != 3 || (d->residual && d->out_invstd), UCD_EINVAL, "%s: out_mode 3 needs x (residual) and invstd", fn);
@@ -702,6 +740,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   a.in_act = d->in_act & UCD_ACT_MASK; a.in_slope = a.in_act == UCD_ACT_IDENTITY ? 1.f : d->in_slope;
   a.out_mean = d->out_mean; a.out_scale = d->out_scale; a.out_shift = d->out_shift; a.out_invstd = d->out_invstd;
   a.R = (const bf16*)d->residual; a.ldr = d->ldr;
+  a.Z = (const bf16*)d->side2; a.ldz = d->ld2;
   a.out_act = d->out_act & UCD_ACT_MASK; a.out_slope = a.out_act == UCD_ACT_IDENTITY ? 1.f : d->out_slope;
   a.partial = d->partial; a.accumulate = d->accumulate;
   a.iH = d->H; a.iW = d->W; a.dil = d->dilation;
@@ -712,7 +751,9 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   // double-buffered form (256->256 50.6 -> 47.3 us, the ASPP branches 338-356 -> 308-314); fuller grids are faster with
   // the single stage and four workgroups per CU (512->512 170 vs 179, 128->128 at 65^2 48.7 vs 52.6)
   // (the 1x1 products of such grids gain too: 1024 -> 256 23.3 -> 21.7 us, with statistics 25.1 -> 23.6)
-  const bool db = (conv3 || !d->in_scale) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640;
+  // out_mode 4 keeps three side tiles in registers next to the accumulators: 168 VGPRs + 96 B of scratch in the single-stage
+  // form at three workgroups per CU, 194 VGPRs and no scratch in the double-buffered form (two per CU) - it always takes that
+  const bool db = ((conv3 || !d->in_scale) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640) || (d->out_mode == 4 && BN == 128);
   const size_t lds_main = (size_t)(kBM + BN) * 128 * (db ? 2 : 1), lds_out = (size_t)64 * (BN + 4) * 4;
   size_t lds = lds_main > lds_out ? lds_main : lds_out;
   const size_t lds_red = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;       // statistics reduction scratch
@@ -734,7 +775,11 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
     case 0: UCD_C1_LAUNCH(BNV, PROV, 0) break;                                  \
     case 1: UCD_C1_LAUNCH(BNV, PROV, 1) break;                                  \
     case 2: UCD_C1_LAUNCH(BNV, PROV, 2) break;                                  \
-    default: UCD_C1_LAUNCH(BNV, PROV, 3) break;                                 \
+    case 3: UCD_C1_LAUNCH(BNV, PROV, 3) break;                                  \
+    default:                                                                    \
+      if (db) conv1x1_kernel<BNV, false, 4, false, true><<<grid, kThreads, lds, s>>>(a); \
+      else conv1x1_kernel<BNV, false, 4><<<grid, kThreads, lds, s>>>(a);         \
+      break;                                                                    \
   }
 #define UCD_C3_OUT(BNV)                                                                        \
   switch (d->out_mode) {                                                                       \
@@ -747,6 +792,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
     case 2: if (db) conv1x1_kernel<BNV, false, 2, true, true><<<grid, kThreads, lds, s>>>(a);  \
             else conv1x1_kernel<BNV, false, 2, true, false><<<grid, kThreads, lds, s>>>(a);    \
             break;                                                                             \
+    case 4: UCD_REQUIRE(false, UCD_EINVAL, "%s: out_mode 4 belongs to the 1x1 products", fn);  \
     default: if (db) conv1x1_kernel<BNV, false, 3, true, true><<<grid, kThreads, lds, s>>>(a); \
              else conv1x1_kernel<BNV, false, 3, true, false><<<grid, kThreads, lds, s>>>(a);   \
              break;                                                                            \

@@ -47,7 +47,8 @@ class Conv1x1Desc(C.Structure):
                 ("out_mean", C.c_void_p), ("out_scale", C.c_void_p), ("out_shift", C.c_void_p), ("out_invstd", C.c_void_p),
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("out_act", C.c_int), ("out_slope", C.c_float),
                 ("partial", C.c_void_p), ("accumulate", C.c_int),
-                ("taps", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dilation", C.c_int)]
+                ("taps", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dilation", C.c_int),
+                ("side2", C.c_void_p), ("ld2", C.c_int)]
 
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -501,7 +502,8 @@ def attmap(x, ld_x, y, ld_y, B, HW, Cc):
 # ---------------------------------------------------------------------------------------------
 # 1x1 convolutions as fused GEMMs (csrc/conv1x1.hip)
 # ---------------------------------------------------------------------------------------------
-def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, partial=None, accumulate=False, conv3=None):
+def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, partial=None, accumulate=False, conv3=None,
+            side2=None):
     """y[M, N] = out(in(a)[M, K] . w[N, K]^T).  ``in_norm`` = (mean, scale, shift, act, slope) of the producer's ABN or None;
     ``out_norm`` = (mean, scale, shift, invstd, act, slope) for out_mode 1 / 3.  All 2-D bf16 row matrices.
     ``conv3 = (H, W, dilation)``: 3x3 convolution (stride 1, padding = dilation) of the [B, H, W, K] map behind ``a`` with the
@@ -524,11 +526,14 @@ def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, par
         d.out_act, d.out_slope = act & ACT_MASK, slope
     if residual is not None:
         d.residual, d.ldr = residual.data_ptr(), residual.stride(0)
+    if side2 is not None:           # out_mode 4: the conv output z of the block whose output is ``residual``
+        d.side2, d.ld2 = side2.data_ptr(), side2.stride(0)
     d.partial = ptr(partial)
     d.accumulate = 1 if accumulate else 0
     # roofline work of the instrumented bench pass: algorithmic bytes for the 1x1 products (HBM-bound at the network's
     # shapes), flop for the 3x3 implicit GEMM (9 K deep: MFMA-bound)
-    work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)))
+    work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)
+                                                                                 + (side2 is not None)))
     with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work):
         _check(lib.ucd_conv1x1(C.byref(d), stream()), "ucd_conv1x1")
     return y
