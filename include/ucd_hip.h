@@ -478,6 +478,19 @@ int ucd_conv1x1_wgrad(const void* dy, int ld_dy, const void* a, int lda, int M, 
                       const float* in_mean, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                       void* dw, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
+/* Weight gradient of a stride-1 convolution on channels-last maps (backward of modules/residual.py:57-73 conv1 / conv2 / conv3 /
+ * proj_conv, modules/deeplab.py:24-37 map_convs / red_conv; replaces MIOpen's weight-gradient solvers and the batched split-M
+ * library products on the train step):
+ *     dw[n][t][k] = sum_m dz[m][n] * x[shift_t(m)][k]      taps = 1: the 1x1 product dz^T x;  taps = 9: the 3x3 convolution with
+ *                                                          padding = dilation over the [B, H, W, K] map behind x (M = B*H*W)
+ * dz [M][N] and x [M][K] bf16 row matrices (leading dimensions in elements), N and K multiples of 64.  The result is in the
+ * weight's channels-last order [N][kh][kw][K]: dw (bf16, may be NULL) and / or dw32 (fp32, may be NULL; += when accumulate32,
+ * e.g. straight into the fp32 gradient bucket).  workspace: ucd_conv_wgrad_workspace_bytes(M, N, K, taps) bytes of fp32 slabs
+ * (one per row chunk), added in a fixed order (deterministic). */
+size_t ucd_conv_wgrad_workspace_bytes(int M, int N, int K, int taps);
+int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
+                   void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+
 /* The weights of the input-gradient convolutions of ALL stride-1 layers in one launch: for table entry e = {src offset,
  * dst offset, Co, Ci, KH*KW} (elements into the flat bf16 buffers; 4-D weights in channels-last memory order
  * [out][kh][kw][in]), dst_e = src_e.flip(2, 3).transpose(0, 1) in the same memory order.  blocks [n_blocks][4] (device,

@@ -762,3 +762,59 @@ def test_block_link_moves_bn3_backward_into_the_next_blocks_first_product(cin, c
         assert worst < 3e-2, (use_node, worst)
     for i, (a, b) in enumerate(zip(res[(True, "1")], res[(False, "1")])):
         assert _rel(a, b) < 1e-2, i                                       # node and twin agree with the link on
+
+
+# ---- weight gradients (csrc/wgrad.hip) ----------------------------------------------------------------------------------------
+WGRAD_CASES = [
+    # M, N (out), K (in), (H, W, dilation) or None
+    (300, 64, 64, None), (1000, 128, 256, None), (4356, 256, 128, (33, 33, 2)), (2 * 9 * 11, 64, 128, (9, 11, 1)),
+    (26136, 256, 1024, None), (26136, 1024, 256, None), (26136, 256, 256, (33, 33, 1)), (26136, 512, 512, (33, 33, 2)),
+    (26136, 256, 2048, (33, 33, 12)), (101400, 128, 512, None), (101400, 128, 128, (65, 65, 1)),
+    (399384, 256, 64, None), (399384, 64, 256, None), (399384, 64, 64, (129, 129, 1)),
+]
+
+
+def _wgrad_ref(dz, x, sp):
+    """fp32 reference by plain matmuls: dw[n, t, k] = sum_m dz[m, n] x[shift_t(m), k] (zero outside the map)."""
+    M, N = dz.shape
+    K = x.shape[1]
+    if sp is None:
+        return dz.float().t() @ x.float()
+    H, W, d = sp
+    B = M // (H * W)
+    xp = F.pad(x.float().view(B, H, W, K), (0, 0, d, d, d, d))
+    out = torch.empty(N, 9, K, device=dz.device)
+    for kh in range(3):
+        for kw in range(3):
+            out[:, kh * 3 + kw] = dz.float().t() @ xp[:, kh * d:kh * d + H, kw * d:kw * d + W, :].reshape(M, K)
+    return out.reshape(N, 9 * K)
+
+
+@pytest.mark.parametrize("M,N,K,sp", WGRAD_CASES)
+def test_conv_wgrad_exact_on_integers_and_against_fp32(M, N, K, sp):
+    """dW = dZ^T X (1x1) and the 9-tap form of the 3x3 layers through ucd_conv_wgrad at the network's shapes (B = 24 row counts
+    included: the chunk / XCD mapping, the chunk that ends inside a 64-row step, rows that shift off the map): sparse
+    small-integer operands make every output an exactly representable integer, so the comparison is bit-exact in bf16 AND in the
+    fp32 output; then random operands against the fp32 product at bf16 rounding, and the += form into an fp32 buffer."""
+    from ucd_amd import hip
+    g = torch.Generator(DEV).manual_seed(M + N + K)
+    dens = min(0.5, (24.0 / M) ** 0.5)
+    zi = (torch.randint(-2, 3, (M, N), device=DEV, generator=g) * (torch.rand(M, N, device=DEV, generator=g) < dens)).bfloat16()
+    xi = (torch.randint(-1, 2, (M, K), device=DEV, generator=g) * (torch.rand(M, K, device=DEV, generator=g) < dens)).bfloat16()
+    taps = 9 if sp else 1
+    dw = torch.full((N, taps * K), float("nan"), device=DEV, dtype=torch.bfloat16)
+    dw32 = torch.full((N, taps * K), float("nan"), device=DEV)
+    hip.conv_wgrad(zi, xi, dw, conv3=sp, dw32=dw32)
+    exact = _wgrad_ref(zi, xi, sp)
+    assert exact.abs().max().item() <= 256
+    assert torch.equal(dw32, exact)
+    assert torch.equal(dw.float(), exact)
+    z = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    x = (torch.randn(M, K, device=DEV, generator=g) * 1.3 + 0.2).bfloat16()
+    ref = _wgrad_ref(z, x, sp)
+    hip.conv_wgrad(z, x, dw, conv3=sp)
+    assert _rel(dw, ref) < 3e-3
+    base = torch.randn(N, taps * K, device=DEV, generator=g)
+    acc = base.clone()
+    hip.conv_wgrad(z, x, None, conv3=sp, dw32=acc, accumulate32=True)
+    assert _rel(acc - base, ref) < 1e-4

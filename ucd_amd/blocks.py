@@ -40,6 +40,12 @@ def _wgrad_split(M: int) -> int:
     return 1
 
 
+def _own_wgrad() -> bool:
+    """Weight gradients on the own kernel (csrc/wgrad.hip: ucd_conv_wgrad) instead of MIOpen's weight-gradient solvers / the
+    batched split-M library products; ``UCD_OWN_WGRAD=0`` restores those (the A/B reference of the tests and probes)."""
+    return os.environ.get("UCD_OWN_WGRAD", "1") != "0"
+
+
 def _lib_gemm():
     """``ucd_amd.hip`` when its hipBLASLt entry point (tuned once per shape, ~12 us of host time per call instead of
     ~19 through the framework) can be used, else None (then the same products go through torch)."""
@@ -94,7 +100,11 @@ class _Gemm1x1(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             M, Co = dy.shape
             S = _wgrad_split(M)
-            if S > 1:        # K = B*H*W is long: 8 batched chunks + a sum beat every single-kernel candidate (41 vs 96 us)
+            if (_own_wgrad() and dy.dtype == torch.bfloat16 and rows.dtype == torch.bfloat16 and Co % 64 == 0
+                    and rows.shape[1] % 64 == 0 and rows.is_contiguous()):
+                from . import hip
+                dw = hip.conv_wgrad(dy, rows, torch.empty(Co, rows.shape[1], dtype=dy.dtype, device=dy.device))
+            elif S > 1:      # K = B*H*W is long: 8 batched chunks + a sum beat every single-kernel candidate (41 vs 96 us)
                 dw = torch.bmm(dy.view(S, M // S, Co).transpose(1, 2), rows.view(S, M // S, rows.shape[1])).sum(0)
             elif lib is None:
                 dw = dy.t() @ rows
@@ -167,9 +177,34 @@ class _StrideOneConvFn(torch.autograd.Function):
             else:
                 dx = F.conv2d(dy, wt, None, 1, pad, d)
         if ctx.needs_input_grad[1]:
-            dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [pad, pad], [d, d], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            dw = _own_wgrad_4d(dy, x, w, d if w.shape[2] == 3 else 0)
+            if dw is None:
+                dw = torch.ops.aten.convolution_backward(dy, x, w, None, [1, 1], [pad, pad], [d, d], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return dx, dw, None, None, None, None
+
+
+def _own_wgrad_4d(dz, x, w4, dilation):
+    """Weight gradient of a stride-1 convolution (dilation 0: 1x1) on the own kernel, as a tensor with the weight's sizes and
+    channels-last strides; None when the layer is not one it takes (alignment, dtype, UCD_OWN_WGRAD=0)."""
+    if not (_own_wgrad() and dz.is_cuda and dz.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and w4.shape[0] % 64 == 0
+            and w4.shape[1] % 64 == 0 and x.shape[2] > 1 and x.shape[3] > 1 and x.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22)):
+        return None
+    if dilation > 0 and not (tuple(w4.shape[2:]) == (3, 3) and w4.is_contiguous(memory_format=torch.channels_last)
+                             and w4.shape[0] * w4.shape[1] < (1 << 18)):      # 512 -> 512 and the ASPP branches: MIOpen is faster
+        return None
+    from . import hip
+    if not dz.is_contiguous(memory_format=torch.channels_last):
+        dz = dz.contiguous(memory_format=torch.channels_last)
+    N, K = w4.shape[0], w4.shape[1]
+    B, _, H, W = x.shape
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(B * H * W, t.shape[1])
+    taps = 9 if dilation > 0 else 1
+    dw = torch.empty((N, taps * K), dtype=x.dtype, device=x.device)
+    hip.conv_wgrad(rows(dz), rows(x), dw, conv3=(H, W, dilation) if dilation > 0 else None)
+    k = 3 if dilation > 0 else 1
+    return dw.view(N, k, k, K).permute(0, 3, 1, 2)
 
 
 def _own3x3(x, w, d):
@@ -197,7 +232,7 @@ def _stride_one_conv(x, w, d, wt=None, own_fwd=False, own_dgrad=False):
     from . import abn
     node = abn._abn_node()
     if node is not None and hasattr(node, "conv_stride1"):
-        return node.conv_stride1(x, w, d, wt, bool(own_fwd), bool(own_dgrad), _hip_stream())
+        return node.conv_stride1(x, w, d, wt, bool(own_fwd), bool(own_dgrad), _hip_stream(), _own_wgrad())
     return _StrideOneConvFn.apply(x, w, d, wt, bool(own_fwd), bool(own_dgrad))
 
 
@@ -274,7 +309,7 @@ class Conv1x1(Conv2d):
             w4 = w16 if w16 is not None else self.weight.to(rows.dtype)
             node = _gemm_node() if rows.dtype == torch.bfloat16 else None
             if node is not None:          # same library calls, autograd node in C++ (host time per layer 71 -> ~25 us)
-                y = node.gemm1x1(rows, w4, _hip_stream())
+                y = node.gemm1x1(rows, w4, _hip_stream(), _own_wgrad())
             else:
                 y = _Gemm1x1.apply(rows, w4)
         else:
@@ -302,7 +337,8 @@ def _conv1_with_skip(conv, x):
     if not rows.is_contiguous():
         return None
     w16 = conv.working_weight()
-    y, skip = node.gemm1x1_skip(rows.reshape(B * H * W, C), w16 if w16 is not None else conv.weight.to(x.dtype), _hip_stream())
+    y, skip = node.gemm1x1_skip(rows.reshape(B * H * W, C), w16 if w16 is not None else conv.weight.to(x.dtype), _hip_stream(),
+                                _own_wgrad())
     return (y.view(B, H, W, conv.out_channels).permute(0, 3, 1, 2), skip.view(B, H, W, C).permute(0, 3, 1, 2))
 
 
@@ -434,8 +470,10 @@ class _ConvABNFunction(torch.autograd.Function):
                 else:
                     dx = F.conv2d(dz, wflip, None, 1, dilation, dilation)
             if ctx.needs_input_grad[1]:
-                dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [dilation, dilation], [dilation, dilation],
-                                                         False, [0, 0], 1, [False, True, False])[1]
+                dw = _own_wgrad_4d(dz, x, w4, dilation) if wgrad_conv == 2 else None
+                if dw is None:
+                    dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [dilation, dilation], [dilation, dilation],
+                                                             False, [0, 0], 1, [False, True, False])[1]
             return dx, dw, sums[N:], sums[:N], dres, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None
         w2 = w4.reshape(N, K)
         dx = dw = None
@@ -457,7 +495,13 @@ class _ConvABNFunction(torch.autograd.Function):
                 hip.gemm_bf16(1, rows(dz), w2, rows(dx))
             if dskip is not None and not fold:
                 dx = dx + dskip
-        if ctx.needs_input_grad[1] and wgrad_conv:
+        if ctx.needs_input_grad[1] and wgrad_conv == 2:
+            dw = _own_wgrad_4d(dz, x, w4, 0)
+            if dw is None:
+                wgrad_conv = 1
+        if dw is not None:
+            pass
+        elif ctx.needs_input_grad[1] and wgrad_conv == 1:
             dw = torch.ops.aten.convolution_backward(dz, x, w4, None, [1, 1], [0, 0], [1, 1], False, [0, 0], 1,
                                                      [False, True, False])[1]
         elif ctx.needs_input_grad[1]:
@@ -491,7 +535,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
             and _is_fused_abn(bn) and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda
             and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
         return None
-    dilation, wflip, fused, own_dgrad, wgrad_conv = 0, None, None, False, False
+    dilation, wflip, fused, own_dgrad, wgrad_conv = 0, None, None, False, 0      # wgrad_conv: 0 batched products, 1 MIOpen, 2 own
     if is3:
         if not (conv.stride == (1, 1) and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1]
                 and conv.groups == 1 and not with_skip and conv.weight.is_contiguous(memory_format=torch.channels_last)):
@@ -508,7 +552,9 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
         own_dgrad = conv.own_dgrad or (link is not None and conv.link_dgrad and not with_skip) or (blink is not None and conv.link_dgrad)
         # the transposed weight: cached with the bf16 working copies, else made per call below (same kernels either way)
         wflip = conv._w16_flip if (own_dgrad and conv.working_weight() is not None) else None
-        wgrad_conv = not conv.wide
+        wgrad_conv = 0 if conv.wide else 1
+    if _own_wgrad():
+        wgrad_conv = 2
     if link is not None and (not own_dgrad or with_skip):
         link = None                              # the consumer's input gradient does not run on the own kernel: no link
     if blink is not None and (not own_dgrad or is3):
@@ -553,7 +599,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     bn.__dict__.pop("_eval_cache", None)
     out = node.conv_abn_train(x, w16, bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, bn.momentum, bn.eps, act,
                               slope, comm.handle if comm is not None else 0, world, _hip_stream(), bn._direct_grad_ptr(),
-                              bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad), bool(wgrad_conv),
+                              bool(with_skip), bool(fused), dilation, wflip, bool(own_dgrad), int(wgrad_conv),
                               bool(make_link),
                               *((blink[0], blink[1], None, blink[2], blink[3], 0, float(blink[4]), 3) if blink is not None else
                                 (link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]), 1) if link is not None

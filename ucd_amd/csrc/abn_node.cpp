@@ -58,6 +58,30 @@ int dtype_code(const at::Tensor& x) {
 
 const float* fptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 
+// Weight gradient of a stride-1 convolution on the own kernel (ucd_conv_wgrad, csrc/wgrad.hip): dz [B, N, H, W] and x [B, K, H, W]
+// dense channels-last bf16 -> a tensor with the weight's sizes and (channels-last) strides.  dilation 0: 1x1.
+bool own_wgrad_ok(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w4, int64_t dilation) {
+  return dz.defined() && dense_channels_last(dz) && dense_channels_last(x) && dz.scalar_type() == at::kBFloat16 &&
+         x.scalar_type() == at::kBFloat16 && w4.size(0) % 64 == 0 && w4.size(1) % 64 == 0 && dz.size(1) == w4.size(0) &&
+         x.size(1) == w4.size(1) && x.size(0) * x.size(2) * x.size(3) < (1 << 22) &&
+         (dilation == 0 ? (w4.size(2) == 1 && w4.size(3) == 1)
+                        // the 9-tap form where it beats MIOpen's solver (tools/wgrad_probe2.py: 64-256 channel layers 55-75 vs
+                        // 81-100 us; 512 -> 512 and the ASPP branches 228 / 414 vs 220 / 371 us: MIOpen keeps those)
+                        : (w4.size(2) == 3 && w4.size(3) == 3 && w4.size(0) * w4.size(1) < (1 << 18)));
+}
+
+at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w4, int64_t dilation, int64_t stream) {
+  const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0), M = B * H * W;
+  const int taps = dilation > 0 ? 9 : 1;
+  at::Tensor dw = at::empty({N, taps == 9 ? 3 : 1, taps == 9 ? 3 : 1, K}, x.options().memory_format(c10::nullopt));
+  const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)N, (int)K, taps);
+  check(ucd_conv_wgrad(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
+                       (int)(dilation > 0 ? dilation : 1), dw.data_ptr(), nullptr, 0, workspace(x, wsb, stream, 2), wsb,
+                       (ucd_stream_t)stream),
+        "ucd_conv_wgrad");
+  return dw.permute({0, 3, 1, 2});      // [N, K, kh, kw] with channels-last strides: the weight's own memory order
+}
+
 class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
  public:
   static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor weight, at::Tensor bias,
@@ -156,6 +180,23 @@ class ABNTrainNode : public torch::autograd::Function<ABNTrainNode> {
   }
 };
 
+// dw[Co, Ci] = dy[M, Co]^T rows[M, Ci] on the own kernel (2-D row matrices, contiguous bf16)
+bool own_wgrad_rows_ok(const at::Tensor& dy, const at::Tensor& rows) {
+  return dy.dim() == 2 && rows.dim() == 2 && dy.is_contiguous() && rows.is_contiguous() && dy.scalar_type() == at::kBFloat16 &&
+         rows.scalar_type() == at::kBFloat16 && dy.size(1) % 64 == 0 && rows.size(1) % 64 == 0 && dy.size(0) < (1 << 22) &&
+         (reinterpret_cast<uintptr_t>(dy.data_ptr()) & 15) == 0 && (reinterpret_cast<uintptr_t>(rows.data_ptr()) & 15) == 0;
+}
+
+at::Tensor own_wgrad_rows(const at::Tensor& dy, const at::Tensor& rows, int64_t stream) {
+  const int64_t M = rows.size(0), Ci = rows.size(1), Co = dy.size(1);
+  at::Tensor dw = at::empty({Co, Ci}, rows.options());
+  const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)Co, (int)Ci, 1);
+  check(ucd_conv_wgrad(dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, (int)M, (int)Co, (int)Ci, 1, 0, 0, 1, dw.data_ptr(), nullptr, 0,
+                       workspace(rows, wsb, stream, 2), wsb, (ucd_stream_t)stream),
+        "ucd_conv_wgrad");
+  return dw;
+}
+
 // ---- wide 1x1 convolution as a row-matrix GEMM (ucd_amd/blocks.py::_Gemm1x1 is the Python twin) ------------------
 // y[M, Co] = rows[M, Ci] . w[Co, Ci]^T through ucd_gemm_bf16 (hipBLASLt, tuned once per shape); the weight gradient of a
 // long M is eight batched K-chunks + a sum (41 us against 96 for the best single-kernel candidate at M = 26136).
@@ -168,10 +209,11 @@ int64_t wgrad_split(int64_t M) {
 
 class Gemm1x1Node : public torch::autograd::Function<Gemm1x1Node> {
  public:
-  static at::Tensor forward(AutogradContext* ctx, at::Tensor rows, at::Tensor w4, int64_t stream) {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor rows, at::Tensor w4, int64_t stream, bool own_wg) {
     TORCH_CHECK(rows.dim() == 2 && rows.is_contiguous() && rows.scalar_type() == at::kBFloat16 && w4.dim() == 4 &&
                     w4.scalar_type() == at::kBFloat16 && w4.size(1) == rows.size(1) && w4.size(2) == 1 && w4.size(3) == 1,
                 "ucd gemm1x1 node: rows [M, Ci] bf16 contiguous and weight [Co, Ci, 1, 1] bf16 expected");
+    ctx->saved_data["own_wgrad"] = own_wg;
     const int64_t M = rows.size(0), Ci = rows.size(1), Co = w4.size(0);
     at::Tensor y = at::empty({M, Co}, rows.options());
     const size_t wsb = ucd_gemm_workspace_bytes();
@@ -201,7 +243,9 @@ class Gemm1x1Node : public torch::autograd::Function<Gemm1x1Node> {
     }
     if (ctx->needs_input_grad(1)) {
       const int64_t S = wgrad_split(M);
-      if (S > 1) {
+      if (ctx->saved_data["own_wgrad"].toBool() && own_wgrad_rows_ok(dy, rows)) {
+        dw = own_wgrad_rows(dy, rows, stream);
+      } else if (S > 1) {
         dw = at::bmm(dy.view({S, M / S, Co}).transpose(1, 2), rows.view({S, M / S, Ci})).sum(0);
       } else {
         dw = at::empty({Co, Ci}, rows.options());
@@ -211,11 +255,11 @@ class Gemm1x1Node : public torch::autograd::Function<Gemm1x1Node> {
       }
       dw = dw.as_strided(w4.sizes(), w4.strides());   // [Co, Ci, 1, 1] is one memory order in either format
     }
-    return {dx, dw, at::Tensor()};
+    return {dx, dw, at::Tensor(), at::Tensor()};
   }
 };
 
-at::Tensor gemm1x1(at::Tensor rows, at::Tensor w4, int64_t stream) { return Gemm1x1Node::apply(rows, w4, stream); }
+at::Tensor gemm1x1(at::Tensor rows, at::Tensor w4, int64_t stream, bool own_wg) { return Gemm1x1Node::apply(rows, w4, stream, own_wg); }
 
 // First 1x1 convolution of an identity-shortcut bottleneck block, together with the shortcut itself: returns (y, rows) so
 // that the block input has ONE consumer.  The backward then receives the shortcut's gradient next to dy and folds it
@@ -223,10 +267,11 @@ at::Tensor gemm1x1(at::Tensor rows, at::Tensor w4, int64_t stream) { return Gemm
 // [M, Ci] tensors afterwards (one 3-pass elementwise kernel per block, 24 blocks).
 class Gemm1x1SkipNode : public torch::autograd::Function<Gemm1x1SkipNode> {
  public:
-  static variable_list forward(AutogradContext* ctx, at::Tensor rows, at::Tensor w4, int64_t stream) {
+  static variable_list forward(AutogradContext* ctx, at::Tensor rows, at::Tensor w4, int64_t stream, bool own_wg) {
     TORCH_CHECK(rows.dim() == 2 && rows.is_contiguous() && rows.scalar_type() == at::kBFloat16 && w4.dim() == 4 &&
                     w4.scalar_type() == at::kBFloat16 && w4.size(1) == rows.size(1) && w4.size(2) == 1 && w4.size(3) == 1,
                 "ucd gemm1x1 skip node: rows [M, Ci] bf16 contiguous and weight [Co, Ci, 1, 1] bf16 expected");
+    ctx->saved_data["own_wgrad"] = own_wg;
     const int64_t M = rows.size(0), Ci = rows.size(1), Co = w4.size(0);
     at::Tensor y = at::empty({M, Co}, rows.options());
     const size_t wsb = ucd_gemm_workspace_bytes();
@@ -275,7 +320,9 @@ class Gemm1x1SkipNode : public torch::autograd::Function<Gemm1x1SkipNode> {
     }
     if (ctx->needs_input_grad(1) && dy.defined()) {
       const int64_t S = wgrad_split(M);
-      if (S > 1) {
+      if (ctx->saved_data["own_wgrad"].toBool() && own_wgrad_rows_ok(dy, rows)) {
+        dw = own_wgrad_rows(dy, rows, stream);
+      } else if (S > 1) {
         dw = at::bmm(dy.view({S, M / S, Co}).transpose(1, 2), rows.view({S, M / S, Ci})).sum(0);
       } else {
         dw = at::empty({Co, Ci}, rows.options());
@@ -285,12 +332,12 @@ class Gemm1x1SkipNode : public torch::autograd::Function<Gemm1x1SkipNode> {
       }
       dw = dw.as_strided(w4.sizes(), w4.strides());
     }
-    return {dx, dw, at::Tensor()};
+    return {dx, dw, at::Tensor(), at::Tensor()};
   }
 };
 
-std::vector<at::Tensor> gemm1x1_skip(at::Tensor rows, at::Tensor w4, int64_t stream) {
-  return Gemm1x1SkipNode::apply(rows, w4, stream);
+std::vector<at::Tensor> gemm1x1_skip(at::Tensor rows, at::Tensor w4, int64_t stream, bool own_wg) {
+  return Gemm1x1SkipNode::apply(rows, w4, stream, own_wg);
 }
 
 // ---- stride-1 convolution (3x3 with padding = dilation, or 1x1) whose input gradient runs on the FORWARD solver --------
@@ -314,13 +361,14 @@ class StrideOneConvNode : public torch::autograd::Function<StrideOneConvNode> {
   }
 
   static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt_,
-                            bool own_fwd, bool own_dgrad, int64_t stream) {
+                            bool own_fwd, bool own_dgrad, int64_t stream, bool own_wg) {
     const int64_t pad = d * (w.size(2) / 2);
     // wt = w.flip(2, 3).transpose(0, 1) in channels-last order when the caller keeps it cached (ucd_amd/master.py: one
     // batched kernel per optimiser step instead of a flip + copy per layer and step)
     ctx->save_for_backward({x, w, wt_.has_value() ? *wt_ : at::Tensor()});
     ctx->saved_data["d"] = d;
     ctx->saved_data["own_dgrad"] = own_dgrad;
+    ctx->saved_data["own_wgrad"] = own_wg;
     ctx->saved_data["stream"] = stream;
     if (own_fwd) return own3x3(x, w, d, stream);
     return at::conv2d(x, w, {}, {1, 1}, {pad, pad}, {d, d}, 1);
@@ -342,16 +390,23 @@ class StrideOneConvNode : public torch::autograd::Function<StrideOneConvNode> {
       }
     }
     if (ctx->needs_input_grad(1)) {
-      dw = std::get<1>(at::convolution_backward(dy, x, w, c10::nullopt, {1, 1}, {pad, pad}, {d, d}, false, {0, 0}, 1,
-                                                {false, true, false}));
+      const int64_t dil = w.size(2) == 3 ? d : 0;
+      at::Tensor dyc = dy;
+      if (ctx->saved_data["own_wgrad"].toBool() && dyc.scalar_type() == at::kBFloat16 && !dense_channels_last(dyc))
+        dyc = dyc.contiguous(at::MemoryFormat::ChannelsLast);
+      if (ctx->saved_data["own_wgrad"].toBool() && own_wgrad_ok(dyc, x, w, dil) && (dil == 0 || w.is_contiguous(at::MemoryFormat::ChannelsLast)))
+        dw = own_wgrad(dyc, x, w, dil, ctx->saved_data["stream"].toInt());
+      else
+        dw = std::get<1>(at::convolution_backward(dy, x, w, c10::nullopt, {1, 1}, {pad, pad}, {d, d}, false, {0, 0}, 1,
+                                                  {false, true, false}));
     }
-    return {dx, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
+    return {dx, dw, at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
 at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d, c10::optional<at::Tensor> wt, bool own_fwd, bool own_dgrad,
-                        int64_t stream) {
-  return StrideOneConvNode::apply(x, w, d, wt, own_fwd, own_dgrad, stream);
+                        int64_t stream, bool own_wg) {
+  return StrideOneConvNode::apply(x, w, d, wt, own_fwd, own_dgrad, stream, own_wg);
 }
 
 // ---- 1x1 convolution + training-mode ABN as ONE node ------------------------------------------------------
@@ -407,7 +462,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                c10::optional<at::Tensor> residual_, at::Tensor running_mean, at::Tensor running_var,
                                double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
                                int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
-                               c10::optional<at::Tensor> wflip_, bool own_dgrad, bool wgrad_conv, bool make_link,
+                               c10::optional<at::Tensor> wflip_, bool own_dgrad, int64_t wgrad_conv, bool make_link,
                                c10::optional<at::Tensor> lk_z_, c10::optional<at::Tensor> lk_buf_,
                                c10::optional<at::Tensor> lk_bias_, c10::optional<at::Tensor> lk_partial_,
                                c10::optional<at::Tensor> lk_flag_, int64_t lk_act, double lk_slope, int64_t lk_kind) {
@@ -420,7 +475,8 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     // (make_link with a residual), B the first convolution of an identity-shortcut block (with_skip); lk_bias is unused.
     // dilation = 0: 1x1 convolution; dilation >= 1: 3x3, stride 1, padding = dilation (implicit GEMM, taps = 9), weight in
     // channels-last memory order; wflip = w.flip(2, 3).transpose(0, 1) (channels-last; for a 1x1 layer the transposed
-    // weight [Ci, Co]) for the input gradient through the own kernel (own_dgrad); wgrad_conv: weight gradient by MIOpen
+    // weight [Ci, Co]) for the input gradient through the own kernel (own_dgrad); wgrad_conv: weight gradient by 0 the batched
+    // split-M library products, 1 MIOpen, 2 the own kernel (ucd_conv_wgrad; 3x3 layers: 2 or MIOpen)
     TORCH_CHECK(dense_channels_last(x) && x.scalar_type() == at::kBFloat16, "ucd conv+abn node: x must be dense channels-last bf16");
     const bool conv3 = dilation > 0;
     TORCH_CHECK(w4.dim() == 4 && w4.scalar_type() == at::kBFloat16 && w4.size(1) == x.size(1) &&
@@ -647,9 +703,13 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
           dx = at::conv2d(dz, wflip, {}, {1, 1}, {dilation, dilation}, {dilation, dilation}, 1);
         }
       }
-      if (ctx->needs_input_grad(1) && dz.defined())
-        dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {dilation, dilation}, {dilation, dilation}, false,
-                                                  {0, 0}, 1, {false, true, false}));
+      if (ctx->needs_input_grad(1) && dz.defined()) {
+        if (ctx->saved_data["wgrad_conv"].toInt() == 2 && own_wgrad_ok(dz, x, w4, dilation))
+          dw = own_wgrad(dz, x, w4, dilation, stream);
+        else
+          dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {dilation, dilation}, {dilation, dilation}, false,
+                                                    {0, 0}, 1, {false, true, false}));
+      }
       return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
               none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
@@ -696,7 +756,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         dx = dskip;
       }
     }
-    if (ctx->needs_input_grad(1) && dz.defined() && ctx->saved_data["wgrad_conv"].toBool()) {
+    if (ctx->needs_input_grad(1) && dz.defined() && ctx->saved_data["wgrad_conv"].toInt() == 2 && own_wgrad_ok(dz, x, w4, 0)) {
+      dw = own_wgrad(dz, x, w4, 0, stream);
+    } else if (ctx->needs_input_grad(1) && dz.defined() && ctx->saved_data["wgrad_conv"].toInt() == 1) {
       // narrow layers (<= 512 channels at 65^2 / 129^2): MIOpen's weight-gradient solver beats the split-M products
       dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {1, 1}, {0, 0}, {1, 1}, false, {0, 0}, 1,
                                                 {false, true, false}));
@@ -722,7 +784,7 @@ std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor w
                                        c10::optional<at::Tensor> residual, at::Tensor running_mean, at::Tensor running_var,
                                        double momentum, double eps, int64_t act, double slope, int64_t comm, int64_t world,
                                        int64_t stream, int64_t param_grad, bool with_skip, bool fused, int64_t dilation,
-                                       c10::optional<at::Tensor> wflip, bool own_dgrad, bool wgrad_conv, bool make_link,
+                                       c10::optional<at::Tensor> wflip, bool own_dgrad, int64_t wgrad_conv, bool make_link,
                                        c10::optional<at::Tensor> lk_z, c10::optional<at::Tensor> lk_buf,
                                        c10::optional<at::Tensor> lk_bias, c10::optional<at::Tensor> lk_partial,
                                        c10::optional<at::Tensor> lk_flag, int64_t lk_act, double lk_slope, int64_t lk_kind) {

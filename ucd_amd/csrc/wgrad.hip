@@ -1,0 +1,430 @@
+// Weight gradients of the stride-1 convolutions of the UCD student on the bf16 matrix cores (the
+// backward of modules/residual.py:57-73 conv1 / conv2 / conv3 / proj_conv and modules/deeplab.py:24-37 map_convs / red_conv):
+//
+//     dW[n][t][k] = sum_m dZ[m][n] * X[shift_t(m)][k]        n < N out channels, k < K in channels, t < taps (1 or 9)
+//
+// on channels-last maps: dZ is the [M = B*H*W][N] row matrix of the output gradient, X the [M][K] row matrix of the layer's
+// input, shift_t the pixel offset ((t/3 - 1) d, (t%3 - 1) d) of tap t of a 3x3 convolution with padding = dilation d (rows
+// that fall off the map contribute zero), and dW comes out in the weight's own channels-last order [N][kh][kw][K].
+//
+// The reduction runs over M, the SLOW index of both operands - the opposite of the forward product - so
+//   * both MFMA operands (8 consecutive reduction indices per lane) come from row-major [m][channel] LDS tiles through
+//     ds_read_b64_tr_b16 (hardware transpose: a 16-lane group reads a 4-row x 16-column block, lane i receives column i);
+//   * the output is small (N x taps K) and the reduction long (26 136 ... 399 384 rows): the rows are cut into chunks, every
+//     workgroup owns one (output tile, tap, chunk), writes an fp32 slab, and a second kernel adds the slabs in a fixed order
+//     (deterministic; float atomics would cap at 1.3 TB/s of added bytes and change bits from run to run).
+// Tiling: 4 waves as 2 x 2 over a BNO x BKO output tile (128 or 64 wide: the 64-channel layers), 64 reduction rows per step,
+// two LDS stages filled by LDS-DMA (buffer_load_dwordx4 ... lds: the 3x3 shift, the zero padding and the chunk's end are per-lane
+// SOURCE offsets - an out-of-range offset for rows that do not exist, which the descriptor's range check zero-fills), the fill
+// of step s+1 in flight under the 16 MFMAs of step s behind a counted vmcnt.  The LDS image is lane-linear, so the bank-conflict swizzle of the transposed reads sits on the
+// source address too: 256-byte rows store chunk c of row r at c ^ (((r & 3) << 2) | ((r >> 2) & 3)), 128-byte rows at
+// c ^ (((r >> 1) & 1) << 2) - the four rows of a transposed read then lie in four different 64-byte bank ranges.
+// Workgroup -> work: all tiles and taps of one row chunk sit on one XCD (ids congruent mod 8 share an L2), so a chunk's rows
+// of dZ and X leave HBM once and are re-read by its tiles from that L2.
+#include <type_traits>
+
+#include "common.h"
+
+namespace ucd {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __hip_bfloat16 bf16;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kThreads = 256;
+constexpr int kRows = 64;            // reduction rows per step
+
+struct WArgs {
+  const bf16* dZ; int ldz;
+  const bf16* X; int ldx;
+  int M, N, K;
+  int taps, H, W, dil;
+  int chunks, rows_per_chunk;
+  int tiles_n, tiles_k, ksplit;     // ksplit: k-tile groups of one chunk that go to different XCDs (large outputs, few chunks)
+  float* partial;                   // [chunks][N][taps * K]
+  float inv_w, inv_hw;
+};
+
+// slot of logical 16-byte chunk c of row r in an LDS image with SLOTS chunks per row (see the header comment)
+template <int SLOTS>
+__device__ __forceinline__ int swz_slot(int r, int c) {
+  return SLOTS == 16 ? (c ^ (((r & 3) << 2) | ((r >> 2) & 3))) : (c ^ (((r >> 1) & 1) << 2));
+}
+
+// exact m / d for 0 <= m < 2^22 and d < 2^15 from a float reciprocal and one correction step
+__device__ __forceinline__ int fdiv(int m, int d, float inv) {
+  int q = (int)((float)m * inv);
+  int r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) ++q;
+  return q;
+}
+
+typedef unsigned long long u64;
+union Frag { bf16x8 v; u64 h[2]; };
+
+// Transposed fragment reads of one 16-row group as inline asm: behind the builtin hipcc waits vmcnt(0) before the first LDS read
+// of a step (it cannot tell the stage being read from the stage the LDS-DMA in flight is filling) and so drains the prefetch
+// every step (found in the ISA; 416 TF/s).  An asm read is invisible to that bookkeeping, so its completion is counted by hand:
+// a counted lgkmcnt per group (mma_group: the reads of the NEXT group, issued behind the previous MFMAs into the other register
+// set, stay in flight).  Nothing else touches LDS or scalar memory between the first read of a stage and its last MFMA.
+template <int TNW, int TKW, int IMM_Y, int IMM_X>
+__device__ __forceinline__ void read_group(Frag (&fy)[TNW], Frag (&fx)[TKW], const unsigned (&yaddr)[TNW][2],
+                                           const unsigned (&xaddr)[TKW][2]) {
+#pragma unroll
+  for (int a = 0; a < TNW; ++a) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fy[a].h[0]) : "v"(yaddr[a][0]), "n"(IMM_Y));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fy[a].h[1]) : "v"(yaddr[a][1]), "n"(IMM_Y));
+  }
+#pragma unroll
+  for (int b = 0; b < TKW; ++b) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fx[b].h[0]) : "v"(xaddr[b][0]), "n"(IMM_X));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(fx[b].h[1]) : "v"(xaddr[b][1]), "n"(IMM_X));
+  }
+}
+
+// PENDING: transposed reads issued AFTER the ones this group consumes (they stay in flight: LDS returns in order)
+template <int TNW, int TKW, int PENDING>
+__device__ __forceinline__ void mma_group(f32x16 (&acc)[TNW][TKW], Frag (&fy)[TNW], Frag (&fx)[TKW]) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING) : "memory");
+  __builtin_amdgcn_sched_barrier(0);                   // no MFMA above the wait (cdna_hip_programming.md 5.4 rule 18)
+#pragma unroll
+  for (int a = 0; a < TNW; ++a)
+#pragma unroll
+    for (int b = 0; b < TKW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[a].v, fx[b].v, acc[a][b], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);                   // ... and the next reads stay behind these MFMAs
+}
+
+// the four 16-row groups of stage ST (byte offsets are compile-time immediates of the reads)
+template <int BNO, int BKO, int ST, int TNW, int TKW>
+__device__ __forceinline__ void compute_stage(f32x16 (&acc)[TNW][TKW], const unsigned (&yaddr)[TNW][2], const unsigned (&xaddr)[TKW][2]) {
+  constexpr int kStage = kRows * (BNO + BKO) * 2, RY = BNO * 2, RX = BKO * 2, B = ST * kStage;
+  Frag ay[TNW], ax[TKW], by[TNW], bx[TKW];
+  constexpr int NR = 2 * (TNW + TKW);                   // reads of one group
+  read_group<TNW, TKW, B + 0 * RY, B + 0 * RX>(ay, ax, yaddr, xaddr);
+  read_group<TNW, TKW, B + 16 * RY, B + 16 * RX>(by, bx, yaddr, xaddr);
+  mma_group<TNW, TKW, NR>(acc, ay, ax);
+  read_group<TNW, TKW, B + 32 * RY, B + 32 * RX>(ay, ax, yaddr, xaddr);
+  mma_group<TNW, TKW, NR>(acc, by, bx);
+  read_group<TNW, TKW, B + 48 * RY, B + 48 * RX>(by, bx, yaddr, xaddr);
+  mma_group<TNW, TKW, NR>(acc, ay, ax);
+  mma_group<TNW, TKW, 0>(acc, by, bx);
+}
+
+template <int BNO, int BKO, bool T9>
+__global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
+  constexpr int SY = BNO / 8, SX = BKO / 8;                 // 16-byte chunks per LDS row
+  constexpr int YB = kRows * BNO * 2, XB = kRows * BKO * 2;  // bytes of the two tiles of a stage
+  constexpr int kStage = YB + XB;
+  constexpr int CY = YB / 1024 / 4, CX = XB / 1024 / 4;      // LDS-DMA instructions per wave and tile
+  constexpr int TNW = BNO / 64, TKW = BKO / 64;              // 32-wide sub-tiles per wave
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+  // ---- which (chunk, tile, tap) ---------------------------------------------------------------------------------------
+  const int tiles_kg = p.tiles_k / p.ksplit;                 // k tiles of one group
+  const int per_group = p.tiles_n * tiles_kg * p.taps;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int group = (j / per_group) * 8 + xcd;
+  if (group >= p.chunks * p.ksplit) return;
+  const int chunk = group / p.ksplit, kpart = group - chunk * p.ksplit;
+  int rest = j % per_group;
+  const int tap = rest % p.taps; rest /= p.taps;
+  const int tn = rest % p.tiles_n, tk = kpart * tiles_kg + rest / p.tiles_n;
+  const int n0 = tn * BNO, k0 = tk * BKO;
+  const int mb = chunk * p.rows_per_chunk, me = min(p.M, mb + p.rows_per_chunk);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int dy = T9 ? (tap / 3 - 1) * p.dil : 0, dx = T9 ? (tap % 3 - 1) * p.dil : 0;
+  const int shift = dy * p.W + dx;
+  const int hw = p.H * p.W;
+
+  f32x16 acc[TNW][TKW];
+#pragma unroll
+  for (int a = 0; a < TNW; ++a)
+#pragma unroll
+    for (int b = 0; b < TKW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // ---- staging: lane l of instruction i of this wave lands on LDS row (wave * C + i) * RPI + l / SLOTS, slot l % SLOTS and
+  // fetches the logical chunk slot ^ f(row) of that row ------------------------------------------------------------------
+  constexpr int RPY = 64 / SY * 1, RPX = 64 / SX * 1;        // rows per 1 KiB instruction (4 for 256-byte rows, 8 for 128)
+  int yrow[CY], ycol[CY], xrow[CX], xcol[CX];
+#pragma unroll
+  for (int i = 0; i < CY; ++i) {
+    yrow[i] = (wave * CY + i) * RPY + lane / SY;
+    ycol[i] = n0 + swz_slot<SY>(yrow[i], lane % SY) * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < CX; ++i) {
+    xrow[i] = (wave * CX + i) * RPX + lane / SX;
+    xcol[i] = k0 + swz_slot<SX>(xrow[i], lane % SX) * 8;
+  }
+  // Rows that do not exist (past the chunk, or shifted off the map) fetch through an OUT-OF-RANGE offset of a buffer descriptor:
+  // the range check zero-fills the LDS bytes (tools/lds_dma_oob_probe.hip) - no branch around a load, no 64-bit select
+  const auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.dZ, 0, (int)((size_t)p.M * p.ldz * 2), 0x00020000);
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((size_t)p.M * p.ldx * 2), 0x00020000);
+  constexpr int kOOB = 0x7FFFFFF0;
+  auto fill = [&](int s, unsigned char* stage) {
+    const int m0 = mb + s * kRows;
+#pragma unroll
+    for (int i = 0; i < CY; ++i) {
+      const int m = m0 + yrow[i];
+      const int off = m < me ? (m * p.ldz + ycol[i]) * 2 : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lptr_t)(stage + (wave * CY + i) * 1024), 16, off, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < CX; ++i) {
+      const int m = m0 + xrow[i];
+      bool ok = m < me;
+      if (T9) {
+        const int pix = m - fdiv(m, hw, p.inv_hw) * hw;
+        const int y = fdiv(pix, p.W, p.inv_w), x = pix - y * p.W;
+        ok = ok && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+      }
+      const int off = ok ? ((m + shift) * p.ldx + xcol[i]) * 2 : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(stage + YB + (wave * CX + i) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  // ---- transposed fragment reads: byte offsets inside a 16-row group (independent of the group: see swz_slot) -----------
+  // lane = 32 h + 16 g + 4 q + pp: rows 4 h + q (+ 8 for the second read), columns 16 g + 4 pp .. + 3 of a 32-wide sub-tile
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  int yoff[TNW][2], xoff[TKW][2];
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi) {
+    const int row = 4 * h + q + 8 * hi;
+#pragma unroll
+    for (int a = 0; a < TNW; ++a) {
+      const int c = (wn * (BNO / 2) + a * 32 + 16 * g) / 8 + (pp >> 1);
+      yoff[a][hi] = row * (BNO * 2) + swz_slot<SY>(row, c) * 16 + 8 * (pp & 1);
+    }
+#pragma unroll
+    for (int b = 0; b < TKW; ++b) {
+      const int c = (wk * (BKO / 2) + b * 32 + 16 * g) / 8 + (pp >> 1);
+      xoff[b][hi] = YB + row * (BKO * 2) + swz_slot<SX>(row, c) * 16 + 8 * (pp & 1);
+    }
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned yaddr[TNW][2], xaddr[TKW][2];
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi) {
+#pragma unroll
+    for (int a = 0; a < TNW; ++a) yaddr[a][hi] = lds0 + yoff[a][hi];
+#pragma unroll
+    for (int b = 0; b < TKW; ++b) xaddr[b][hi] = lds0 + xoff[b][hi];
+  }
+
+  const int nsteps = (me - mb + kRows - 1) / kRows;
+  fill(0, smem);
+  // one step: {all waves done with the stage about to be refilled; issue the next fill; wait for THIS step's fill (counted:
+  // the next one stays in flight); barrier; 16 MFMAs}.  Unrolled by the two stages by hand - a runtime stage index makes the
+  // compiler keep two register assignments of the accumulators and copy all 64 between them on every loop edge.
+#define UCD_WG_STEP(s_, ST_)                                                                     \
+  {                                                                                              \
+    if (s_) __builtin_amdgcn_s_barrier();                                                        \
+    if ((s_) + 1 < nsteps) {                                                                     \
+      fill((s_) + 1, smem + (1 - ST_) * kStage);                                                 \
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CY + CX) : "memory");                            \
+    } else {                                                                                     \
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+    }                                                                                            \
+    __builtin_amdgcn_s_barrier();                                                                \
+    compute_stage<BNO, BKO, ST_, TNW, TKW>(acc, yaddr, xaddr);                                   \
+  }
+  for (int s = 0; s < nsteps; s += 2) {
+    UCD_WG_STEP(s, 0)
+    if (s + 1 < nsteps) UCD_WG_STEP(s + 1, 1)
+  }
+#undef UCD_WG_STEP
+
+  // ---- fp32 slab of this (chunk, tile, tap): lanes 0..31 of a register write 32 consecutive k (128 bytes) ---------------
+  const size_t ldp = (size_t)p.taps * p.K;
+  float* dst = p.partial + ((size_t)chunk * p.N + n0) * ldp + (size_t)tap * p.K + k0;
+#pragma unroll
+  for (int a = 0; a < TNW; ++a)
+#pragma unroll
+    for (int b = 0; b < TKW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = wn * (BNO / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dst[(size_t)n * ldp + wk * (BKO / 2) + b * 32 + (lane & 31)] = acc[a][b][r];
+      }
+}
+
+// dW (bf16) and / or dW32 (fp32, += when accumulate) = sum over the chunks' slabs in a fixed order.  A thread owns 8
+// consecutive outputs of one chunk lane; CL lanes (1, 4 or 16: small outputs cut into many chunks - 64 x 256 weights over 250
+// chunks would otherwise be eight workgroups walking 250 slabs one after the other) take chunks c = lane, lane + CL, ... and are
+// combined through LDS in lane order.
+template <int CL>
+__global__ __launch_bounds__(kThreads) void wgrad_sum_kernel(const float* __restrict__ partial, int chunks, size_t total,
+                                                            bf16* __restrict__ dW, float* __restrict__ dW32, int accumulate) {
+  constexpr int OG = kThreads / CL;                      // 8-output groups per workgroup
+  __shared__ float red[CL > 1 ? CL : 1][OG][9];
+  const int og = threadIdx.x % OG, cl = threadIdx.x / OG;
+  const size_t i = ((size_t)blockIdx.x * OG + og) * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < total) {
+    int c = cl;
+    for (; c + CL < chunks; c += 2 * CL) {               // two slabs (four loads) in flight
+      const float4 a0 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i);
+      const float4 a1 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(partial + (size_t)(c + CL) * total + i);
+      const float4 b1 = *reinterpret_cast<const float4*>(partial + (size_t)(c + CL) * total + i + 4);
+      s[0] += a0.x; s[1] += a0.y; s[2] += a0.z; s[3] += a0.w; s[4] += a1.x; s[5] += a1.y; s[6] += a1.z; s[7] += a1.w;
+      s[0] += b0.x; s[1] += b0.y; s[2] += b0.z; s[3] += b0.w; s[4] += b1.x; s[5] += b1.y; s[6] += b1.z; s[7] += b1.w;
+    }
+    if (c < chunks) {
+      const float4 a0 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i);
+      const float4 a1 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i + 4);
+      s[0] += a0.x; s[1] += a0.y; s[2] += a0.z; s[3] += a0.w; s[4] += a1.x; s[5] += a1.y; s[6] += a1.z; s[7] += a1.w;
+    }
+  }
+  if (CL > 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[cl][og][e] = s[e];
+    __syncthreads();
+    if (cl != 0) return;
+#pragma unroll
+    for (int l = 1; l < CL; ++l)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += red[l][og][e];
+  }
+  if (i >= total) return;
+  if (dW) {
+    Vec<bf16> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.set(e, s[e]);
+    o.store(dW + i);
+  }
+  if (dW32) {
+    float4* d = reinterpret_cast<float4*>(dW32 + i);
+    if (accumulate) {
+      const float4 o0 = d[0], o1 = d[1];
+      s[0] += o0.x; s[1] += o0.y; s[2] += o0.z; s[3] += o0.w; s[4] += o1.x; s[5] += o1.y; s[6] += o1.z; s[7] += o1.w;
+    }
+    d[0] = make_float4(s[0], s[1], s[2], s[3]);
+    d[1] = make_float4(s[4], s[5], s[6], s[7]);
+  }
+}
+
+struct Plan { int bno, bko, tiles_n, tiles_k, chunks, rows, ksplit; };
+
+// chunks: about `target` workgroups in all (two per CU), whole 64-row steps, at least 256 rows each; a multiple of 8 chunks
+// (one XCD each) where the output is small, else few chunks with the k tiles of a chunk split over the XCDs
+Plan make_plan(int M, int N, int K, int taps, int target) {
+  Plan pl;
+  pl.bno = N % 128 == 0 ? 128 : 64;
+  pl.bko = K % 128 == 0 ? 128 : 64;
+  pl.tiles_n = N / pl.bno; pl.tiles_k = K / pl.bko;
+  const int per_chunk = pl.tiles_n * pl.tiles_k * taps;
+  int chunks = target / per_chunk;
+  const int max_chunks = (M + 255) / 256;
+  if (chunks > max_chunks) chunks = max_chunks;
+  pl.ksplit = 1;
+  if (chunks >= 8) {
+    chunks = chunks / 8 * 8;
+  } else {
+    if (chunks < 1) chunks = 1;
+    while (chunks & (chunks - 1)) --chunks;                        // 1, 2, 4
+    int ks = 8 / chunks;
+    while (ks > 1 && pl.tiles_k % ks) ks >>= 1;
+    pl.ksplit = ks;
+  }
+  int rows = ceil_div(M, chunks);
+  rows = ceil_div(rows, kRows) * kRows;
+  pl.rows = rows;
+  pl.chunks = ceil_div(M, rows);
+  return pl;
+}
+
+// Workgroups aimed for (tools/wgrad_probe2.py on MI355X, B = 24): the 1x1 products are bound by the slab traffic
+// (chunks x |dW| x 4 bytes written and read back) - one workgroup per CU; the 9-tap products are MFMA work at low per-workgroup
+// efficiency - four per CU (two resident, two waiting) were fastest.  UCD_WGRAD_TARGET overrides (probes).
+int wgrad_target(int taps, int per_chunk) {
+  const char* e = getenv("UCD_WGRAD_TARGET");
+  const int v = e ? atoi(e) : 0;
+  if (v > 0) return v;
+  if (taps == 1) return per_chunk >= 64 ? 512 : 256;
+  return per_chunk <= 9 && taps == 9 ? 512 : 1024;
+}
+
+int plan_target(int N, int K, int taps) {
+  const int per_chunk = (N / (N % 128 == 0 ? 128 : 64)) * (K / (K % 128 == 0 ? 128 : 64)) * taps;
+  return wgrad_target(taps, per_chunk);
+}
+
+}  // namespace
+}  // namespace ucd
+
+using namespace ucd;
+
+extern "C" {
+
+size_t ucd_conv_wgrad_workspace_bytes(int M, int N, int K, int taps) {
+  if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64 || (taps != 1 && taps != 9)) return 0;
+  const Plan pl = make_plan(M, N, K, taps, plan_target(N, K, taps));
+  return (size_t)pl.chunks * N * taps * K * sizeof(float);
+}
+
+int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
+                   void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  static const char* fn = "ucd_conv_wgrad";
+  UCD_REQUIRE(dz && x && (dw || dw32) && workspace, UCD_EINVAL, "%s: NULL argument", fn);
+  UCD_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, UCD_EUNSUPPORTED, "%s: N (%d) and K (%d) must be multiples of 64", fn, N, K);
+  UCD_REQUIRE(taps == 1 || taps == 9, UCD_EINVAL, "%s: taps must be 1 or 9", fn);
+  UCD_REQUIRE(taps == 1 || (H > 0 && W > 0 && dilation >= 1 && (long long)M % ((long long)H * W) == 0 && H < 32768 && W < 32768),
+              UCD_EINVAL, "%s: the 3x3 form needs H, W, dilation and M = B*H*W", fn);
+  UCD_REQUIRE(M < (1 << 22), UCD_EUNSUPPORTED, "%s: M = %d rows exceed the index arithmetic of the 3x3 form (2^22)", fn, M);
+  UCD_REQUIRE((size_t)M * ld_dz * 2 < 0x7FFFFFF0u && (size_t)M * ld_x * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
+              "%s: operands beyond 2 GiB exceed the 32-bit offsets of the staging loads", fn);
+  UCD_REQUIRE(aligned16(dz) && aligned16(x) && (!dw || aligned16(dw)) && (!dw32 || aligned16(dw32)) && ld_dz % 8 == 0 && ld_x % 8 == 0 &&
+                  ld_dz >= N && ld_x >= K,
+              UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
+  const Plan pl = make_plan(M, N, K, taps, plan_target(N, K, taps));
+  const size_t total = (size_t)N * taps * K;
+  UCD_REQUIRE(workspace_bytes >= (size_t)pl.chunks * total * sizeof(float), UCD_EWORKSPACE, "%s: workspace too small", fn);
+  WArgs a;
+  a.dZ = (const bf16*)dz; a.ldz = ld_dz; a.X = (const bf16*)x; a.ldx = ld_x;
+  a.M = M; a.N = N; a.K = K; a.taps = taps; a.H = taps == 9 ? H : 1; a.W = taps == 9 ? W : M; a.dil = dilation;
+  a.chunks = pl.chunks; a.rows_per_chunk = pl.rows; a.tiles_n = pl.tiles_n; a.tiles_k = pl.tiles_k; a.ksplit = pl.ksplit;
+  a.partial = (float*)workspace;
+  a.inv_w = 1.f / (float)a.W; a.inv_hw = 1.f / ((float)a.H * (float)a.W);
+  const int groups = pl.chunks * pl.ksplit;
+  const int per_group = pl.tiles_n * (pl.tiles_k / pl.ksplit) * taps;
+  const int grid = ceil_div(groups, 8) * 8 * per_group;
+  const size_t lds = (size_t)2 * kRows * (pl.bno + pl.bko) * 2;
+  hipStream_t s = (hipStream_t)stream;
+#define UCD_WG_LAUNCH(BN_, BK_)                                                             \
+  {                                                                                         \
+    if (taps == 9) {                                                                        \
+      UCD_TRY_LDS((wgrad_kernel<BN_, BK_, true>), (int)lds);                                \
+      wgrad_kernel<BN_, BK_, true><<<grid, kThreads, lds, s>>>(a);                          \
+    } else {                                                                                \
+      UCD_TRY_LDS((wgrad_kernel<BN_, BK_, false>), (int)lds);                               \
+      wgrad_kernel<BN_, BK_, false><<<grid, kThreads, lds, s>>>(a);                         \
+    }                                                                                       \
+  }
+  if (pl.bno == 128 && pl.bko == 128) UCD_WG_LAUNCH(128, 128)
+  else if (pl.bno == 128) UCD_WG_LAUNCH(128, 64)
+  else if (pl.bko == 128) UCD_WG_LAUNCH(64, 128)
+  else UCD_WG_LAUNCH(64, 64)
+#undef UCD_WG_LAUNCH
+  int rc = check_launch(fn);
+  if (rc) return rc;
+  // chunk lanes of the sum: enough workgroups to fill the chip when the output is small and the chunks many
+  const size_t groups8 = total / 8;
+  if (pl.chunks >= 64 && groups8 <= (size_t)16 * 1024)
+    wgrad_sum_kernel<16><<<(unsigned)((groups8 + 15) / 16), kThreads, 0, s>>>((const float*)workspace, pl.chunks, total, (bf16*)dw, dw32, accumulate32);
+  else if (pl.chunks >= 16 && groups8 <= (size_t)64 * 1024)
+    wgrad_sum_kernel<4><<<(unsigned)((groups8 + 63) / 64), kThreads, 0, s>>>((const float*)workspace, pl.chunks, total, (bf16*)dw, dw32, accumulate32);
+  else
+    wgrad_sum_kernel<1><<<(unsigned)((groups8 + kThreads - 1) / kThreads), kThreads, 0, s>>>((const float*)workspace, pl.chunks, total, (bf16*)dw, dw32, accumulate32);
+  return check_launch(fn);
+}
+
+}  // extern "C"

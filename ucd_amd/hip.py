@@ -102,6 +102,8 @@ SIGNATURES = {
     "ucd_abn_reduce_partials": (_i, [_p, _i, _i, _p, _p, _p, _i, _p]),
     "ucd_conv1x1_wgrad_workspace_bytes": (_z, [_i, _i, _i]),
     "ucd_conv1x1_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "ucd_conv_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
     "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
     "ucd_sgd_chunk": (_i, []),
@@ -554,6 +556,25 @@ def conv1x1_wgrad(dy, a, dw, in_norm=None):
         _check(lib.ucd_conv1x1_wgrad(ptr(dy), dy.stride(0), ptr(a), a.stride(0), M, N, K, ptr(mean), ptr(scale), ptr(shift),
                                      act & ACT_MASK, float(slope), ptr(dw), ptr(ws), nbytes, stream()), "ucd_conv1x1_wgrad")
     return dw
+
+
+def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False):
+    """Weight gradient of a stride-1 convolution (ucd_conv_wgrad): ``dz`` [M, N] and ``x`` [M, K] bf16 row matrices ->
+    ``dw`` [N, taps * K] bf16 (channels-last weight order [N][kh][kw][K]) and / or ``dw32`` fp32 (+= when ``accumulate32``);
+    ``conv3 = (H, W, dilation)`` selects the 3x3 form over the [B, H, W, K] map behind ``x``."""
+    lib = load()
+    M, N = dz.shape
+    K = x.shape[1]
+    taps = 9 if conv3 is not None else 1
+    H, W, d = (int(conv3[0]), int(conv3[1]), int(conv3[2])) if conv3 is not None else (0, 0, 1)
+    nbytes = lib.ucd_conv_wgrad_workspace_bytes(M, N, K, taps)
+    ws = workspace(nbytes, dz.device, "wgrad")
+    # MFMA-bound for the 3x3 layers, HBM / L2-bound for the 1x1 layers: flop for one, algorithmic bytes for the other
+    work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * N + M * K)
+    with _timed("ucd_conv3x3_wgrad" if conv3 is not None else "ucd_conv1x1_wgrad", work):
+        _check(lib.ucd_conv_wgrad(ptr(dz), dz.stride(0), ptr(x), x.stride(0), M, N, K, taps, H, W, d, ptr(dw), ptr(dw32),
+                                  1 if accumulate32 else 0, ptr(ws), nbytes, stream()), "ucd_conv_wgrad")
+    return dw if dw is not None else dw32
 
 
 def transpose_bf16(src, dst):
