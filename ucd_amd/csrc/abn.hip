@@ -159,12 +159,14 @@ __global__ __launch_bounds__(kBlock) void abn_stats_kernel(const T* __restrict__
 // With FINALIZE the same block turns the two sums into the normalisation constants (one launch less per
 // layer than a separate finalize kernel).
 // MODE 0: sums only (and an optional second copy), 1: + finalize, 2: + pack [mean_r | M2_r] for the SyncBN gather
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int C,
-                                                              float* __restrict__ sums, FinalizeArgs fin,
-                                                              float* __restrict__ sums2 = nullptr,
-                                                              const float* __restrict__ sign_of = nullptr) {
-  __shared__ float lds[16][17];
+template <int MODE, int LANES = 16>
+__global__ __launch_bounds__(16 * LANES) void reduce_bands_kernel(const float* __restrict__ partial, int bands, int C,
+                                                                  float* __restrict__ sums, FinalizeArgs fin,
+                                                                  float* __restrict__ sums2 = nullptr,
+                                                                  const float* __restrict__ sign_of = nullptr) {
+  // LANES band-lanes per channel row (16, or 64 = 1024 threads when there are hundreds of bands / row tiles: the loop is a chain
+  // of dependent ~1 us round trips, 6-7 us per call with 16 lanes on 512 bands - and 220 such calls per step)
+  __shared__ float lds[LANES][17];
   const int kl = threadIdx.x & 15, lane = threadIdx.x >> 4;
   const int c = blockIdx.x * 8 + (kl & 7);
   const int k = (kl < 8 ? 0 : C) + c;   // row index inside a [2C] partial
@@ -172,20 +174,29 @@ __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __res
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < C) {
     int b = lane;
-    for (; b + 48 < bands; b += 64) {
+    for (; b + 3 * LANES < bands; b += 4 * LANES) {
       s0 += partial[(size_t)b * n + k];
-      s1 += partial[(size_t)(b + 16) * n + k];
-      s2 += partial[(size_t)(b + 32) * n + k];
-      s3 += partial[(size_t)(b + 48) * n + k];
+      s1 += partial[(size_t)(b + LANES) * n + k];
+      s2 += partial[(size_t)(b + 2 * LANES) * n + k];
+      s3 += partial[(size_t)(b + 3 * LANES) * n + k];
     }
-    for (; b < bands; b += 16) s0 += partial[(size_t)b * n + k];
+    for (; b < bands; b += LANES) s0 += partial[(size_t)b * n + k];
   }
   lds[lane][kl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
+  if (LANES > 16) {                      // 64 lanes -> 16 (fixed order), then the common tail
+    if (lane < 16) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < LANES / 16; ++i) t += lds[lane * (LANES / 16) + i][kl];
+      lds[lane * (LANES / 16)][kl] = t;
+    }
+    __syncthreads();
+  }
   if (lane == 0 && c < C) {
     float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) t += lds[i][kl];
+    for (int i = 0; i < 16; ++i) t += lds[i * (LANES / 16)][kl];
     // abs-gamma layers: the second row holds d weight = sign(weight) * sum dz*xhat (bwd_apply undoes the sign)
     if (sign_of && kl >= 8 && sign_of[c] < 0.f) t = -t;
     sums[k] = t;
@@ -206,6 +217,13 @@ __global__ __launch_bounds__(kBlock) void reduce_bands_kernel(const float* __res
     }
   }
 }
+
+// launch: 64 band-lanes (1024 threads) from 96 bands up
+#define UCD_REDUCE_BANDS(MODE, bands, ...)                                                        \
+  do {                                                                                             \
+    if ((bands) >= 96) reduce_bands_kernel<MODE, 64><<<ceil_div(C, 8), 1024, 0, s>>>(__VA_ARGS__);  \
+    else reduce_bands_kernel<MODE, 16><<<ceil_div(C, 8), 256, 0, s>>>(__VA_ARGS__);                \
+  } while (0)
 
 // SyncBN: Chan's combination of the per-rank (mean, M2) pairs (equal counts per rank) + the usual finalize.
 // gathered: [world][2C] = [mean_r | M2_r]; fin.count = world * m_local.
@@ -682,11 +700,11 @@ static int abn_stats_impl(const void* x, int ld_x, int dtype, int M, int C, cons
   }
   UCD_TRY(check_launch(fn));
   if (fin && fin->pack)
-    reduce_bands_kernel<2><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, *fin);
+    UCD_REDUCE_BANDS(2, g.gy, partial, g.gy, C, sums, *fin);
   else if (fin)
-    reduce_bands_kernel<1><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, *fin);
+    UCD_REDUCE_BANDS(1, g.gy, partial, g.gy, C, sums, *fin);
   else
-    reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{});
+    UCD_REDUCE_BANDS(0, g.gy, partial, g.gy, C, sums, FinalizeArgs{});
   return check_launch(fn);
 }
 
@@ -792,8 +810,7 @@ static int bwd_reduce_impl(const char* fn, const void* x, int ld_x, const void* 
   }
 #undef LAUNCH_RED
   UCD_TRY(check_launch(fn));
-  reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, s>>>(partial, g.gy, C, sums, FinalizeArgs{}, sums_copy,
-                                                           (act & UCD_NORM_ABS_GAMMA) ? weight : nullptr);
+  UCD_REDUCE_BANDS(0, g.gy, partial, g.gy, C, sums, FinalizeArgs{}, sums_copy, (act & UCD_NORM_ABS_GAMMA) ? weight : nullptr);
   return check_launch(fn);
 }
 
@@ -809,8 +826,8 @@ int ucd_abn_reduce_partials(const float* partial, int tiles, int C, float* sums,
                             int flags, ucd_stream_t stream) {
   static const char* fn = "ucd_abn_reduce_partials";
   UCD_REQUIRE(partial && sums && tiles > 0 && C > 0, UCD_EINVAL, "%s: bad arguments", fn);
-  reduce_bands_kernel<0><<<ceil_div(C, 8), kBlock, 0, (hipStream_t)stream>>>(partial, tiles, C, sums, FinalizeArgs{}, sums_copy,
-                                                                            (flags & UCD_NORM_ABS_GAMMA) ? weight : nullptr);
+  hipStream_t s = (hipStream_t)stream;
+  UCD_REDUCE_BANDS(0, tiles, partial, tiles, C, sums, FinalizeArgs{}, sums_copy, (flags & UCD_NORM_ABS_GAMMA) ? weight : nullptr);
   return check_launch(fn);
 }
 

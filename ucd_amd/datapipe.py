@@ -43,6 +43,51 @@ def target_lut(labels, labels_old, masking=True, data_masking="current"):
     return torch.tensor([inverted_order[x] if x in tmp_labels else masking_value for x in range(256)], dtype=torch.uint8)
 
 
+def ade_target_lut(labels, labels_old, masking=True, ignore_test_bg=False):
+    """uint8 [256] table of ``AdeSegmentationIncremental`` (dataset/ade.py:103-147): order ``[0] + labels_old + labels`` with the
+    zeros stripped from both lists, 255 kept by the re-ordering table; with ``masking`` only the step's own labels keep their
+    id - the background 0 and the ignore label 255 included go to the masking value (ade.py:139-141 tests ``x in self.labels``,
+    which holds neither), 0 or 255 with ``ignore_test_bg``."""
+    labels = [l for l in labels if l != 0]
+    labels_old = [l for l in labels_old if l != 0]
+    order = [0] + labels_old + labels
+    inverted = {label: order.index(label) for label in order}
+    masking_value = 255 if ignore_test_bg else 0
+    if ignore_test_bg:
+        inverted[0] = masking_value
+    inverted[255] = 255
+    keep = labels if masking else list(inverted)
+    return torch.tensor([inverted[x] if x in keep else masking_value for x in range(256)], dtype=torch.uint8)
+
+
+# raw Cityscapes labelIds -> the 19 training classes + void 0 (dataset/cityscape.py:49-66: np.digitize against -1 .. 33, then
+# the `_key` table): entry r is the class of raw id r; ids outside 0 .. 33 do not occur (the reference asserts)
+CITY_KEY = (0, 0, 0, 0, 0, 0, 0, 1, 2, 0, 0, 3, 4, 5, 0, 0, 0, 6, 0, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 0, 0, 17, 18, 19)
+
+
+def city_class_lut():
+    """uint8 [256]: raw labelId -> class index 0 .. 19 (``CitySegmentation._class_to_index``); the reference's table starts at
+    raw id -1 (``_mapping = range(-1, 34)``, digitize with right=True), so raw id r reads ``_key[r + 1]``... which is what
+    CITY_KEY[r] holds for r >= 0 after dropping the -1 entry."""
+    lut = torch.zeros(256, dtype=torch.uint8)
+    lut[:len(CITY_KEY)] = torch.tensor(CITY_KEY, dtype=torch.uint8)
+    return lut
+
+
+def city_target_lut(labels, labels_old, masking=True, train=True):
+    """uint8 [256] table of ``CitySegmentationIncremental`` over CLASS indices (dataset/cityscape.py:123-152): labels get a
+    leading 0, order ``[0] + labels_old + labels``, the masking value is 0 in training and 255 otherwise and 255 itself maps to
+    it; with ``masking`` only ``[0] + labels + [255]`` keep their (re-ordered) id."""
+    labels = [l for l in labels if l != 0]
+    labels_old = [l for l in labels_old if l != 0]
+    order = [0] + labels_old + labels
+    masking_value = 0 if train else 255
+    inverted = {label: order.index(label) for label in order}
+    inverted[255] = masking_value
+    keep = ([0] + labels + [255]) if masking else list(inverted)
+    return torch.tensor([inverted[x] if x in keep else masking_value for x in range(256)], dtype=torch.uint8)
+
+
 def random_resized_crop_params(height, width, scale=(0.5, 2.0), ratio=(3. / 4., 4. / 3.)):
     """``RandomResizedCrop.get_params`` (transform.py:505-540): (i, j, h, w), same draws from ``random`` in the same order."""
     area = width * height

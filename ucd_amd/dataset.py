@@ -14,8 +14,9 @@ re-ordering - split where the hardware wants it:
   on the host with ``num_workers=0`` (37 img/s measured against 142 846 on the device, tests/diag/datapipe_bench.py).
 
 Validation with ``--crop_val`` (``Resize`` + ``CenterCrop``, run.py:58-65) resizes on the host with Pillow (exact by
-construction) and normalises on the device.  ADE20K / Cityscapes have the same structure (dataset/ade.py, cityscape.py) and
-are not wired.
+construction) and normalises on the device.  ADE20K (dataset/ade.py) and Cityscapes (dataset/cityscape.py) follow the same
+split: their listings, filters and label tables are mirrored here (the Cityscapes raw-id -> class table is composed with the
+step's table into ONE device gather).  ``DeviceLoader`` puts the decode into DataLoader worker processes.
 """
 from __future__ import annotations
 
@@ -134,6 +135,154 @@ class VOCSegmentationIncremental(data.Dataset):
 
     def __len__(self):
         return len(self.indices)
+
+
+class _Incremental(data.Dataset):
+    """What the three incremental datasets share (dataset/{voc,ade,cityscape}.py): filter the full listing by the step's labels
+    (index file when present), keep the step's label table for the device, hand out raw uint8 pairs."""
+
+    def _select(self, full, labels, labels_old, idxs_path, overlap):
+        if idxs_path is not None and os.path.exists(idxs_path):
+            return np.load(idxs_path).tolist()
+        idxs = filter_images(full, labels, labels_old, overlap=overlap)
+        if idxs_path is not None and (not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0):
+            _save_index_file(idxs_path, idxs)
+        return idxs
+
+    def __getitem__(self, index):
+        img, lab = self.full[self.indices[index]]
+        return torch.from_numpy(img), torch.from_numpy(lab)
+
+    def __len__(self):
+        return len(self.indices)
+
+
+class AdeSegmentation(data.Dataset):
+    """File listing of the reference's ``AdeSegmentation`` (dataset/ade.py:38-58): every file of
+    ``ADEChallengeData2016/images/{training,validation}`` in sorted order, annotation = same name with ``png``."""
+
+    def __init__(self, root, train=True, transform=None):
+        ade_root = os.path.join(os.path.expanduser(root), "ADEChallengeData2016")
+        split = "training" if train else "validation"
+        image_folder = os.path.join(ade_root, "images", split)
+        annotation_folder = os.path.join(ade_root, "annotations", split)
+        if not os.path.isdir(image_folder):
+            raise RuntimeError(f"Dataset not found or corrupted. at location = {image_folder}")
+        self.images = [(os.path.join(image_folder, x), os.path.join(annotation_folder, x[:-3] + "png"))
+                       for x in sorted(os.listdir(image_folder))]
+
+    def __getitem__(self, index):
+        return _open_rgb(self.images[index][0]), _open_label(self.images[index][1])
+
+    def label(self, index):
+        return _open_label(self.images[index][1])
+
+    def __len__(self):
+        return len(self.images)
+
+
+class AdeSegmentationIncremental(_Incremental):
+    """``AdeSegmentationIncremental(root, train, transform, labels, labels_old, idxs_path, masking, overlap, data_masking,
+    ignore_test_bg)`` (dataset/ade.py:78-175); ``transform`` accepted and ignored (device batch transform), ``self.lut`` the
+    step's label table (``datapipe.ade_target_lut``)."""
+
+    def __init__(self, root, train=True, transform=None, labels=None, labels_old=None, idxs_path=None, masking=True,
+                 overlap=True, data_masking="current", ignore_test_bg=False, **kwargs):
+        self.full, self.train = AdeSegmentation(root, train), train
+        self.labels, self.labels_old = [], []
+        if labels is not None:
+            labels = [l for l in labels if l != 0]
+            labels_old = [l for l in (labels_old or []) if l != 0]
+            assert not any(l in labels_old for l in labels), "labels and labels_old must be disjoint sets"
+            self.labels, self.labels_old, self.order = labels, labels_old, [0] + labels_old + labels
+            self.indices = self._select(self.full, labels, labels_old, idxs_path, overlap)
+            self.lut = datapipe.ade_target_lut(labels, labels_old, masking=masking, ignore_test_bg=ignore_test_bg)
+        else:
+            self.indices = list(range(len(self.full)))
+            self.lut = torch.arange(256, dtype=torch.uint8)
+
+
+class CitySegmentation(data.Dataset):
+    """File listing of ``CitySegmentation`` (dataset/cityscape.py:34-47, get_city_pairs :166-203): ``os.walk`` over
+    ``Cityscapes/leftImg8bit/<split>``, every ``*.png`` whose ``gtFine/<split>/<city>/*_gtFine_labelIds.png`` exists, in walk
+    order.  Items are the raw uint8 image and the RAW labelIds map; ``label(i)`` returns the class-index map the reference's
+    ``_class_to_index`` makes (what ``filter_images`` looks at)."""
+
+    def __init__(self, root, train=True):
+        city_root = os.path.join(os.path.expanduser(root), "Cityscapes")
+        split = "train" if train else "val"
+        img_folder, mask_folder = os.path.join(city_root, "leftImg8bit/" + split), os.path.join(city_root, "gtFine/" + split)
+        self.images, self.mask_paths = [], []
+        for r, _dirs, files in os.walk(img_folder):
+            for filename in files:
+                if filename.endswith(".png"):
+                    imgpath = os.path.join(r, filename)
+                    maskpath = os.path.join(mask_folder, os.path.basename(os.path.dirname(imgpath)),
+                                            filename.replace("leftImg8bit", "gtFine_labelIds"))
+                    if os.path.isfile(imgpath) and os.path.isfile(maskpath):
+                        self.images.append(imgpath)
+                        self.mask_paths.append(maskpath)
+        if len(self.images) == 0:
+            raise RuntimeError("Found 0 images in subfolders of: " + city_root + "\n")
+        self._class_lut = datapipe.city_class_lut().numpy()
+
+    def __getitem__(self, index):
+        return _open_rgb(self.images[index]), _open_label(self.mask_paths[index])
+
+    def label(self, index):
+        raw = _open_label(self.mask_paths[index])
+        assert raw.max() <= 33, "Cityscapes labelIds are 0 .. 33 (dataset/cityscape.py:58-62 asserts the same)"
+        return self._class_lut[raw]
+
+    def __len__(self):
+        return len(self.images)
+
+
+class CitySegmentationIncremental(_Incremental):
+    """``CitySegmentationIncremental(root, train, transform, labels, labels_old, idxs_path, masking, overlap)``
+    (dataset/cityscape.py:103-163).  ``self.lut`` maps RAW labelIds straight to the step's ids: the class table composed with
+    the step table, one gather on the device."""
+
+    def __init__(self, root, train=True, transform=None, labels=None, labels_old=None, idxs_path=None, masking=True,
+                 overlap=True, **kwargs):
+        self.full, self.train = CitySegmentation(root, train), train
+        self.labels, self.labels_old = [], []
+        if labels is not None:
+            labels = [l for l in labels if l != 0]
+            labels_old = [l for l in (labels_old or []) if l != 0]
+            assert not any(l in labels_old for l in labels), "labels and labels_old must be disjoint sets"
+            self.labels, self.labels_old, self.order = [0] + labels, [0] + labels_old, [0] + labels_old + labels
+            self.indices = self._select(self.full, labels, labels_old, idxs_path, overlap)
+            step = datapipe.city_target_lut(labels, labels_old, masking=masking, train=train)
+            self.lut = step[datapipe.city_class_lut().long()]
+        else:
+            self.indices = list(range(len(self.full)))
+            self.lut = datapipe.city_class_lut()
+
+
+def _identity(samples):
+    return samples
+
+
+class DeviceLoader:
+    """The train / validation loader: ``torch.utils.data.DataLoader`` worker PROCESSES decode (Pillow) and hand raw uint8 pairs
+    through shared, pinned memory; the batch transform runs in the main process on the device (``DeviceBatcher``) - no HIP call
+    ever happens in a worker.  The random crop / flip parameters are drawn in the main process in sample order, i.e. the same
+    ``random`` sequence as the reference's ``num_workers=0`` loader (argparser.py:53).  Iterating yields what the trainer
+    takes; ``sampler`` / ``__len__`` as the reference's loader exposes them (train.py:93, run.py:189)."""
+
+    def __init__(self, dataset, batch_size, sampler, batcher, num_workers=0, drop_last=False, prefetch_factor=4):
+        kw = dict(persistent_workers=True, prefetch_factor=prefetch_factor) if num_workers > 0 else {}
+        self.loader = data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, num_workers=num_workers, drop_last=drop_last,
+                                      collate_fn=_identity, pin_memory=num_workers > 0, **kw)
+        self.sampler, self.batcher, self.batch_size = sampler, batcher, batch_size
+
+    def __iter__(self):
+        for samples in self.loader:
+            yield self.batcher(samples)
+
+    def __len__(self):
+        return len(self.loader)
 
 
 class DeviceBatcher:

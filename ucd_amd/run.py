@@ -98,6 +98,91 @@ def load_step_checkpoint(opts, model, model_old, state, device):
     model_old.eval()
 
 
+def _incremental_datasets():
+    from .dataset import AdeSegmentationIncremental, CitySegmentationIncremental, VOCSegmentationIncremental
+    return {"voc": VOCSegmentationIncremental, "ade": AdeSegmentationIncremental, "city": CitySegmentationIncremental}
+
+
+class _Lazy(dict):
+    def __missing__(self, key):
+        self.update(_incremental_datasets())
+        if key not in self:
+            raise NotImplementedError(key)                       # run.py:84-85
+        return self[key]
+
+
+DATASETS = _Lazy()
+
+
+def loader_workers(opts, world_size):
+    """Decode processes per rank.  The reference's default is 0 (argparser.py:53: decode + transform in the training process,
+    ~37 img/s - it cannot feed one GPU); ``--num_workers N`` is honoured, and 0 with real data means "enough": the host's
+    cores shared between the ranks, at most 16 (profiles/r03_loader_bench.txt: 8 workers decode ~3x what the step consumes)."""
+    if opts.num_workers > 0:
+        return opts.num_workers
+    return max(1, min(16, (os.cpu_count() or 8) // max(1, world_size)))
+
+
+def get_dataset(opts, device, world_size, rank, labels, labels_old):
+    """The reference's ``get_dataset`` + loader construction (run.py:46-113, 150-164) on the device data pipeline: returns
+    (train_loader, val_dst or None, val_loader_of(dataset) -> loader, real).  ``--data_root synthetic`` - and only that - gives
+    the closed-form synthetic batches; a root without the dataset's directory raises like the reference's classes."""
+    real = opts.data_root != "synthetic"
+    if not real:
+        train_dst = SyntheticSegmentation(24 * 8, opts.crop_size, [l for l in labels if l != 0] or [1], seed=opts.step)
+        sampler = torch.utils.data.distributed.DistributedSampler(train_dst, num_replicas=world_size, rank=rank)
+        train_loader = torch.utils.data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler,
+                                                   num_workers=opts.num_workers, drop_last=True)
+
+        def val_loader_of(dst):
+            return torch.utils.data.DataLoader(
+                dst, batch_size=opts.batch_size if opts.crop_val else 1, num_workers=opts.num_workers,
+                sampler=torch.utils.data.distributed.DistributedSampler(dst, num_replicas=world_size, rank=rank, shuffle=False))
+        return train_loader, None, val_loader_of, False
+    marker = {"voc": "splits", "ade": "ADEChallengeData2016", "city": "Cityscapes"}.get(opts.dataset)
+    if marker is None:
+        raise NotImplementedError(opts.dataset)
+    if not os.path.isdir(os.path.join(opts.data_root, marker)):
+        # dataset/voc.py:58-59: a mistyped or unmounted root must not train (and checkpoint) on synthetic batches
+        raise RuntimeError(f"Dataset not found or corrupted. at location = {opts.data_root} (no {marker}/ directory; pass "
+                           "--data_root synthetic for the closed-form synthetic batches)")
+    if device.type != "cuda":
+        raise RuntimeError("the device data pipeline needs a GPU (there is no CPU fallback)")
+    from .dataset import DeviceBatcher, DeviceLoader
+    dataset = DATASETS[opts.dataset]
+    _, _, path_base = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
+    path_base += "-ov" if opts.overlap else ""
+    os.makedirs(path_base, exist_ok=True)
+    train_dst = dataset(opts.data_root, train=True, labels=list(labels), labels_old=list(labels_old),
+                        idxs_path=path_base + f"/train-{opts.step}.npy", masking=not opts.no_mask, overlap=opts.overlap)
+    train_lut = train_dst.lut
+    workers = loader_workers(opts, world_size)
+    collate_train = DeviceBatcher(device, opts.crop_size, train_lut, train=True)
+    val_dst = None
+    if not opts.no_cross_val:
+        # run.py:95-97: the validation subset is a random split of the TRAINING set, so it goes through the training transform
+        # (random crop to crop_size + flip) - batches of opts.batch_size crops
+        train_len = int(0.8 * len(train_dst))
+        train_dst, val_dst = torch.utils.data.random_split(train_dst, [train_len, len(train_dst) - train_len])
+        cross_val_batcher = collate_train
+    else:
+        val_dst = dataset(opts.data_root, train=False, labels=list(labels), labels_old=list(labels_old),
+                          idxs_path=path_base + f"/val-{opts.step}.npy", masking=not opts.no_mask, overlap=True)
+        cross_val_batcher = None
+    sampler = torch.utils.data.distributed.DistributedSampler(train_dst, num_replicas=world_size, rank=rank)
+    train_loader = DeviceLoader(train_dst, opts.batch_size, sampler, collate_train, num_workers=workers, drop_last=True)
+
+    def val_loader_of(dst):
+        lut = dst.dataset.lut if hasattr(dst, "dataset") else dst.lut
+        batcher = cross_val_batcher if (cross_val_batcher is not None and hasattr(dst, "dataset")) else \
+            DeviceBatcher(device, opts.crop_size, lut, train=False, crop=opts.crop_val)
+        full_size = batcher is not cross_val_batcher and not opts.crop_val
+        return DeviceLoader(dst, 1 if full_size else opts.batch_size,
+                            torch.utils.data.distributed.DistributedSampler(dst, num_replicas=world_size, rank=rank, shuffle=False),
+                            batcher, num_workers=min(workers, 4))
+    return train_loader, val_dst, val_loader_of, True
+
+
 def main(opts):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", opts.MASTER_PORT)
@@ -119,47 +204,7 @@ def main(opts):
 
     classes = tasks.get_per_task_classes(opts.dataset, opts.task, opts.step)
     labels, labels_old, _ = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
-    real = opts.data_root != "synthetic"
-    if real and not os.path.isdir(os.path.join(opts.data_root, "splits")):
-        # dataset/voc.py:58-59: a mistyped or unmounted root must not train (and checkpoint) on synthetic batches
-        raise RuntimeError(f"Dataset not found or corrupted. at location = {opts.data_root} (no splits/ directory; pass "
-                           "--data_root synthetic for the closed-form synthetic batches)")
-    if real and opts.dataset != "voc":
-        raise NotImplementedError("real-data loading is wired for --dataset voc (ucd_amd/dataset.py); ADE20K and Cityscapes "
-                                  "share its structure and are not wired - use --data_root synthetic")
-    val_dst = None
-    collate_train = collate_val = None
-    if real:
-        # the reference's get_dataset (run.py:46-113): index files under data/voc/<task>[-ov]/, masking / overlap flags; host
-        # decode, batch transform on the device (collate_fn), so num_workers must stay 0 (device work in the main process)
-        from .dataset import DeviceBatcher, VOCSegmentationIncremental
-        _, _, path_base = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
-        path_base += "-ov" if opts.overlap else ""
-        os.makedirs(path_base, exist_ok=True)
-        train_dst = VOCSegmentationIncremental(opts.data_root, train=True, labels=list(labels), labels_old=list(labels_old),
-                                               idxs_path=path_base + f"/train-{opts.step}.npy", masking=not opts.no_mask,
-                                               overlap=opts.overlap)
-        if not opts.no_cross_val:
-            train_len = int(0.8 * len(train_dst))
-            train_dst, val_dst = torch.utils.data.random_split(train_dst, [train_len, len(train_dst) - train_len])
-            lut = train_dst.dataset.lut
-        else:
-            val_dst = VOCSegmentationIncremental(opts.data_root, train=False, labels=list(labels), labels_old=list(labels_old),
-                                                 idxs_path=path_base + f"/val-{opts.step}.npy", masking=not opts.no_mask,
-                                                 overlap=True)
-            lut = train_dst.lut
-        if device.type != "cuda":
-            raise RuntimeError("the device data pipeline needs a GPU (there is no CPU fallback)")
-        collate_train = DeviceBatcher(device, opts.crop_size, lut, train=True)
-        collate_val = DeviceBatcher(device, opts.crop_size, lut, train=False, crop=opts.crop_val)
-        workers = 0
-    else:
-        n_train = 24 * 8
-        train_dst = SyntheticSegmentation(n_train, opts.crop_size, [l for l in labels if l != 0] or [1], seed=opts.step)
-        workers = opts.num_workers
-    sampler = torch.utils.data.distributed.DistributedSampler(train_dst, num_replicas=world_size, rank=rank)
-    train_loader = torch.utils.data.DataLoader(train_dst, batch_size=opts.batch_size, sampler=sampler, num_workers=workers,
-                                               drop_last=True, collate_fn=collate_train)
+    train_loader, val_dst, val_loader_of, real = get_dataset(opts, device, world_size, rank, labels, labels_old)
     model, model_old = build_models(opts, device, classes)
     optimizer = make_optimizer(opts, model)
     scheduler = PolyLR(optimizer, max_iters=opts.epochs * len(train_loader), power=opts.lr_power)
@@ -182,10 +227,7 @@ def main(opts):
     seen = [l for l in (list(labels_old) + list(labels)) if l != 0] or [1]
     if val_dst is None:
         val_dst = SyntheticSegmentation(max(2 * opts.batch_size, 2), opts.crop_size, seen, seed=1000 + opts.step)
-    val_loader = torch.utils.data.DataLoader(
-        val_dst, batch_size=opts.batch_size if opts.crop_val else 1,
-        sampler=torch.utils.data.distributed.DistributedSampler(val_dst, num_replicas=world_size, rank=rank, shuffle=False),
-        num_workers=workers, collate_fn=collate_val)
+    val_loader = val_loader_of(val_dst)
     val_metrics = StreamSegMetrics(n_classes)
 
     cur_epoch, best_score = 0, 0.0
@@ -219,15 +261,12 @@ def main(opts):
     dist.barrier()
     if real:
         # final pass over the test split with every class seen so far (run.py:108-111, 340-372)
-        from .dataset import DeviceBatcher, VOCSegmentationIncremental
         image_set = "train" if opts.val_on_trainset else "val"
-        labels_cum = list(labels_old) + list(labels)
-        test_dst = VOCSegmentationIncremental(opts.data_root, train=opts.val_on_trainset, labels=labels_cum,
-                                              idxs_path=path_base + f"/test_on_{image_set}-{opts.step}.npy")
-        test_loader = torch.utils.data.DataLoader(
-            test_dst, batch_size=opts.batch_size if opts.crop_val else 1, num_workers=0,
-            sampler=torch.utils.data.distributed.DistributedSampler(test_dst, num_replicas=world_size, rank=rank, shuffle=False),
-            collate_fn=DeviceBatcher(device, opts.crop_size, test_dst.lut, train=False, crop=opts.crop_val))
+        _, _, path_base = tasks.get_task_labels(opts.dataset, opts.task, opts.step)
+        path_base += "-ov" if opts.overlap else ""
+        test_dst = DATASETS[opts.dataset](opts.data_root, train=opts.val_on_trainset, labels=list(labels_old) + list(labels),
+                                          idxs_path=path_base + f"/test_on_{image_set}-{opts.step}.npy")
+        test_loader = val_loader_of(test_dst)
         model.eval()
         val_loss, val_score, _ = trainer.validate(loader=test_loader, metrics=val_metrics, logger=logger)
         logger.info(f"*** End of Test, Total Loss={float(val_loss[0]) + float(val_loss[1])}, Class Loss={float(val_loss[0])},"
