@@ -367,7 +367,19 @@ def _run_golden_step(gname, dataset, task, step, seed_state, crop, new_ids, extr
     for k in g:
         if k.startswith("grad_abs::"):
             n = k.split("::")[1]
-            assert params[n].grad.double().abs().sum().item() == pytest.approx(float(g[k]), rel=grads_rel), n   # see module docstring
+            got = params[n].grad.double().abs().sum().item()
+            if tol > 1e-3 and n.startswith("body."):
+                # bf16: the backward through 33 train-mode blocks of a random-weight network multiplies rounding differences
+                # (the mirror image of BF16_TRAIN_LOGITS_L2): the SAME step with one kernel switched (UCD_BLOCK_LINK, UCD_OWN_WGRAD,
+                # UCD_BWD_LINK, UCD_FUSED_CONV1X1 = 0) or simply run again moves these abs-sums between 0.69 and 1.26 of the fp32
+                # golden (tests/diag/bf16_grad_diag.py, profiles/r03_bf16_grad_diag.txt), while the head's stay within 3 % -
+                # the body gradients are held to the order of magnitude here and to 1e-2 / 2.5e-2 per block by the bench-shape
+                # chain tests (tests/test_conv1x1_fused_gpu.py::test_bench_shape_block_chain..., slope 1)
+                assert 0.5 < got / float(g[k]) < 2.0, (n, got, float(g[k]))
+            else:
+                # bf16 head parameters: 3 % on the convolutions / red_bn / classifier; the image-pooling branch's norm sees B values
+                # per channel (two at B = 2: x-hat is +-1 whatever the input), its scale's gradient moved 9 % on the 2 x 768^2 case
+                assert got == pytest.approx(float(g[k]), rel=grads_rel if tol <= 1e-3 else 0.15), n   # see module docstring
     return r, g
 
 
@@ -393,9 +405,8 @@ BF16_TOL = 1e-2      # --opt_level O1 (bf16 activations, fp16 contrastive operan
 # with every stored map rounded to bf16 - profiles/r03_bf16_layer_probe.txt).  The frozen teacher (running statistics: no mean
 # removal) holds 1e-2, the losses (averages over 5e5 pixels) hold 1e-2; the train-mode logits get the measured bound.
 BF16_TRAIN_LOGITS_L2 = 0.12      # measured 5.3 % (VOC 2 x 513^2), 3.2 % (ADE 3 x 512^2), 9.8 % (Cityscapes 2 x 768^2)
-# Gradient abs-sums in bf16: the leaky-ReLU branch flips (tests/test_conv1x1_fused_gpu.py::test_bench_shape_block_chain...: 7 % per
-# block on the input gradient) add to a weight gradient in quadrature, which INFLATES its abs-sum - measured +16-17 % on the first
-# and the last convolution of the body; bound 25 %.
+# Gradient abs-sums in bf16: head parameters within 15 % of the fp32 golden (3 % measured but for the B-sample pooling norm); body parameters within a factor of two (see the
+# comment at the assertion in _run_golden_step: chaotic amplification of rounding through the random-weight body's backward).
 
 
 def test_bf16_step_at_513_calibrated_checkpoint_within_1e2_of_the_reference():
