@@ -18,6 +18,9 @@ pytestmark = pytest.mark.gpu
     (2, 151, 101, 8, 128, True),     # ADE 100-50
     (2, 21, 16, 9, 129, False),      # cross entropy only
     (2, 21, 1, 9, 129, False),       # step 0: plain cross entropy (old_cl = 1)
+    (3, 151, 101, 32, 512, True),    # ADE 100-50 at the per-rank shape of configs[3] (the many-class kernel at full size)
+    (2, 41, 27, 11, 173, True),      # many-class kernel: class counts off the 4-grid, non-integer scale, ragged tiles
+    (2, 151, 1, 8, 128, False),      # many-class kernel without a teacher (ADE step 0)
 ])
 def test_fused_seg_losses_vs_oracle(B, Ctot, K, h, H, with_kd):
     from ucd_amd.loss import fused_seg_losses

@@ -324,6 +324,235 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   }
 }
 
+// ---- the same losses for MANY classes (ADE20K: 151 student / 101 teacher classes; any Ctot the LDS holds) ----------------------
+// The generic form above (CT == 0) re-interpolates every logit in each of its passes and adds every pixel's gradient to LDS with
+// four float atomics per class - 604 contended LDS atomics and ~900 exponentials per pixel at 151 classes: 4.8 ms for ONE rank's
+// 3 x 512^2 batch (26 % of that step; bench.py --dataset ade --task 100-50 --global_batch 3).  Here:
+//   * a thread owns one pixel column of RW rows; phase A walks all classes of a row twice (maxima, then sums: student e_c and -
+//     for the old classes - teacher te_c in the same pass; exp(z_c - LSE_S) is e_c / sum_S e, so no exponential is evaluated
+//     for a ratio) and keeps 8 constants per row in registers; the loss values need nothing else:
+//         kd_pix = q_0 (LSE_bn - den) + (sum_{1<=c<K} te_c z_c - den sum_{1<=c<K} te_c) / sum te;
+//   * phase B walks the classes again in chunks of 16: g_c = e_c (a_all - a_old [c<K] - b_bn [c in bkg/new]) - hot [c == label]
+//     - b_q te_c [1<=c<K] from those constants, accumulated in 2 x 16 registers over the rows that share a low-resolution row
+//     pair and flushed with one LDS atomic per class and corner (RW-fold fewer atomics, kRepW copies against column conflicts);
+//   * logits are read from LDS four classes at a time (rows padded to a multiple of four with -1e30: their exponentials are 0).
+constexpr int kRW = 8;            // rows per thread: a 32 x 64 pixel tile per workgroup
+constexpr int kRepW = 4;
+
+__device__ __forceinline__ float4 interp4(const float* base, int o00, int o01, int o10, int o11, int c, float lx0, float lx1,
+                                          float ly0, float ly1) {
+  const float4 a = *reinterpret_cast<const float4*>(base + o00 + c), b = *reinterpret_cast<const float4*>(base + o01 + c);
+  const float4 d = *reinterpret_cast<const float4*>(base + o10 + c), e = *reinterpret_cast<const float4*>(base + o11 + c);
+  // torch's up-sampling arithmetic: h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11)
+  return make_float4(ly0 * (lx0 * a.x + lx1 * b.x) + ly1 * (lx0 * d.x + lx1 * e.x), ly0 * (lx0 * a.y + lx1 * b.y) + ly1 * (lx0 * d.y + lx1 * e.y),
+                     ly0 * (lx0 * a.z + lx1 * b.z) + ly1 * (lx0 * d.z + lx1 * e.z), ly0 * (lx0 * a.w + lx1 * b.w) + ly1 * (lx0 * d.w + lx1 * e.w));
+}
+
+__global__ __launch_bounds__(kThreads) void seg_losses_wide_kernel(
+    const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
+    int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
+    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kTY = 4 * kRW;
+  constexpr float kL2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f, kNegBig = -1e30f;
+  const int CS = (Ctot + 3) & ~3, KS = sem_t ? ((K + 3) & ~3) : 0;
+  const int b = blockIdx.z, ty0 = blockIdx.y * kTY, tx0 = blockIdx.x * kTileX;
+  int ya, yb, xa, xb, dummy;
+  float f0, f1;
+  up_src(ty0, h, scale_h, ya, dummy, f0, f1);
+  up_src(min(ty0 + kTY, H) - 1, h, scale_h, dummy, yb, f0, f1);
+  up_src(tx0, w, scale_w, xa, dummy, f0, f1);
+  up_src(min(tx0 + kTileX, W) - 1, w, scale_w, dummy, xb, f0, f1);
+  const int ny = yb - ya + 1, nx = xb - xa + 1, ncell = ny * nx;
+  float* s_log = smem;                         // [ncell][CS]
+  float* t_log = s_log + ncell * CS;           // [ncell][KS]
+  float* g_acc = t_log + ncell * KS;           // [kRepW][ncell][CS]
+  float* red = g_acc + kRepW * ncell * CS;     // [2][4]
+  const int gstride = ncell * CS;
+  for (int i = threadIdx.x; i < ncell * CS; i += kThreads) {
+    const int cell = i / CS, c = i - cell * CS;
+    const int cy = ya + cell / nx, cx = xa + cell % nx;
+    s_log[i] = c < Ctot ? sem_s[((size_t)(b * h + cy) * w + cx) * ld_s + c] : kNegBig;
+  }
+  for (int i = threadIdx.x; i < kRepW * gstride; i += kThreads) g_acc[i] = 0.f;
+  for (int i = threadIdx.x; i < ncell * KS; i += kThreads) {
+    const int cell = i / KS, c = i - cell * KS;
+    const int cy = ya + cell / nx, cx = xa + cell % nx;
+    t_log[i] = c < K ? sem_t[((size_t)(b * h + cy) * w + cx) * ld_t + c] : kNegBig;
+  }
+  __syncthreads();
+
+  const int X = tx0 + (threadIdx.x & 63), Ybase = ty0 + (threadIdx.x >> 6) * kRW;
+  const float invK = K > 0 ? 1.f / (float)K : 0.f;
+  const float kdw = sem_t ? kd_scale * invK : 0.f;
+  int x0 = 0, x1 = 0;
+  float lx0 = 0.f, lx1 = 0.f;
+  if (X < W) up_src(X, w, scale_w, x0, x1, lx0, lx1);
+  const int cx0 = x0 - xa, cx1 = x1 - xa;
+  float ce_sum = 0.f, kd_sum = 0.f;
+  // ---- phase A: per row, the normalisers and the loss values --------------------------------------------------------------
+  float rmzl[kRW], ra_all[kRW], ra_old[kRW], rhot[kRW], rbbn[kRW], rmtl[kRW], rbq[kRW];
+  int rlab[kRW];
+#pragma unroll
+  for (int it = 0; it < kRW; ++it) {
+    const int Y = Ybase + it;
+    rmzl[it] = 0.f; ra_all[it] = 0.f; ra_old[it] = 0.f; rhot[it] = 0.f; rbbn[it] = 0.f; rmtl[it] = 0.f; rbq[it] = 0.f; rlab[it] = -1;
+    if (X >= W || Y >= H) continue;
+    int y0, y1;
+    float ly0, ly1;
+    up_src(Y, h, scale_h, y0, y1, ly0, ly1);
+    const int r0 = (y0 - ya) * nx, r1 = (y1 - ya) * nx;
+    const int s00 = (r0 + cx0) * CS, s01 = (r0 + cx1) * CS, s10 = (r1 + cx0) * CS, s11 = (r1 + cx1) * CS;
+    const int t00 = (r0 + cx0) * KS, t01 = (r0 + cx1) * KS, t10 = (r1 + cx0) * KS, t11 = (r1 + cx1) * KS;
+    const int64_t lab64 = labels[((size_t)b * H + Y) * W + X];
+    const bool ignored = lab64 == ignore_index;
+    int lab = ignored ? 0 : (int)lab64;
+    if (lab < K) lab = 0;                                    // loss.py:104-105
+    float mz = kNegBig, mt = kNegBig;
+    for (int c = 0; c < CS; c += 4) {
+      const float4 v = interp4(s_log, s00, s01, s10, s11, c, lx0, lx1, ly0, ly1);
+      mz = fmaxf(fmaxf(mz, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    for (int c = 0; c < KS; c += 4) {
+      const float4 v = interp4(t_log, t00, t01, t10, t11, c, lx0, lx1, ly0, ly1);
+      mt = fmaxf(fmaxf(mt, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    }
+    const float mzl = mz * kL2e, mtl = mt * kL2e;
+    float s_all = 0.f, s_old = 0.f, s_bn = 0.f, z_lab = 0.f, st = 0.f, te0 = 0.f, T0 = 0.f, T1 = 0.f;
+    for (int c = 0; c < CS; c += 4) {
+      const float4 v4 = interp4(s_log, s00, s01, s10, s11, c, lx0, lx1, ly0, ly1);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      float tv[4] = {kNegBig, kNegBig, kNegBig, kNegBig};
+      if (c < KS) {                                          // wave-uniform
+        const float4 t4 = interp4(t_log, t00, t01, t10, t11, c, lx0, lx1, ly0, ly1);
+        tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cc = c + j;
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], kL2e, -mzl));
+        s_all += e;
+        s_old += cc < K ? e : 0.f;
+        s_bn += (cc == 0 || cc >= K) ? e : 0.f;
+        z_lab = cc == lab ? v[j] : z_lab;
+        if (c < KS) {
+          const float te = __builtin_amdgcn_exp2f(__builtin_fmaf(tv[j], kL2e, -mtl));   // 0 for the padding classes
+          st += te;
+          te0 = cc == 0 ? te : te0;
+          const float tq = (cc >= 1 && cc < K) ? te : 0.f;
+          T0 += tq;
+          T1 = __builtin_fmaf(tq, v[j], T1);
+        }
+      }
+    }
+    const float den = mz + kLn2 * __builtin_amdgcn_logf(s_all);
+    const float lse_old = mz + kLn2 * __builtin_amdgcn_logf(s_old), lse_bn = mz + kLn2 * __builtin_amdgcn_logf(s_bn);
+    const bool lab0 = lab == 0;
+    const float logp = lab0 ? lse_old - den : z_lab - den;
+    if (!ignored) ce_sum += -logp;
+    const float ce_w = ignored ? 0.f : ce_scale;
+    float inv_st = 0.f, q0 = 0.f;
+    if (sem_t) {
+      inv_st = 1.f / st;
+      q0 = te0 * inv_st;
+      const float kd_pix = q0 * (lse_bn - den) + inv_st * (T1 - den * T0);
+      kd_sum += -kd_pix * invK;
+    }
+    rmzl[it] = mzl;
+    ra_all[it] = (ce_w + kdw) / s_all;
+    ra_old[it] = lab0 ? ce_w / s_old : 0.f;
+    rhot[it] = lab0 ? 0.f : ce_w;
+    rlab[it] = lab;
+    rbbn[it] = kdw * q0 / s_bn;
+    rmtl[it] = mtl;
+    rbq[it] = kdw * inv_st;
+  }
+  // ---- phase B: gradients, 16 classes at a time ------------------------------------------------------------------------------
+  float* ga = g_acc + (threadIdx.x & (kRepW - 1)) * gstride;
+  for (int cb = 0; cb < CS; cb += 16) {
+    float acc0[16], acc1[16];
+    int cur_y0 = -1, cur_y1 = -1;
+    auto flush = [&]() {
+      if (cur_y0 < 0) return;
+      const int r0 = (cur_y0 - ya) * nx, r1 = (cur_y1 - ya) * nx;
+      float* g00 = ga + (r0 + cx0) * CS + cb; float* g01 = ga + (r0 + cx1) * CS + cb;
+      float* g10 = ga + (r1 + cx0) * CS + cb; float* g11 = ga + (r1 + cx1) * CS + cb;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (cb + k < Ctot) {
+          atomicAdd(g00 + k, lx0 * acc0[k]);
+          atomicAdd(g01 + k, lx1 * acc0[k]);
+          atomicAdd(g10 + k, lx0 * acc1[k]);
+          atomicAdd(g11 + k, lx1 * acc1[k]);
+        }
+    };
+#pragma unroll
+    for (int it = 0; it < kRW; ++it) {
+      const int Y = Ybase + it;
+      if (X >= W || Y >= H) continue;
+      int y0, y1;
+      float ly0, ly1;
+      up_src(Y, h, scale_h, y0, y1, ly0, ly1);
+      if (y0 != cur_y0 || y1 != cur_y1) {                    // wave-uniform: a wave's lanes share the row
+        flush();
+        cur_y0 = y0; cur_y1 = y1;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
+      }
+      const int r0 = (y0 - ya) * nx, r1 = (y1 - ya) * nx;
+      const int s00 = (r0 + cx0) * CS, s01 = (r0 + cx1) * CS, s10 = (r1 + cx0) * CS, s11 = (r1 + cx1) * CS;
+      const int t00 = (r0 + cx0) * KS, t01 = (r0 + cx1) * KS, t10 = (r1 + cx0) * KS, t11 = (r1 + cx1) * KS;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = cb + 4 * q;
+        if (c >= CS) continue;                               // uniform
+        const float4 v4 = interp4(s_log, s00, s01, s10, s11, c, lx0, lx1, ly0, ly1);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        float tv[4] = {kNegBig, kNegBig, kNegBig, kNegBig};
+        if (c < KS) {
+          const float4 t4 = interp4(t_log, t00, t01, t10, t11, c, lx0, lx1, ly0, ly1);
+          tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int cc = c + j;
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], kL2e, -rmzl[it]));
+          const float coef = ra_all[it] - (cc < K ? ra_old[it] : 0.f) - ((cc == 0 || cc >= K) ? rbbn[it] : 0.f);
+          float g = e * coef - (cc == rlab[it] ? rhot[it] : 0.f);
+          if (c < KS) {
+            const float te = __builtin_amdgcn_exp2f(__builtin_fmaf(tv[j], kL2e, -rmtl[it]));
+            g = __builtin_fmaf(-rbq[it], (cc >= 1 && cc < K) ? te : 0.f, g);
+          }
+          acc0[4 * q + j] = __builtin_fmaf(ly0, g, acc0[4 * q + j]);
+          acc1[4 * q + j] = __builtin_fmaf(ly1, g, acc1[4 * q + j]);
+        }
+      }
+    }
+    flush();
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncell * CS; i += kThreads) {
+    const int cell = i / CS, c = i - cell * CS;
+    if (c >= Ctot) continue;
+    float v = g_acc[i];
+#pragma unroll
+    for (int r = 1; r < kRepW; ++r) v += g_acc[r * gstride + i];
+    if (v != 0.f) {
+      const int cy = ya + cell / nx, cx = xa + cell % nx;
+      atomicAdd(&d_sem[((size_t)(b * h + cy) * w + cx) * ld_d + c], v);
+    }
+  }
+  ce_sum = wave_sum(ce_sum);
+  kd_sum = wave_sum(kd_sum);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = ce_sum; red[4 + (threadIdx.x >> 6)] = kd_sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int blk = (blockIdx.z * tiles_y + blockIdx.y) * tiles_x + blockIdx.x;
+    loss_part[2 * blk + 0] = red[0] + red[1] + red[2] + red[3];
+    loss_part[2 * blk + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
 // ---- validation: up-sampling + arg-max + confusion matrix ---------------------------------------
 // The reference's validation (train.py:242-246, metrics/stream_metrics.py:44-47,65-71) up-samples the logits, takes
 // outputs.max(dim=1), copies predictions and labels to the host and runs a numpy bincount per image.  Here a block owns a
@@ -415,7 +644,7 @@ using namespace ucd;
 extern "C" {
 
 size_t ucd_seg_losses_workspace_bytes(int B, int H, int W) {
-  return (size_t)B * ceil_div(H, kTileY) * ceil_div(W, kTileX) * 2 * sizeof(float);
+  return (size_t)B * ceil_div(H, 4 * kRW) * ceil_div(W, kTileX) * 2 * sizeof(float);      // the finer tiling of the two kernels
 }
 
 int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, const int64_t* labels, int B, int H, int W,
@@ -430,14 +659,18 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
               "%s: built for up-sampling factors >= 4 (the model's is 16)", fn);
   UCD_REQUIRE(workspace_bytes >= ucd_seg_losses_workspace_bytes(B, H, W), UCD_EWORKSPACE, "%s: workspace too small", fn);
   hipStream_t s = (hipStream_t)stream;
-  const int tiles_x = ceil_div(W, kTileX), tiles_y = ceil_div(H, kTileY);
+  const bool wide = Ctot > 24;                       // many classes (ADE): seg_losses_wide_kernel on 32 x 64 pixel tiles
+  const int tile_y = wide ? 4 * kRW : kTileY;
+  const int tiles_x = ceil_div(W, kTileX), tiles_y = ceil_div(H, tile_y);
   // worst-case LDS: (tile/scale + 3) cells per dimension
-  const int ny = (int)(kTileY * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
-  const size_t lds = ((size_t)ny * nx * ((Ctot <= 24 ? 17 : 2) * Ctot + K) + 8) * sizeof(float);
+  const int ny = (int)(tile_y * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
+  const int CS = (Ctot + 3) & ~3, KS = sem_t ? ((K + 3) & ~3) : 0;
+  const size_t lds = wide ? ((size_t)ny * nx * ((1 + kRepW) * CS + KS) + 8) * sizeof(float)
+                          : ((size_t)ny * nx * (17 * Ctot + K) + 8) * sizeof(float);
   UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
   UCD_TRY_LDS((seg_losses_kernel<24, 16>), 150 * 1024);
   UCD_TRY_LDS((seg_losses_kernel<24, 24>), 150 * 1024);
-  UCD_TRY_LDS((seg_losses_kernel<0, 0>), 150 * 1024);
+  UCD_TRY_LDS(seg_losses_wide_kernel, 150 * 1024);
   hipError_t e = hipMemsetAsync(d_sem, 0, (size_t)B * h * w * ld_d * sizeof(float), s);
   if (e != hipSuccess) { set_error("%s: %s", fn, hipGetErrorString(e)); return (int)e; }
   const float inv_pix = 1.f / ((float)B * H * W);
@@ -452,7 +685,7 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
         sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
         ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
   else
-    seg_losses_kernel<0, 0><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
+    seg_losses_wide_kernel<<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
         sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
         ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
   int rc = check_launch(fn);
