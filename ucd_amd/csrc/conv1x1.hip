@@ -94,7 +94,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // taps x K/64 steps, the A tile of tap (kh, kw) is the row tile shifted by ((kh-1) d, (kw-1) d) pixels - with LDS-DMA the
 // source address is per lane, so the shift and the zero padding (lanes outside the map fetch a 16-byte zero constant) are
 // free; W is the channels-last 4-D weight [N][kh][kw][K] read as 9 [N][K] slices (row pitch 9 K).
-__device__ const uint4 g_zero16 = {0u, 0u, 0u, 0u};
 
 // DB: two LDS stages, for grids that give a CU one or two workgroups (N = 256 at 33^2: 410 workgroups) instead of the four
 // whose interleaving hides the fill latency of the single-stage form - the 9 K deep, MFMA-bound 3x3 products most of all: the
@@ -118,7 +117,9 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
   const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
   if (tm >= p.tiles_m) return;
   const int m0 = tm * kBM, n0 = tn * BN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the wave index as a SCALAR: every LDS-DMA destination is wave-uniform, and with a VGPR-derived index the compiler moves each
+  // one through a VGPR + v_readfirstlane into M0 (25 of those per two K steps next to 32 MFMAs)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
   f32x16 acc[2][TN];
@@ -179,19 +180,32 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i]);
   }
+  // CONV3: the A tile of a tap is fetched through a buffer descriptor with 32-bit byte offsets computed ONCE per tap (shifted
+  // pixel, bounds test); pixels outside the map carry an out-of-range offset, which the descriptor's range check zero-fills
+  // (tools/lds_dma_oob_probe.hip) - the K steps inside a tap only add k0 (the first version re-derived tap, shift, bounds and a
+  // 64-bit select per load and step: 36 % of the wave's cycles were instruction issue, tools/prof_kernel.sh)
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, CONV3 ? (int)((size_t)p.M * p.lda * 2) : 0, 0x00020000);
+  constexpr unsigned kOOB = 0x7FFFFFF0u;
+  unsigned aoff[CA];
+  int atap = -1;
+  auto set_tap = [&](int tap) {
+    const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
+#pragma unroll
+    for (int i = 0; i < CA; ++i) {
+      const int yy = py[i] + dy, xx = px[i] + dx;
+      const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
+      aoff[i] = ok ? (unsigned)(((pimg[i] + yy * p.iW + xx) * p.lda + pslot[i]) * 2) : kOOB;
+    }
+    atap = tap;
+  };
   auto fill3 = [&](int kb, unsigned char* Ad, unsigned char* Bd) {   // LDS-DMA fill of step kb (double-buffered form)
     const int tap = CONV3 ? kb / kpt : 0;
     const int k0 = (kb - tap * kpt) * kBK;
     if (CONV3) {
-      const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
+      if (tap != atap) set_tap(tap);
 #pragma unroll
-      for (int i = 0; i < CA; ++i) {
-        const int yy = py[i] + dy, xx = px[i] + dx;
-        const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
-        const bf16* src = ok ? p.A + (size_t)(pimg[i] + yy * p.iW + xx) * p.lda + pslot[i] + k0
-                             : reinterpret_cast<const bf16*>(&g_zero16);
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, 0, 0);
-      }
+      for (int i = 0; i < CA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, (int)(aoff[i] + (unsigned)k0 * 2u), 0, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < CA; ++i)
@@ -254,15 +268,10 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
       if (CONV3) {
-        const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
+        if (tap != atap) set_tap(tap);
 #pragma unroll
-        for (int i = 0; i < CA; ++i) {
-          const int yy = py[i] + dy, xx = px[i] + dx;
-          const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
-          const bf16* src = ok ? p.A + (size_t)(pimg[i] + yy * p.iW + xx) * p.lda + pslot[i] + k0
-                               : reinterpret_cast<const bf16*>(&g_zero16);
-          __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (wave * CA + i) * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < CA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + (wave * CA + i) * 1024), 16, (int)(aoff[i] + (unsigned)k0 * 2u), 0, 0, 0);
       } else {
 #pragma unroll
         for (int i = 0; i < CA; ++i)
@@ -717,6 +726,8 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   UCD_REQUIRE(!conv3 || (d->H > 0 && d->W > 0 && d->dilation >= 1 && (long long)d->M % ((long long)d->H * d->W) == 0 &&
                          d->ldw >= 9 * d->K && !d->in_scale),
               UCD_EINVAL, "%s: 3x3 mode needs H, W, dilation, M = B*H*W, ldw >= 9 K, no input transform", fn);
+  UCD_REQUIRE(!conv3 || (size_t)d->M * d->lda * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
+              "%s: a 3x3 input map beyond 2 GiB exceeds the 32-bit offsets of the staging loads", fn);
   UCD_REQUIRE(aligned16(d->a) && aligned16(d->w) && aligned16(d->y) && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldy % 8 == 0 &&
                   d->lda >= d->K && d->ldw >= d->K && d->ldy >= d->N,
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
   const int tn = rest % p.tiles_n, tk = kpart * tiles_kg + rest / p.tiles_n;
   const int n0 = tn * BNO, k0 = tk * BKO;
   const int mb = chunk * p.rows_per_chunk, me = min(p.M, mb + p.rows_per_chunk);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS-DMA destinations
   const int wn = wave >> 1, wk = wave & 1;
   const int dy = T9 ? (tap / 3 - 1) * p.dil : 0, dx = T9 ? (tap % 3 - 1) * p.dil : 0;
   const int shift = dy * p.W + dx;
