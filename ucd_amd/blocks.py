@@ -356,11 +356,13 @@ def _own_gemm_with_stats(K, N):
 
 def _own_conv3x3(M, K, N):
     """The implicit-GEMM 3x3 (csrc/conv1x1.hip, taps = 9) instead of MIOpen: measured on MI355X (tools/conv3x3_probe.py,
-    B = 24): 256->256 at 33^2 47-49 vs 56 us, 128->128 at 65^2 49 vs 47-52, 64->64 at 129^2 55 vs 63, the ASPP branches 303-315
-    vs 382-390 - and the following ABN's statistics for +1 us instead of a separate pass; MIOpen keeps the 512->512 layers
-    (135-142 vs 167 us) and maps too small to give every CU a tile (3 images per GPU: 23 vs 31 us)."""
+    B = 24, profiles/r03_conv3x3_probe.txt): 256->256 at 33^2 40 vs 58 us, 512->512 (dilation 2) 132 vs 142, 128->128 at 65^2
+    42 vs 48, 64->64 at 129^2 51 vs 63, the ASPP branches 229-252 vs 386-391 - and the following ABN's statistics for +1 us
+    instead of a separate pass; MIOpen keeps the maps too small to give every CU a tile (3 images per GPU: 23 vs 27 us)."""
     tiles = ((M + 127) // 128) * max(1, N // 128)
-    return tiles >= 256 and not (K >= 512 and N >= 512)
+    if K >= 512 and N >= 512 and os.environ.get("UCD_OWN3X3_WIDE", "1") == "0":      # A/B switch: the 512 -> 512 layers on MIOpen
+        return False
+    return tiles >= 256
 
 
 class _ConvABNFunction(torch.autograd.Function):

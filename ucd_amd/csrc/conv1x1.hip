@@ -180,6 +180,15 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(arow[i]);
   }
+  // Every LDS-DMA goes through a buffer descriptor: a per-lane 32-bit byte offset computed once (row, swizzled slot) plus a
+  // SCALAR offset for the K position - no vector arithmetic per load in the K loop.
+  const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((size_t)p.N * p.ldw * 2), 0x00020000);
+  const auto rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((size_t)p.M * p.lda * 2), 0x00020000);
+  unsigned boff[CB], a1off[CA];
+#pragma unroll
+  for (int i = 0; i < CB; ++i) boff[i] = (unsigned)((const char*)gb[i] - (const char*)p.W);
+#pragma unroll
+  for (int i = 0; i < CA; ++i) a1off[i] = (unsigned)((const char*)ga[i] - (const char*)p.A);
   // CONV3: the A tile of a tap is fetched through a buffer descriptor with 32-bit byte offsets computed ONCE per tap (shifted
   // pixel, bounds test); pixels outside the map carry an out-of-range offset, which the descriptor's range check zero-fills
   // (tools/lds_dma_oob_probe.hip) - the K steps inside a tap only add k0 (the first version re-derived tap, shift, bounds and a
@@ -205,15 +214,15 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
       if (tap != atap) set_tap(tap);
 #pragma unroll
       for (int i = 0; i < CA; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, (int)(aoff[i] + (unsigned)k0 * 2u), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, (int)aoff[i], k0 * 2, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < CA; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + k0), (lptr_t)(Ad + (wave * CA + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (lptr_t)(Ad + (wave * CA + i) * 1024), 16, (int)a1off[i], k0 * 2, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CB; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + tap * p.K + k0), (lptr_t)(Bd + (wave * CB + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bd + (wave * CB + i) * 1024), 16, (int)boff[i], (tap * p.K + k0) * 2, 0, 0);
   };
   if (DB) fill3(0, As, Bs);
   for (int kb = 0; kb < nk; ++kb) {
@@ -241,7 +250,7 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
     } else if (PRO) {
 #pragma unroll
       for (int i = 0; i < CB; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + k0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + (wave * CB + i) * 1024), 16, (int)boff[i], k0 * 2, 0, 0);
       float mu[8], sc[8], sh[8];
       {
         const float* pk = Ps + k0 + ks * 8;
@@ -271,15 +280,15 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
         if (tap != atap) set_tap(tap);
 #pragma unroll
         for (int i = 0; i < CA; ++i)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + (wave * CA + i) * 1024), 16, (int)(aoff[i] + (unsigned)k0 * 2u), 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + (wave * CA + i) * 1024), 16, (int)aoff[i], k0 * 2, 0, 0);
       } else {
 #pragma unroll
         for (int i = 0; i < CA; ++i)
-          __builtin_amdgcn_global_load_lds((gptr_t)(ga[i] + k0), (lptr_t)(As + (wave * CA + i) * 1024), 16, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (lptr_t)(As + (wave * CA + i) * 1024), 16, (int)a1off[i], k0 * 2, 0, 0);
       }
 #pragma unroll
       for (int i = 0; i < CB; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(gb[i] + wk0), (lptr_t)(Bs + (wave * CB + i) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bs + (wave * CB + i) * 1024), 16, (int)boff[i], wk0 * 2, 0, 0);
     }
     if (!DB) {
       if (!PRO) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -726,8 +735,8 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   UCD_REQUIRE(!conv3 || (d->H > 0 && d->W > 0 && d->dilation >= 1 && (long long)d->M % ((long long)d->H * d->W) == 0 &&
                          d->ldw >= 9 * d->K && !d->in_scale),
               UCD_EINVAL, "%s: 3x3 mode needs H, W, dilation, M = B*H*W, ldw >= 9 K, no input transform", fn);
-  UCD_REQUIRE(!conv3 || (size_t)d->M * d->lda * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
-              "%s: a 3x3 input map beyond 2 GiB exceeds the 32-bit offsets of the staging loads", fn);
+  UCD_REQUIRE((size_t)d->M * d->lda * 2 < 0x7FFFFFF0u && (size_t)d->N * d->ldw * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
+              "%s: an operand beyond 2 GiB exceeds the 32-bit offsets of the staging loads", fn);
   UCD_REQUIRE(aligned16(d->a) && aligned16(d->w) && aligned16(d->y) && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldy % 8 == 0 &&
                   d->lda >= d->K && d->ldw >= d->K && d->ldy >= d->N,
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
