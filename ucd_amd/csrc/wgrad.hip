@@ -169,25 +169,36 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
   const auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.dZ, 0, (int)((size_t)p.M * p.ldz * 2), 0x00020000);
   const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((size_t)p.M * p.ldx * 2), 0x00020000);
   constexpr int kOOB = 0x7FFFFFF0;
+  // per-lane byte offsets inside a 64-row step, computed once; the step's first row enters as a SCALAR offset.  Only a step
+  // that crosses the chunk's end (the last one) or a shifted tap tests rows.
+  unsigned ybase[CY], xbase[CX];
+#pragma unroll
+  for (int i = 0; i < CY; ++i) ybase[i] = (unsigned)((yrow[i] * p.ldz + ycol[i]) * 2);
+#pragma unroll
+  for (int i = 0; i < CX; ++i) xbase[i] = (unsigned)((xrow[i] * p.ldx + xcol[i]) * 2);
   auto fill = [&](int s, unsigned char* stage) {
     const int m0 = mb + s * kRows;
+    const bool whole = m0 + kRows <= me;                                  // wave-uniform
+    // the scalar offset must not go negative (a shifted tap at the very first rows): the remainder rides on the lane offset,
+    // which stays >= 0 for every row that exists (the range check looks at the lane offset)
+    const int sx = max(0, m0 + shift);
+    const int zs = m0 * p.ldz * 2, xs = sx * p.ldx * 2, xadj = (m0 + shift - sx) * p.ldx * 2;
 #pragma unroll
     for (int i = 0; i < CY; ++i) {
-      const int m = m0 + yrow[i];
-      const int off = m < me ? (m * p.ldz + ycol[i]) * 2 : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lptr_t)(stage + (wave * CY + i) * 1024), 16, off, 0, 0, 0);
+      const unsigned off = (whole || m0 + yrow[i] < me) ? ybase[i] : (unsigned)kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lptr_t)(stage + (wave * CY + i) * 1024), 16, (int)off, zs, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < CX; ++i) {
       const int m = m0 + xrow[i];
-      bool ok = m < me;
+      bool ok = whole || m < me;
       if (T9) {
         const int pix = m - fdiv(m, hw, p.inv_hw) * hw;
         const int y = fdiv(pix, p.W, p.inv_w), x = pix - y * p.W;
         ok = ok && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
       }
-      const int off = ok ? ((m + shift) * p.ldx + xcol[i]) * 2 : kOOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(stage + YB + (wave * CX + i) * 1024), 16, off, 0, 0, 0);
+      const unsigned off = ok ? (unsigned)((int)xbase[i] + xadj) : (unsigned)kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(stage + YB + (wave * CX + i) * 1024), 16, (int)off, xs, 0, 0);
     }
   };
 
