@@ -191,8 +191,7 @@ def _own_wgrad_4d(dz, x, w4, dilation):
             and w4.shape[1] % 64 == 0 and x.shape[2] > 1 and x.shape[3] > 1 and x.is_contiguous(memory_format=torch.channels_last)
             and x.shape[0] * x.shape[2] * x.shape[3] < (1 << 22)):
         return None
-    if dilation > 0 and not (tuple(w4.shape[2:]) == (3, 3) and w4.is_contiguous(memory_format=torch.channels_last)
-                             and w4.shape[0] * w4.shape[1] < (1 << 18)):      # 512 -> 512 and the ASPP branches: MIOpen is faster
+    if dilation > 0 and not (tuple(w4.shape[2:]) == (3, 3) and w4.is_contiguous(memory_format=torch.channels_last)):
         return None
     from . import hip
     if not dz.is_contiguous(memory_format=torch.channels_last):

@@ -65,9 +65,10 @@ bool own_wgrad_ok(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w
          x.scalar_type() == at::kBFloat16 && w4.size(0) % 64 == 0 && w4.size(1) % 64 == 0 && dz.size(1) == w4.size(0) &&
          x.size(1) == w4.size(1) && x.size(0) * x.size(2) * x.size(3) < (1 << 22) &&
          (dilation == 0 ? (w4.size(2) == 1 && w4.size(3) == 1)
-                        // the 9-tap form where it beats MIOpen's solver (tools/wgrad_probe2.py: 64-256 channel layers 55-75 vs
-                        // 81-100 us; 512 -> 512 and the ASPP branches 228 / 414 vs 220 / 371 us: MIOpen keeps those)
-                        : (w4.size(2) == 3 && w4.size(3) == 3 && w4.size(0) * w4.size(1) < (1 << 18)));
+                        // every stride-1 3x3 layer (tools/wgrad_probe2.py, profiles/r03_wgrad_probe.txt: 64-256 channel layers
+                        // 50-58 vs 80-100 us for MIOpen's solver, 512 -> 512 213 vs 215, the ASPP branches 392 vs 372 - plus the
+                        // ~35 us of zero-fill / cast kernels MIOpen wraps around its solver on the step)
+                        : (w4.size(2) == 3 && w4.size(3) == 3));
 }
 
 at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w4, int64_t dilation, int64_t stream) {

@@ -176,6 +176,20 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
   for (int i = 0; i < CY; ++i) ybase[i] = (unsigned)((yrow[i] * p.ldz + ycol[i]) * 2);
 #pragma unroll
   for (int i = 0; i < CX; ++i) xbase[i] = (unsigned)((xrow[i] * p.ldx + xcol[i]) * 2);
+  // T9: pixel coordinates of this lane's X rows, advanced by 64 rows per step instead of two divisions per row and step
+  // (the kernel spent 45-48 % of its cycles issuing instructions, tools/prof_wgrad.sh); fill() is called for s = 0, 1, 2, ...
+  int xy[CX], xx[CX];
+  const int q64 = T9 ? kRows / p.W : 0, r64 = T9 ? kRows - q64 * p.W : 0;
+  const bool incremental = T9 && q64 + 1 <= p.H;            // one wrap per step is enough (always, for real maps)
+  if (T9) {
+#pragma unroll
+    for (int i = 0; i < CX; ++i) {
+      const int m = mb + xrow[i];
+      const int pix = m - fdiv(m, hw, p.inv_hw) * hw;
+      xy[i] = fdiv(pix, p.W, p.inv_w);
+      xx[i] = pix - xy[i] * p.W;
+    }
+  }
   auto fill = [&](int s, unsigned char* stage) {
     const int m0 = mb + s * kRows;
     const bool whole = m0 + kRows <= me;                                  // wave-uniform
@@ -193,8 +207,17 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
       const int m = m0 + xrow[i];
       bool ok = whole || m < me;
       if (T9) {
-        const int pix = m - fdiv(m, hw, p.inv_hw) * hw;
-        const int y = fdiv(pix, p.W, p.inv_w), x = pix - y * p.W;
+        int y, x;
+        if (incremental) {
+          y = xy[i]; x = xx[i];
+          int nx = x + r64, ny = y + q64;                    // the next step's coordinates
+          if (nx >= p.W) { nx -= p.W; ++ny; }
+          if (ny >= p.H) ny -= p.H;
+          xx[i] = nx; xy[i] = ny;
+        } else {
+          const int pix = m - fdiv(m, hw, p.inv_hw) * hw;
+          y = fdiv(pix, p.W, p.inv_w); x = pix - y * p.W;
+        }
         ok = ok && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
       }
       const unsigned off = ok ? (unsigned)((int)xbase[i] + xadj) : (unsigned)kOOB;
