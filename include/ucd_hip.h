@@ -478,6 +478,29 @@ int ucd_conv1x1_wgrad(const void* dy, int ld_dy, const void* a, int lda, int M, 
                       const float* in_mean, const float* in_scale, const float* in_shift, int in_act, float in_slope,
                       void* dw, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
 
+/* The combination + finalize step of ucd_abn_sync_forward on its own (the stem's fused norm + pooling applies the result itself):
+ * gathered [world][2C] = every rank's [mean_r | M2_r] -> buf = [.. | mean | invstd | scale] and the running statistics. */
+int ucd_abn_sync_finalize(const float* gathered, int world, int M, int C, const float* weight, float* running_mean,
+                          float* running_var, float momentum, float eps, float* buf, int flags, ucd_stream_t stream);
+
+/* ---- stem: norm_act + MaxPool2d(3, stride 2, padding 1) as one pass (models/resnet.py:58-64, mod1.bn1 + mod1.pool1) -----------
+ * z [B, H, W, C] dense channels-last bf16 (the 7x7 convolution's output), C a multiple of 8 that divides 2048.
+ *   ucd_stem_apply_pool     out [B, PH, PW, C] = max over each 3x3 window of bf16(act((z - mean) scale + beta)) - bit for bit
+ *                           max_pool2d(abn_apply(z)), first maximum wins; idx (optional, uint8 [B, PH, PW, C]) = window position
+ *                           0..8 of the maximum, kept for the backward; PH = ucd_stem_pooled_size(H)
+ *   ucd_stem_pool_backward  phase 1: sums [2C] = (sum dyact, sum dyact xhat) with dyact = dpool * act' at the arg-max positions
+ *                           (the layer's d bias / d weight; the second row times sign(weight) for UCD_NORM_ABS_GAMMA layers);
+ *                           phase 2: dz [B, H, W, C] = the norm's input gradient for every position (count = B H W x ranks);
+ *                           phase 3: both.  SyncBN all-reduces sums between the phases.  workspace:
+ *                           ucd_stem_pool_workspace_bytes(C).  leaky_relu / identity only. */
+int ucd_stem_pooled_size(int n);
+size_t ucd_stem_pool_workspace_bytes(int C);
+int ucd_stem_apply_pool(const void* z, int B, int H, int W, int C, const float* mean, const float* scale, const float* beta, int act,
+                        float slope, void* out, uint8_t* idx, ucd_stream_t stream);
+int ucd_stem_pool_backward(const void* z, const void* dpool, const uint8_t* idx, int B, int H, int W, int C, const float* mean,
+                           const float* invstd, const float* scale, const float* beta, const float* weight, float* sums, float count,
+                           int act, float slope, void* dz, void* workspace, size_t workspace_bytes, int phase, ucd_stream_t stream);
+
 /* Weight gradient of a stride-1 convolution on channels-last maps (backward of modules/residual.py:57-73 conv1 / conv2 / conv3 /
  * proj_conv, modules/deeplab.py:24-37 map_convs / red_conv; replaces MIOpen's weight-gradient solvers and the batched split-M
  * library products on the train step):

@@ -543,3 +543,56 @@ def test_wrapper_under_the_references_plain_loop(zero_where):
         assert wrapped.module[1]._direct_grad_ptr() != 0
         assert wrapped.module[0].weight.grad.data_ptr() == wrapped.reducer._bucket_of[wrapped.module[0].weight].flat.data_ptr() \
             or wrapped.module[0].weight.grad.untyped_storage().data_ptr() == wrapped.reducer._bucket_of[wrapped.module[0].weight].flat.untyped_storage().data_ptr()
+
+
+@pytest.mark.parametrize("B,C,H,W,slope", [(2, 64, 65, 67, 0.01), (3, 64, 33, 32, 0.01), (2, 128, 9, 11, 1.0), (24, 64, 257, 257, 0.01)])
+def test_stem_norm_pool_fused_equals_the_two_layers(B, C, H, W, slope):
+    """mod1.bn1 + mod1.pool1 (models/resnet.py:58-64) as one kernel forward and two backward (csrc/stem.hip) against the two
+    layers run one after the other (HIP ABN, then ATen's max_pool2d): the forward is BIT-identical (same apply arithmetic, values
+    rounded to bf16 before the comparison, first maximum wins), the gradients agree to bf16 rounding, and both agree with the fp32
+    composition batch_norm -> leaky_relu -> max_pool2d on the same bf16 input; evaluation mode with the running statistics too."""
+    import torch.nn.functional as F
+    from ucd_amd import abn
+    dev = torch.device("cuda:0")
+    z0 = (synth.t_normal(31 + H, (B, C, H, W), stream=1) * 1.5 + 0.3).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    PH, PW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    dp = synth.t_normal(32 + H, (B, C, PH, PW), stream=2).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for mode in ("fused", "layers"):
+        bn = abn.InPlaceABNSync(C, activation="leaky_relu", activation_param=slope).to(dev)
+        with torch.no_grad():
+            bn.weight.copy_(synth.t_normal(5, (C,), stream=3) * 0.3 + 1.0)
+            bn.weight[1] = -0.7                                               # |gamma| + eps semantics on a negative stored scale
+            bn.bias.copy_(synth.t_normal(6, (C,), stream=4) * 0.2)
+        bn.train()
+        z = z0.clone().requires_grad_(True)
+        y = abn.stem_norm_pool(bn, z * 1.0) if mode == "fused" else F.max_pool2d(bn(z * 1.0), 3, 2, 1)
+        assert y is not None and y.shape == (B, C, PH, PW)
+        y.backward(dp)
+        bn.eval()
+        with torch.no_grad():
+            ye = abn.stem_norm_pool(bn, z0.clone()) if mode == "fused" else F.max_pool2d(bn(z0.clone()), 3, 2, 1)
+        res[mode] = (y.detach().clone(), z.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(),
+                     bn.running_var.clone(), ye.clone())
+    a, b = res["fused"], res["layers"]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[6], b[6])                  # forward (train and eval): bit-identical
+    torch.testing.assert_close(a[4], b[4], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a[5], b[5], rtol=1e-5, atol=1e-6)
+    rel = lambda u, v: ((u.float() - v.float()).norm() / v.float().norm()).item()
+    assert rel(a[1], b[1]) < 1e-2 and rel(a[2], b[2]) < 2e-3 and rel(a[3], b[3]) < 2e-3
+    # fp32 composition on the same input
+    zf = z0.float().clone().requires_grad_(True)
+    w = (res["layers"][2] * 0).clone()                                            # shapes only
+    bn32 = abn.InPlaceABNSync(C, activation="leaky_relu", activation_param=slope).to(dev)
+    with torch.no_grad():
+        bn32.weight.copy_(synth.t_normal(5, (C,), stream=3) * 0.3 + 1.0); bn32.weight[1] = -0.7
+        bn32.bias.copy_(synth.t_normal(6, (C,), stream=4) * 0.2)
+    g = (bn32.weight.abs() + bn32.eps).detach().requires_grad_(True)
+    beta = bn32.bias.detach().clone().requires_grad_(True)
+    yf = F.max_pool2d(F.leaky_relu(F.batch_norm(zf, None, None, g, beta, True, 0.1, bn32.eps), slope), 3, 2, 1)
+    yf.backward(dp.float())
+    assert rel(a[0], yf.detach()) < 5e-3
+    assert rel(a[1], zf.grad) < 3e-2          # bf16 ties in a window route the gradient to another (equal-valued) position
+    sgn = torch.where(bn32.weight < 0, -1.0, 1.0)
+    assert rel(a[2], g.grad * sgn) < 1e-2 and rel(a[3], beta.grad) < 1e-2
+    del w

@@ -342,6 +342,100 @@ def global_avg_pool(x):
     return _PlaneMean.apply(x)
 
 
+class _StemABNPoolFunction(torch.autograd.Function):
+    """``max_pool2d(abn(z), 3, stride 2, padding 1)`` of the stem (models/resnet.py:58-64: mod1.bn1 + mod1.pool1) as one pass
+    forward and two passes backward (csrc/stem.hip): the normalised 257 x 257 map - the largest activation of the network - is
+    never written, and the pooling's backward, the norm's reduction and the norm's apply stop being three trips over it.
+    Training: batch statistics (shifted sums + finalize; under SyncBN the per-rank (mean, M2) pairs are gathered and combined),
+    then the fused apply + pool; evaluation: the running-statistics constants.  The backward's two sums are all-reduced between
+    its phases under SyncBN, exactly like ucd_abn_sync_backward_comm."""
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, running_mean, running_var, training, momentum, eps, act, slope, group, eval_consts):
+        B, Cc, H, W = z.shape
+        M, HW = B * H * W, H * W
+        zr, _, _, _, ld = hip.rows_view(z)
+        dev = z.device
+        world = _group_size(group) if training else 1
+        sync = training and group is not False and (world > 1 or (_FORCE_SYNC and dist.is_initialized()))
+        if training:
+            buf = torch.empty(((8 + 2 * world) if sync else 6) * Cc, dtype=torch.float32, device=dev)
+            if sync:
+                pack = buf[6 * Cc:8 * Cc]
+                hip.abn_sync_stats(zr, ld, M, Cc, None, HW, buf[:2 * Cc], buf[2 * Cc:3 * Cc], pack)
+                comm = direct_comm(group)
+                if comm is not None:
+                    gathered = buf[8 * Cc:]
+                    hip._check(hip.load().ucd_comm_all_gather(comm.handle, hip.ptr(pack), hip.ptr(gathered), 2 * Cc, hip.stream()),
+                               "ucd_comm_all_gather")
+                else:
+                    gathered = _all_gather_stats(pack, world, group)
+                hip.abn_sync_finalize(gathered, world, M, Cc, weight, running_mean, running_var, momentum, eps, buf, act)
+            else:
+                hip.abn_stats_finalize(zr, ld, M, Cc, None, HW, buf[:2 * Cc], buf[2 * Cc:3 * Cc], weight, running_mean, running_var,
+                                       momentum, eps, buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:6 * Cc], act)
+            mean, invstd, scale = buf[3 * Cc:4 * Cc], buf[4 * Cc:5 * Cc], buf[5 * Cc:6 * Cc]
+        else:
+            mean, invstd, scale = running_mean, eval_consts[0], eval_consts[1]
+        need_bwd = any(ctx.needs_input_grad[:3])
+        out, idx = hip.stem_apply_pool(z, mean, scale, bias, act, slope, need_bwd)
+        if need_bwd:
+            ctx.save_for_backward(z, idx, weight, bias, mean, invstd, scale)
+            ctx.cfg = (training, act, slope, group, world, sync, float(M * world))
+        return out
+
+    @staticmethod
+    def backward(ctx, dp):
+        z, idx, weight, bias, mean, invstd, scale = ctx.saved_tensors
+        training, act, slope, group, world, sync, count = ctx.cfg
+        if not training:
+            raise RuntimeError("ucd_amd.abn: the fused stem has no frozen-statistics backward (fix_bn keeps the separate layers)")
+        Cc = z.shape[1]
+        if dp.dtype != z.dtype:
+            dp = dp.to(z.dtype)
+        if not dp.is_contiguous(memory_format=torch.channels_last):
+            dp = dp.contiguous(memory_format=torch.channels_last)
+        sums = torch.empty(2 * Cc, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z) if ctx.needs_input_grad[0] else None
+        if not sync:
+            hip.stem_pool_backward(z, dp, idx, mean, invstd, scale, bias, weight, sums, count, act, slope, dz, 3 if dz is not None else 1)
+            dbias, dweight = sums[:Cc], sums[Cc:]
+        else:
+            hip.stem_pool_backward(z, dp, idx, mean, invstd, scale, bias, weight, sums, count, act, slope, None, 1)
+            local = sums.clone()                                   # this rank's sums = its d bias / d weight
+            dbias, dweight = local[:Cc], local[Cc:]
+            comm = direct_comm(group)
+            if comm is not None:
+                hip._check(hip.load().ucd_comm_all_reduce_sum(comm.handle, hip.ptr(sums), 2 * Cc, hip.stream()), "ucd_comm_all_reduce_sum")
+            else:
+                _all_reduce_sums(sums, group)
+            if dz is not None:
+                hip.stem_pool_backward(z, dp, idx, mean, invstd, scale, bias, weight, sums, count, act, slope, dz, 2)
+        return (dz, dweight if weight is not None else None, dbias if bias is not None else None) + (None,) * 9
+
+
+def stem_norm_pool(bn, z):
+    """``pool(bn(z))`` of the stem through the fused kernels, or None when this layer / input is not one they take (the caller
+    then runs the two modules): HIP ABN with leaky_relu / identity, dense channels-last bf16 map, channel count a multiple of
+    8 dividing 2048; frozen statistics only without gradients (``UCD_STEM_FOLD=0`` switches the fold off)."""
+    import os
+    if os.environ.get("UCD_STEM_FOLD", "1") == "0" or not getattr(bn, "ucd_fused_abn", False):
+        return None
+    Cc = z.shape[1] if z.dim() == 4 else 0
+    if not (z.is_cuda and z.dim() == 4 and z.dtype == torch.bfloat16 and z.is_contiguous(memory_format=torch.channels_last)
+            and z.shape[2] > 2 and z.shape[3] > 2 and Cc % 8 == 0 and 2048 % max(Cc, 1) == 0
+            and bn.activation in ("leaky_relu", "identity")):
+        return None
+    needs_grad = torch.is_grad_enabled() and (z.requires_grad or (bn.weight is not None and bn.weight.requires_grad))
+    if needs_grad and not bn.training:
+        return None
+    act = _act_code(bn.activation) | (hip.NORM_ABS_GAMMA if bn._abs_gamma else 0)
+    if bn.training:
+        bn.__dict__.pop("_eval_cache", None)
+    return _StemABNPoolFunction.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, bn.momentum, bn.eps, act,
+                                      bn.activation_param, bn._group(), None if bn.training else bn._eval_constants())
+
+
 class ABN(nn.Module):
     """BatchNorm + activation on the HIP kernels; base class of the in-place variants."""
 

@@ -60,8 +60,21 @@ class ResNet(nn.Module):
             self.classifier = nn.Sequential(OrderedDict(
                 [("avg_pool", GlobalAvgPool2d()), ("fc", nn.Linear(cin, classes))]))
 
+    def _stem(self, x):
+        """mod1 = conv1 -> norm_act -> 3x3/2 max pool (models/resnet.py:58-64).  With the HIP ABN the norm's apply pass and the
+        pooling are one kernel and their backward two (ucd_amd.abn.stem_norm_pool, csrc/stem.hip); otherwise the modules."""
+        m = self.mod1
+        if hasattr(m, "pool1") and getattr(m.bn1, "ucd_fused_abn", False) and x.is_cuda:
+            pool = m.pool1
+            if (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False):
+                from .abn import stem_norm_pool
+                z = m.conv1(x)
+                y = stem_norm_pool(m.bn1, z)
+                return y if y is not None else pool(m.bn1(z))
+        return m(x)
+
     def forward(self, x):
-        outs = [self.mod1(x)]
+        outs = [self._stem(x)]
         for name in ("mod2", "mod3", "mod4", "mod5"):
             outs.append(getattr(self, name)(outs[-1]))
         if hasattr(self, "classifier"):

@@ -346,11 +346,15 @@ def _is_fused_abn(m) -> bool:
 
 
 def _own_gemm_with_stats(K, N):
-    """Forward kernel choice of a conv + training-ABN pair, from tools/conv1x1_probe.py on MI355X (M = 26 136): the fused GEMM
-    with the statistics epilogue costs its plain time + 1-4 us; the tuned library GEMM needs a statistics pass over its
-    output on top (11-30 us).  The library only stays ahead where the product is large on both sides (2048 -> 512: 44 + 16
-    against 72 us; 1024 -> 2048: 101 + 30 against 134)."""
-    return not (K * N >= (1 << 20) and K >= 1024)
+    """Forward kernel choice of a conv + training-ABN pair, from tools/conv1x1_probe.py on MI355X (M = 26 136,
+    profiles/r03_conv1x1_probe.txt): the fused GEMM with the statistics epilogue costs its plain time + 1-6 us; the tuned library
+    GEMM needs a statistics pass over its output on top (11-30 us).  Since the staging loads go through buffer descriptors the own
+    kernel is level or ahead on every layer of the network, the two large products included (2048 -> 512: 59.6 against 43.5 + 16;
+    1024 -> 2048: 110.8 against 93.1 + 30), so every aligned 1x1 layer takes it; ``UCD_LIB_GEMM_WIDE=1`` restores the library
+    for those two (A/B)."""
+    if os.environ.get("UCD_LIB_GEMM_WIDE", "0") == "1":
+        return not (K * N >= (1 << 20) and K >= 1024)
+    return True
 
 
 def _own_conv3x3(M, K, N):

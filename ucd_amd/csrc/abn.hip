@@ -855,6 +855,17 @@ int ucd_abn_sync_forward(const void* x, int ld_x, void* y, int ld_y, const void*
   return ucd_abn_apply(x, ld_x, y, ld_y, residual, ld_r, dtype, M, C, plane_bias, HW, mean, scale, bias, act, slope, stream);
 }
 
+int ucd_abn_sync_finalize(const float* gathered, int world, int M, int C, const float* weight, float* running_mean,
+                          float* running_var, float momentum, float eps, float* buf, int flags, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_sync_finalize";
+  UCD_REQUIRE(gathered && buf && world >= 1 && C > 0 && M > 0, UCD_EINVAL, "%s: bad arguments", fn);
+  float *mean = buf + 3 * C, *invstd = buf + 4 * C, *scale = buf + 5 * C;
+  FinalizeArgs fin{nullptr, weight, running_mean, running_var, mean, invstd, scale, (float)M * (float)world, momentum, eps,
+                   nullptr, (flags & UCD_NORM_ABS_GAMMA) != 0};
+  abn_combine_finalize_kernel<<<ceil_div(C, 256), 256, 0, (hipStream_t)stream>>>(gathered, world, C, (float)M, fin);
+  return check_launch(fn);
+}
+
 int ucd_abn_sync_forward_comm(ucd_comm_t comm, int world, const void* x, int ld_x, void* y, int ld_y, const void* residual,
                               int ld_r, int dtype, int M, int C, const float* plane_bias, int HW, const float* weight,
                               const float* bias, float* running_mean, float* running_var, float momentum, float eps,

@@ -1,0 +1,310 @@
+// The stem's norm + pooling as one pass (models/resnet.py:58-64: mod1 = conv1 7x7/2 -> norm_act -> MaxPool2d(3, stride 2, padding 1)).
+//
+// The 7x7 convolution leaves the LARGEST activation of the network ([B, 64, 257, 257] at 513^2: 203 MB in bf16 for B = 24); the
+// layer-by-layer path writes its normalised copy (203 MB), the pooling reads that back and writes a quarter of it, and the
+// backward walks the same maps three more times (pooling backward, the norm's reduction, the norm's apply).  Here
+//   forward   out[b, ph, pw, c] = max over the 3x3 window (stride 2, padding 1) of act((z - mean_c) scale_c + beta_c), each value
+//             rounded to bf16 before the comparison (so the result - and the first-maximum tie rule - is bit for bit that of
+//             max_pool2d(abn(z))); the normalised map is never written; idx keeps the window position (0..8) of the maximum;
+//   backward  the gradient of the pooled map reaches z only at the arg-max positions:  dyact = dpool * act'(.) there, 0 elsewhere;
+//             phase 1 sums  dyact  and  dyact * xhat  per channel over the pooled map (a quarter of the positions), phase 2 writes
+//             dz = gamma~ invstd (dyact - mean(dyact) - xhat mean(dyact xhat)) for every position of z, gathering dyact from the
+//             (at most four) windows a position belongs to through idx.  Between the phases SyncBN all-reduces the two sums.
+// One thread owns 8 channels (16 bytes) of one pixel; maps are dense channels-last bf16.
+#include "common.h"
+
+namespace ucd {
+namespace {
+
+typedef __hip_bfloat16 bf16;
+constexpr int kThreads = 256;
+constexpr int kRedBlocks = 1024;      // workgroups (= partial rows) of the backward reduction
+constexpr int kApplyRows = 4;         // the backward apply gives one thread 4 rows x 2 columns x 8 channels of z
+
+__device__ __forceinline__ float leaky(float z, float slope) { return z > 0.f ? z : z * slope; }
+__device__ __forceinline__ float bf16_round(float v) { return __bfloat162float(__float2bfloat16(v)); }
+
+struct StemArgs {
+  const bf16* z; int B, H, W, C, PH, PW;
+  const float *mean, *scale, *beta, *invstd, *weight, *sums;
+  float slope, inv_count;
+  int abs_gamma, cg_shift;
+};
+
+// window position (kh, kw) of pooled pixel (ph, pw) -> input pixel (2 ph - 1 + kh, 2 pw - 1 + kw)
+__global__ __launch_bounds__(kThreads) void stem_apply_pool_kernel(StemArgs p, bf16* __restrict__ out, uint8_t* __restrict__ idx) {
+  // grid (row chunks, PH, B): 32-bit index arithmetic only, the channel-group count is a power of two
+  const int cgs = p.cg_shift, CG = 1 << cgs;
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  const int cg = t & (CG - 1), pw = t >> cgs, ph = blockIdx.y, b = blockIdx.z;
+  if (pw >= p.PW) return;
+  const size_t pix = ((size_t)b * p.PH + ph) * p.PW + pw;
+  float mu[8], sc[8], sh[8], best[8];
+  int bi[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    mu[e] = p.mean[cg * 8 + e]; sc[e] = p.scale[cg * 8 + e]; sh[e] = p.beta ? p.beta[cg * 8 + e] : 0.f;
+    best[e] = -INFINITY; bi[e] = 0;
+  }
+  // all nine loads are issued before the first use: positions outside the map load a clamped (valid) address and are masked after
+  Vec<bf16> v[9];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int y = min(max(2 * ph - 1 + kh, 0), p.H - 1);
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int x = min(max(2 * pw - 1 + kw, 0), p.W - 1);
+      v[kh * 3 + kw].load(p.z + (((size_t)b * p.H + y) * p.W + x) * p.C + cg * 8);
+    }
+  }
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const bool yin = (unsigned)(2 * ph - 1 + kh) < (unsigned)p.H;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const bool in = yin && (unsigned)(2 * pw - 1 + kw) < (unsigned)p.W;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float a = bf16_round(leaky((v[kh * 3 + kw].get(e) - mu[e]) * sc[e] + sh[e], p.slope));   // what the un-fused apply pass stores
+        if (in && a > best[e]) { best[e] = a; bi[e] = kh * 3 + kw; }                                  // first maximum wins (max_pool2d)
+      }
+    }
+  }
+  Vec<bf16> o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o.set(e, best[e]);
+  o.store(out + pix * p.C + cg * 8);
+  if (idx) {
+    uint2 w;
+    w.x = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+    w.y = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+    *reinterpret_cast<uint2*>(idx + pix * p.C + cg * 8) = w;
+  }
+}
+
+// phase 1: partial[block][0..C) = sum dyact, partial[block][C..2C) = sum dyact * xhat over the pooled pixels of the block
+__global__ __launch_bounds__(kThreads) void stem_pool_bwd_reduce_kernel(StemArgs p, const bf16* __restrict__ dpool,
+                                                                       const uint8_t* __restrict__ idx, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int CG = p.C / 8, PL = kThreads / CG;           // pixel lanes per workgroup
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  const long long npix = (long long)p.B * p.PH * p.PW;
+  float acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (pl < PL) {
+    float mu[8], sc[8], sh[8], is[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      mu[e] = p.mean[cg * 8 + e]; sc[e] = p.scale[cg * 8 + e]; sh[e] = p.beta ? p.beta[cg * 8 + e] : 0.f; is[e] = p.invstd[cg * 8 + e];
+    }
+    for (int pix = blockIdx.x * PL + pl; pix < (int)npix; pix += gridDim.x * PL) {
+      const int rowi = pix / p.PW;                              // one 32-bit division per pixel and thread
+      const int pw = pix - rowi * p.PW, b = rowi / p.PH, ph = rowi - b * p.PH;
+      Vec<bf16> g;
+      g.load(dpool + (size_t)pix * p.C + cg * 8);
+      const uint2 w = *reinterpret_cast<const uint2*>(idx + (size_t)pix * p.C + cg * 8);
+      float zsel[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      Vec<bf16> v[9];                      // an arg-max position is always inside the map, so clamped loads need no mask
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const int y = min(max(2 * ph - 1 + kh, 0), p.H - 1);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int x = min(max(2 * pw - 1 + kw, 0), p.W - 1);
+          v[kh * 3 + kw].load(p.z + (((size_t)b * p.H + y) * p.W + x) * p.C + cg * 8);
+        }
+      }
+#pragma unroll
+      for (int pos = 0; pos < 9; ++pos)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned id = ((e < 4 ? w.x : w.y) >> (8 * (e & 3))) & 0xffu;
+          zsel[e] = id == (unsigned)pos ? v[pos].get(e) : zsel[e];
+        }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xc = zsel[e] - mu[e];
+        const float dz = g.get(e) * (xc * sc[e] + sh[e] > 0.f ? 1.f : p.slope);
+        acc[e] += dz;
+        acc[8 + e] += dz * (xc * is[e]);
+      }
+    }
+  }
+  // reduce over the pixel lanes (fixed order), lanes past PL carry zeros
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lds[threadIdx.x * 16 + i] = acc[i];
+  __syncthreads();
+  if (pl == 0) {
+    for (int l = 1; l < PL; ++l)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] += lds[(l * CG + cg) * 16 + i];
+    float* dst = partial + (size_t)blockIdx.x * 2 * p.C + cg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dst[e] = acc[e]; dst[p.C + e] = acc[8 + e]; }
+  }
+}
+
+// phase 2: dz for every position of z
+__global__ __launch_bounds__(kThreads) void stem_pool_bwd_apply_kernel(StemArgs p, const bf16* __restrict__ dpool,
+                                                                      const uint8_t* __restrict__ idx, bf16* __restrict__ dz) {
+  const int cgs = p.cg_shift, CG = 1 << cgs;
+  const int t = blockIdx.x * kThreads + threadIdx.x;
+  const int cg = t & (CG - 1), i = t >> cgs, b = blockIdx.z;     // i: column pair (2 i, 2 i + 1)
+  if (2 * i >= p.W) return;
+  // per-channel constants of this thread's 8 channels, once for the 4 x 2 positions it owns
+  float mu[8], sc[8], sh[8], is[8], k0[8], k1[8], gw[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = cg * 8 + e;
+    mu[e] = p.mean[ch]; sc[e] = p.scale[ch]; sh[e] = p.beta ? p.beta[ch] : 0.f; is[e] = p.invstd[ch];
+    k0[e] = p.sums[ch] * p.inv_count;
+    k1[e] = p.sums[p.C + ch] * p.inv_count;
+    if (p.abs_gamma) {                 // sums[C + c] holds sign(weight) * sum dz xhat; scale = (|w| + eps) invstd  (abn_bwd_apply_kernel)
+      if (p.weight && p.weight[ch] < 0.f) k1[e] = -k1[e];
+      gw[e] = sc[e];
+    } else {
+      gw[e] = (p.weight ? p.weight[ch] : 1.f) * is[e];
+    }
+  }
+  // Rows 4 j .. 4 j + 3 lie in the windows of pooled rows 2 j, 2 j + 1, 2 j + 2 only (an even row 2 k in window k at kh = 1, an odd
+  // row 2 k + 1 in window k at kh = 2 and in window k + 1 at kh = 0); the same for the column pair.  So 3 x 2 gathers of
+  // (idx, dpool) serve 4 x 2 positions, all loads - clamped into the maps, masked afterwards - are issued before the first use.
+  const int phb = blockIdx.y * 2, y0 = blockIdx.y * kApplyRows, x0 = 2 * i;
+  Vec<bf16> g[3][2], v[kApplyRows][2];
+  uint2 w[3][2];
+  bool gv[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      gv[a][c] = phb + a < p.PH && i + c < p.PW;
+      const size_t off = (((size_t)b * p.PH + min(phb + a, p.PH - 1)) * p.PW + min(i + c, p.PW - 1)) * p.C + cg * 8;
+      w[a][c] = *reinterpret_cast<const uint2*>(idx + off);
+      g[a][c].load(dpool + off);
+    }
+#pragma unroll
+  for (int r = 0; r < kApplyRows; ++r)
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx)
+      v[r][cx].load(p.z + (((size_t)b * p.H + min(y0 + r, p.H - 1)) * p.W + min(x0 + cx, p.W - 1)) * p.C + cg * 8);
+#pragma unroll
+  for (int r = 0; r < kApplyRows; ++r) {
+    if (y0 + r >= p.H) break;                                    // uniform over the workgroup
+#pragma unroll
+    for (int cx = 0; cx < 2; ++cx) {
+      if (x0 + cx >= p.W) continue;
+      float dy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ya = 0; ya < 2; ++ya) {                           // the (at most two) windows over the row ...
+        if (ya == 1 && !(r & 1)) continue;
+        const int a = (r >> 1) + ya, kh = (r & 1) ? (ya ? 0 : 2) : 1;
+#pragma unroll
+        for (int xa = 0; xa < 2; ++xa) {                         // ... and over the column
+          if (xa == 1 && !cx) continue;
+          const int kw = cx ? (xa ? 0 : 2) : 1;
+          const unsigned pos = gv[a][xa] ? (unsigned)(kh * 3 + kw) : 0xffu;    // 0xff never equals a stored position
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const unsigned id = ((e < 4 ? w[a][xa].x : w[a][xa].y) >> (8 * (e & 3))) & 0xffu;
+            dy[e] += id == pos ? g[a][xa].get(e) : 0.f;
+          }
+        }
+      }
+      Vec<bf16> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xc = v[r][cx].get(e) - mu[e];
+        const float dza = dy[e] * (xc * sc[e] + sh[e] > 0.f ? 1.f : p.slope);
+        o.set(e, (dza - k0[e] - (xc * is[e]) * k1[e]) * gw[e]);
+      }
+      o.store(dz + (((size_t)b * p.H + y0 + r) * p.W + x0 + cx) * p.C + cg * 8);
+    }
+  }
+}
+
+// sums[c] / sums[C + c] over the kRedBlocks partial rows (fixed order); abs-gamma layers carry sign(weight) on the second row
+__global__ __launch_bounds__(kThreads) void stem_sum_partials_kernel(const float* __restrict__ partial, int rows, int C,
+                                                                    const float* __restrict__ sign_of, float* __restrict__ sums) {
+  __shared__ float red[kThreads];
+  const int k = blockIdx.x;                       // one workgroup per output value (2 C of them)
+  float s = 0.f;
+  for (int r = threadIdx.x; r < rows; r += kThreads) s += partial[(size_t)r * 2 * C + k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int st = kThreads / 2; st > 0; st >>= 1) {
+    if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float t = red[0];
+    if (sign_of && k >= C && sign_of[k - C] < 0.f) t = -t;
+    sums[k] = t;
+  }
+}
+
+bool stem_args_ok(const void* z, int B, int H, int W, int C) {
+  return z && B > 0 && B < 65536 && H > 1 && H < 65536 && W > 1 && C >= 8 && (C & (C - 1)) == 0 && C <= 2048 && aligned16(z);
+}
+
+}  // namespace
+}  // namespace ucd
+
+using namespace ucd;
+
+extern "C" {
+
+int ucd_stem_pooled_size(int n) { return (n + 2 - 3) / 2 + 1; }
+
+size_t ucd_stem_pool_workspace_bytes(int C) { return (size_t)kRedBlocks * 2 * C * sizeof(float); }
+
+int ucd_stem_apply_pool(const void* z, int B, int H, int W, int C, const float* mean, const float* scale, const float* beta, int act,
+                        float slope, void* out, uint8_t* idx, ucd_stream_t stream) {
+  static const char* fn = "ucd_stem_apply_pool";
+  UCD_REQUIRE(stem_args_ok(z, B, H, W, C) && mean && scale && out && aligned16(out) && (!idx || (reinterpret_cast<uintptr_t>(idx) & 7) == 0),
+              UCD_EINVAL, "%s: dense channels-last bf16 maps with a power-of-two channel count in 8..2048 expected", fn);
+  const int a = act & UCD_ACT_MASK;
+  UCD_REQUIRE(a != UCD_ACT_ELU, UCD_EUNSUPPORTED, "%s: leaky_relu / identity only (an elu stem keeps the separate passes)", fn);
+  StemArgs p{};
+  p.z = (const bf16*)z; p.B = B; p.H = H; p.W = W; p.C = C; p.PH = ucd_stem_pooled_size(H); p.PW = ucd_stem_pooled_size(W);
+  p.mean = mean; p.scale = scale; p.beta = beta; p.slope = a == UCD_ACT_IDENTITY ? 1.f : slope;
+  p.cg_shift = __builtin_ctz(C / 8);
+  stem_apply_pool_kernel<<<dim3(ceil_div(p.PW * (C / 8), kThreads), p.PH, B), kThreads, 0, (hipStream_t)stream>>>(p, (bf16*)out, idx);
+  return check_launch(fn);
+}
+
+/* phase 1 (reduce -> sums), 2 (apply with the given sums), 3 (both).  sums [2 C]: sum dyact | sum dyact xhat (x sign(weight) for
+ * the |gamma| + eps layers: the layer's d bias | d weight); count = positions per channel over ALL ranks (B H W x world). */
+int ucd_stem_pool_backward(const void* z, const void* dpool, const uint8_t* idx, int B, int H, int W, int C, const float* mean,
+                           const float* invstd, const float* scale, const float* beta, const float* weight, float* sums, float count,
+                           int act, float slope, void* dz, void* workspace, size_t workspace_bytes, int phase, ucd_stream_t stream) {
+  static const char* fn = "ucd_stem_pool_backward";
+  UCD_REQUIRE(stem_args_ok(z, B, H, W, C) && dpool && idx && mean && invstd && scale && sums && aligned16(dpool), UCD_EINVAL,
+              "%s: bad arguments", fn);
+  UCD_REQUIRE(phase >= 1 && phase <= 3 && (!(phase & 2) || (dz && aligned16(dz) && count > 0.f)), UCD_EINVAL, "%s: bad phase / dz", fn);
+  const int a = act & UCD_ACT_MASK;
+  UCD_REQUIRE(a != UCD_ACT_ELU, UCD_EUNSUPPORTED, "%s: leaky_relu / identity only", fn);
+  StemArgs p{};
+  p.z = (const bf16*)z; p.B = B; p.H = H; p.W = W; p.C = C; p.PH = ucd_stem_pooled_size(H); p.PW = ucd_stem_pooled_size(W);
+  p.mean = mean; p.scale = scale; p.beta = beta; p.invstd = invstd; p.weight = weight; p.sums = sums;
+  p.slope = a == UCD_ACT_IDENTITY ? 1.f : slope; p.abs_gamma = (act & UCD_NORM_ABS_GAMMA) != 0;
+  p.cg_shift = __builtin_ctz(C / 8);
+  hipStream_t s = (hipStream_t)stream;
+  if (phase & 1) {
+    UCD_REQUIRE(workspace && workspace_bytes >= ucd_stem_pool_workspace_bytes(C), UCD_EWORKSPACE, "%s: workspace too small", fn);
+    stem_pool_bwd_reduce_kernel<<<kRedBlocks, kThreads, kThreads * 16 * sizeof(float), s>>>(p, (const bf16*)dpool, idx, (float*)workspace);
+    int rc = check_launch(fn);
+    if (rc) return rc;
+    stem_sum_partials_kernel<<<2 * C, kThreads, 0, s>>>((const float*)workspace, kRedBlocks, C, p.abs_gamma ? weight : nullptr, sums);
+    rc = check_launch(fn);
+    if (rc) return rc;
+  }
+  if (phase & 2) {
+    p.inv_count = 1.f / count;
+    stem_pool_bwd_apply_kernel<<<dim3(ceil_div(((W + 1) / 2) * (C / 8), kThreads), ceil_div(H, kApplyRows), B), kThreads, 0, s>>>(p, (const bf16*)dpool, idx, (bf16*)dz);
+    return check_launch(fn);
+  }
+  return 0;
+}
+
+}  // extern "C"

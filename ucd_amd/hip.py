@@ -102,6 +102,11 @@ SIGNATURES = {
     "ucd_abn_reduce_partials": (_i, [_p, _i, _i, _p, _p, _p, _i, _p]),
     "ucd_conv1x1_wgrad_workspace_bytes": (_z, [_i, _i, _i]),
     "ucd_conv1x1_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
+    "ucd_abn_sync_finalize": (_i, [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p, _i, _p]),
+    "ucd_stem_pooled_size": (_i, [_i]),
+    "ucd_stem_pool_workspace_bytes": (_z, [_i]),
+    "ucd_stem_apply_pool": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _i, _f, _p, _p, _p]),
+    "ucd_stem_pool_backward": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _z, _i, _p]),
     "ucd_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "ucd_conv_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
@@ -556,6 +561,38 @@ def conv1x1_wgrad(dy, a, dw, in_norm=None):
         _check(lib.ucd_conv1x1_wgrad(ptr(dy), dy.stride(0), ptr(a), a.stride(0), M, N, K, ptr(mean), ptr(scale), ptr(shift),
                                      act & ACT_MASK, float(slope), ptr(dw), ptr(ws), nbytes, stream()), "ucd_conv1x1_wgrad")
     return dw
+
+
+def abn_sync_finalize(gathered, world, M, Cc, weight, running_mean, running_var, momentum, eps, buf, flags=0):
+    _check(load().ucd_abn_sync_finalize(ptr(gathered), world, M, Cc, ptr(weight), ptr(running_mean), ptr(running_var),
+                                        float(momentum), float(eps), ptr(buf), int(flags) & NORM_ABS_GAMMA, stream()),
+           "ucd_abn_sync_finalize")
+
+
+def stem_apply_pool(z, mean, scale, beta, act, slope, want_idx):
+    """max_pool2d(abn_apply(z), 3, 2, 1) in one pass (ucd_stem_apply_pool); ``z`` [B, C, H, W] dense channels-last bf16.
+    Returns (pooled map, uint8 index map or None)."""
+    lib = load()
+    B, Cc, H, W = z.shape
+    PH, PW = lib.ucd_stem_pooled_size(H), lib.ucd_stem_pooled_size(W)
+    out = torch.empty((B, Cc, PH, PW), dtype=z.dtype, device=z.device, memory_format=torch.channels_last)
+    idx = torch.empty((B, PH, PW, Cc), dtype=torch.uint8, device=z.device) if want_idx else None
+    with _timed("ucd_stem_apply_pool", (z.numel() + out.numel()) * 2 + (idx.numel() if idx is not None else 0)):
+        _check(lib.ucd_stem_apply_pool(ptr(z), B, H, W, Cc, ptr(mean), ptr(scale), ptr(beta), act, float(slope), ptr(out), ptr(idx),
+                                       stream()), "ucd_stem_apply_pool")
+    return out, idx
+
+
+def stem_pool_backward(z, dpool, idx, mean, invstd, scale, beta, weight, sums, count, act, slope, dz, phase):
+    lib = load()
+    B, Cc, H, W = z.shape
+    nbytes = lib.ucd_stem_pool_workspace_bytes(Cc)
+    ws = workspace(nbytes, z.device)
+    work = (z.numel() * (2 if phase & 1 else 0) + (2 * z.numel() * 2 if phase & 2 else 0) + dpool.numel() * 3 * (1 + (phase == 3)))
+    with _timed("ucd_stem_pool_backward", work):
+        _check(lib.ucd_stem_pool_backward(ptr(z), ptr(dpool), ptr(idx), B, H, W, Cc, ptr(mean), ptr(invstd), ptr(scale), ptr(beta),
+                                          ptr(weight), ptr(sums), float(count), act, float(slope), ptr(dz), ptr(ws), nbytes,
+                                          int(phase), stream()), "ucd_stem_pool_backward")
 
 
 def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False):
