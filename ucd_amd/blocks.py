@@ -361,11 +361,14 @@ def _own_conv3x3(M, K, N):
     """The implicit-GEMM 3x3 (csrc/conv1x1.hip, taps = 9) instead of MIOpen: measured on MI355X (tools/conv3x3_probe.py,
     B = 24, profiles/r03_conv3x3_probe.txt): 256->256 at 33^2 40 vs 58 us, 512->512 (dilation 2) 132 vs 142, 128->128 at 65^2
     42 vs 48, 64->64 at 129^2 51 vs 63, the ASPP branches 229-252 vs 386-391 - and the following ABN's statistics for +1 us
-    instead of a separate pass; MIOpen keeps the maps too small to give every CU a tile (3 images per GPU: 23 vs 27 us)."""
+    instead of a separate pass.  Maps too small to give every CU a tile (3-12 images per GPU, the multi-GPU split of the batch) take
+    it as well: the kernel alone is level with MIOpen's there (23 vs 27 us at 3 images) but the step saves MIOpen's weight-gradient
+    zero fills / casts and the separate statistics passes - kernel time per step 16.0 -> 14.3 ms at 3 images, 20.0 -> 17.5 at 6
+    (profiles/r03_small_batch.txt).  ``UCD_OWN3X3_MIN_TILES=256`` restores the library below 256 tiles (A/B)."""
     tiles = ((M + 127) // 128) * max(1, N // 128)
     if K >= 512 and N >= 512 and os.environ.get("UCD_OWN3X3_WIDE", "1") == "0":      # A/B switch: the 512 -> 512 layers on MIOpen
         return False
-    return tiles >= 256
+    return tiles >= int(os.environ.get("UCD_OWN3X3_MIN_TILES", "1"))
 
 
 class _ConvABNFunction(torch.autograd.Function):
