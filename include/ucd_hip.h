@@ -453,6 +453,10 @@ typedef struct ucd_conv1x1_desc {
   int taps, H, W, dilation;
   /* out_mode 4 only: the conv output z of the residual block whose OUTPUT is `residual` (x-hat of its last norm's sums) */
   const void* side2;  int ld2;
+  /* stride > 1 (0 and 1: none): the strided layers of the first block of a stage (modules/residual.py:57-73 conv2 with
+   * stride 2, :79 proj_conv 1x1 stride 2).  a is the [B, H, W, K] map, y the [B, OH, OW, N] one with OH = (H - 1) / stride + 1
+   * (padding 0 for taps <= 1, padding = dilation for taps = 9), M = B*OH*OW; out_mode 0, 1 or 2, no input transform. */
+  int stride;
 } ucd_conv1x1_desc;
 
 int ucd_conv1x1_row_tiles(int M);
@@ -513,6 +517,12 @@ int ucd_stem_pool_backward(const void* z, const void* dpool, const uint8_t* idx,
 size_t ucd_conv_wgrad_workspace_bytes(int M, int N, int K, int taps);
 int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
                    void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, ucd_stream_t stream);
+/* The same for the strided layers (modules/residual.py:57-73 conv2 with stride 2, :79 proj_conv 1x1 stride 2): x is the
+ * [B, H, W, K] input map, dz the [M = B*OH*OW][N] output gradient with OH = (H - 1) / stride + 1; N and K multiples of 128.
+ * stride <= 1 is ucd_conv_wgrad. */
+int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W,
+                           int dilation, int stride, void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes,
+                           ucd_stream_t stream);
 
 /* The weights of the input-gradient convolutions of ALL stride-1 layers in one launch: for table entry e = {src offset,
  * dst offset, Co, Ci, KH*KW} (elements into the flat bf16 buffers; 4-D weights in channels-last memory order

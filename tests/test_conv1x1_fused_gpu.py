@@ -818,3 +818,80 @@ def test_conv_wgrad_exact_on_integers_and_against_fp32(M, N, K, sp):
     acc = base.clone()
     hip.conv_wgrad(z, x, None, conv3=sp, dw32=acc, accumulate32=True)
     assert _rel(acc - base, ref) < 1e-4
+
+
+# ---- the strided layers (first block of a stage: conv2 3x3 stride 2, proj_conv 1x1 stride 2; modules/residual.py:57-82) -------
+STRIDED_CASES = [
+    # B, H, W, K (in), N (out), taps, dilation
+    (2, 9, 11, 64, 64, 1, 1), (2, 9, 11, 128, 128, 9, 1), (3, 10, 8, 128, 256, 9, 1), (24, 129, 129, 256, 512, 1, 1),
+    (24, 65, 65, 512, 1024, 1, 1), (24, 129, 129, 128, 128, 9, 1), (24, 65, 65, 256, 256, 9, 1), (3, 65, 65, 256, 256, 9, 2),
+]
+
+
+def _strided_ref(x4, w4, taps, d):
+    """fp32 F.conv2d of the NCHW views (padding 0 for 1x1, = dilation for 3x3), rows of the channels-last result."""
+    y = F.conv2d(x4.float(), w4.float(), None, 2, d if taps == 9 else 0, d if taps == 9 else 1)
+    return y.permute(0, 2, 3, 1).reshape(-1, y.shape[1]), y.shape[2], y.shape[3]
+
+
+@pytest.mark.parametrize("B,H,W,K,N,taps,d", STRIDED_CASES)
+def test_strided_forward_statistics_and_weight_gradient(B, H, W, K, N, taps, d):
+    """ucd_conv1x1 with stride 2 (the 1x1 row gather and the 3x3 implicit GEMM over the strided pixels) and
+    ucd_conv_wgrad_strided against F.conv2d / its weight gradient: exact on sparse small integers (every sum an exactly
+    representable integer), then at bf16 rounding on random operands; the out_mode-2 partials give the batch statistics of the
+    strided product."""
+    from ucd_amd import hip
+    g = torch.Generator(DEV).manual_seed(B * H + K + N + taps)
+    k = 3 if taps == 9 else 1
+    cl = torch.channels_last
+
+    def operands(integer):
+        if integer:
+            x = (torch.randint(-2, 3, (B, K, H, W), device=DEV, generator=g) * (torch.rand(B, K, H, W, device=DEV, generator=g) < 0.2))
+            w = (torch.randint(-1, 2, (N, K, k, k), device=DEV, generator=g) * (torch.rand(N, K, k, k, device=DEV, generator=g) < 0.3))
+        else:
+            x = torch.randn(B, K, H, W, device=DEV, generator=g) * 1.3 + 0.2
+            w = torch.randn(N, K, k, k, device=DEV, generator=g) * (taps * K) ** -0.5
+        return x.bfloat16().contiguous(memory_format=cl), w.bfloat16().contiguous(memory_format=cl)
+
+    for integer in (True, False):
+        x4, w4 = operands(integer)
+        ref, OH, OW = _strided_ref(x4, w4, taps, d)
+        M = B * OH * OW
+        xr = x4.permute(0, 2, 3, 1).reshape(B * H * W, K)
+        wr = w4.permute(0, 2, 3, 1).reshape(N, taps * K)
+        y = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        partial = hip.conv1x1_stats_partial(M, N, DEV)
+        kw = dict(conv3=(H, W, d, 2)) if taps == 9 else dict(strided=(H, W, 2))
+        hip.conv1x1(xr, wr, y, out_mode=2, partial=partial, **kw)
+        if integer:
+            assert ref.abs().max().item() <= 256
+            assert torch.equal(y.float(), ref)
+        else:
+            assert _rel(y, ref) < 4e-3
+        buf = torch.zeros(6 * N, device=DEV)
+        rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+        hip.conv1x1_stats_finalize(partial, M, N, None, rm, rv, 0.1, 1e-5, buf)
+        yf = y.float()
+        assert torch.allclose(buf[3 * N:4 * N], yf.mean(0), atol=2e-3 * max(1.0, yf.abs().max().item()), rtol=1e-3)
+        assert torch.allclose(buf[4 * N:5 * N], (yf.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=2e-3)
+        # weight gradient: dz over the output map, x the input map
+        if N % 128 or K % 128:
+            continue
+        if integer:
+            dz = (torch.randint(-2, 3, (M, N), device=DEV, generator=g) * (torch.rand(M, N, device=DEV, generator=g) < min(0.5, (24.0 / M) ** 0.5))).bfloat16()
+        else:
+            dz = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        dz4 = dz.view(B, OH, OW, N).permute(0, 3, 1, 2)
+        pad, dil = (d, d) if taps == 9 else (0, 1)
+        gw = torch.ops.aten.convolution_backward(dz4.float(), x4.float(), w4.float(), None, [2, 2], [pad, pad], [dil, dil], False, [0, 0],
+                                                 1, [False, True, False])[1]
+        gw = gw.permute(0, 2, 3, 1).reshape(N, taps * K)
+        dw = torch.full((N, taps * K), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dw32 = torch.full((N, taps * K), float("nan"), device=DEV)
+        hip.conv_wgrad(dz, xr, dw, dw32=dw32, **kw)
+        if integer:
+            assert gw.abs().max().item() <= 256
+            assert torch.equal(dw32, gw) and torch.equal(dw.float(), gw)
+        else:
+            assert _rel(dw, gw) < 3e-3 and _rel(dw32, gw) < 1e-4

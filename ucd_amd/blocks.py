@@ -357,6 +357,21 @@ def _own_gemm_with_stats(K, N):
     return True
 
 
+def _own_stride(conv):
+    """The stride s > 1 of a layer the own strided kernels take (csrc/conv1x1.hip ``stride``, csrc/wgrad.hip STR): the first
+    block of a stage - conv2 3x3 with padding = dilation and proj_conv 1x1 with padding 0 (modules/residual.py:57-82), 128-aligned
+    channels - else 0.  MIOpen needs 209-263 us for each of the four forward products at B = 24 (tools/aten_ops.py), 5-15x their
+    traffic / MFMA time.  ``UCD_OWN_STRIDED=0`` keeps the library (A/B)."""
+    if not (isinstance(conv, Conv2d) and conv.stride[0] == conv.stride[1] and conv.stride[0] > 1 and conv.groups == 1
+            and conv.in_channels % 128 == 0 and conv.out_channels % 128 == 0 and os.environ.get("UCD_OWN_STRIDED", "1") != "0"):
+        return 0
+    if conv.kernel_size == (1, 1) and conv.padding == (0, 0):
+        return conv.stride[0]
+    if conv.kernel_size == (3, 3) and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1]:
+        return conv.stride[0]
+    return 0
+
+
 def _own_conv3x3(M, K, N):
     """The implicit-GEMM 3x3 (csrc/conv1x1.hip, taps = 9) instead of MIOpen: measured on MI355X (tools/conv3x3_probe.py,
     B = 24, profiles/r03_conv3x3_probe.txt): 256->256 at 33^2 40 vs 58 us, 512->512 (dilation 2) 132 vs 142, 128->128 at 65^2
@@ -539,12 +554,22 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     if residual is not None and os.environ.get("UCD_BLOCK_LINK", "1") == "0":
         make_link = False
     is3 = isinstance(conv, Conv3x3)
-    if not ((is3 or (isinstance(conv, Conv1x1) and conv.as_gemm)) and conv.bias is None and conv.weight.requires_grad
+    stride = _own_stride(conv) if not (with_skip or residual is not None) else 0
+    if stride:
+        is3 = conv.kernel_size == (3, 3)
+    if not ((is3 or stride or (isinstance(conv, Conv1x1) and conv.as_gemm)) and conv.bias is None and conv.weight.requires_grad
             and _is_fused_abn(bn) and bn.training and bn.weight is not None and torch.is_grad_enabled() and x.is_cuda
             and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0):
         return None
     dilation, wflip, fused, own_dgrad, wgrad_conv = 0, None, None, False, 0      # wgrad_conv: 0 batched products, 1 MIOpen, 2 own
-    if is3:
+    if stride:
+        # the strided layers of a stage's first block: forward (+ statistics) and weight gradient on the own kernels, the input
+        # gradient stays with the library's backward-data solver; no link consumed (the producer falls back to its own reduction)
+        if is3 and not conv.weight.is_contiguous(memory_format=torch.channels_last):
+            return None
+        dilation, fused, link, blink = (conv.dilation[0] if is3 else 0), True, None, None
+        wgrad_conv = 1
+    elif is3:
         if not (conv.stride == (1, 1) and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1]
                 and conv.groups == 1 and not with_skip and conv.weight.is_contiguous(memory_format=torch.channels_last)):
             return None
@@ -572,6 +597,8 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     node = _gemm_node()
     if node is None or not hasattr(node, "conv_abn_train"):
         # no C++ node (not built, or switched off by bench.py's instrumented pass): the Python twin, single process only
+        if stride:
+            return None                          # the twin has no strided form: the module path
         dense = lambda t: t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and t.shape[2] > 1 and t.shape[3] > 1
         if (_lib_gemm() is None or _abn._group_size(bn._group()) > 1 or not dense(x)
                 or (residual is not None and not (dense(residual) and residual.dtype == x.dtype))):
@@ -611,7 +638,7 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
                               bool(make_link),
                               *((blink[0], blink[1], None, blink[2], blink[3], 0, float(blink[4]), 3) if blink is not None else
                                 (link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]), 1) if link is not None
-                                else (None, None, None, None, None, 0, 0.0, 0)))
+                                else (None, None, None, None, None, 0, 0.0, 0)), int(stride) if stride else 1)
     k = 2 if with_skip else 1
     if len(out) > k:                             # the node made a link: (z, buf, partial, flag) follow the regular outputs
         if residual is None:
@@ -745,12 +772,29 @@ class ResidualBlock(nn.Module):
             h2 = torch.empty((B, cv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
             hip.conv1x1(rows(h1), w3.permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * cv.in_channels), rows(h2), out_mode=1,
                         out_norm=self._eval_norm(c.bn2), conv3=(H, W, cv.dilation[0]))       # conv2 + bn2: one kernel
+        elif _own_stride(cv) and cv.kernel_size == (3, 3):          # the stage's first block: conv2 with a stride, + bn2
+            st = _own_stride(cv)
+            w3 = cv.working_weight()
+            if w3 is None:
+                w3 = cv.weight.to(x.dtype)
+            if not w3.is_contiguous(memory_format=cl):
+                w3 = w3.contiguous(memory_format=cl)
+            h2 = torch.empty((B, cv.out_channels, (H - 1) // st + 1, (W - 1) // st + 1), dtype=x.dtype, device=x.device,
+                             memory_format=cl)
+            hip.conv1x1(rows(h1), w3.permute(0, 2, 3, 1).reshape(cv.out_channels, 9 * cv.in_channels), rows(h2), out_mode=1,
+                        out_norm=self._eval_norm(c.bn2), conv3=(H, W, cv.dilation[0], st))
         else:
             h2 = c.bn2(c.conv2(h1))                                # in place under no_grad (InPlaceABN contract)
         if hasattr(self, "proj_conv"):
+            pst = _own_stride(self.proj_conv)
             if isinstance(self.proj_conv, Conv1x1) and self.proj_conv.in_channels % 64 == 0:
                 res = torch.empty((B, self.proj_conv.out_channels, H, W), dtype=x.dtype, device=x.device, memory_format=cl)
                 hip.conv1x1(xr, w2d(self.proj_conv, x), rows(res), out_mode=1, out_norm=self._eval_norm(self.proj_bn))
+            elif pst and self.proj_conv.kernel_size == (1, 1):     # strided shortcut projection + proj_bn: one row-gather product
+                res = torch.empty((B, self.proj_conv.out_channels, (H - 1) // pst + 1, (W - 1) // pst + 1), dtype=x.dtype,
+                                  device=x.device, memory_format=cl)
+                hip.conv1x1(xr, w2d(self.proj_conv, x), rows(res), out_mode=1, out_norm=self._eval_norm(self.proj_bn),
+                            strided=(H, W, pst))
             else:
                 res = self.proj_bn(self.proj_conv(x))
         else:

@@ -71,14 +71,16 @@ bool own_wgrad_ok(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w
                         : (w4.size(2) == 3 && w4.size(3) == 3));
 }
 
-at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w4, int64_t dilation, int64_t stream) {
-  const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0), M = B * H * W;
+// stride > 1 (the first block of a stage: conv2 3x3 / proj_conv 1x1 with stride 2): dz is the smaller output map
+at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w4, int64_t dilation, int64_t stream,
+                     int64_t stride = 1) {
+  const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0), M = B * dz.size(2) * dz.size(3);
   const int taps = dilation > 0 ? 9 : 1;
   at::Tensor dw = at::empty({N, taps == 9 ? 3 : 1, taps == 9 ? 3 : 1, K}, x.options().memory_format(c10::nullopt));
   const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)N, (int)K, taps);
-  check(ucd_conv_wgrad(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
-                       (int)(dilation > 0 ? dilation : 1), dw.data_ptr(), nullptr, 0, workspace(x, wsb, stream, 2), wsb,
-                       (ucd_stream_t)stream),
+  check(ucd_conv_wgrad_strided(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
+                               (int)(dilation > 0 ? dilation : 1), (int)stride, dw.data_ptr(), nullptr, 0,
+                               workspace(x, wsb, stream, 2), wsb, (ucd_stream_t)stream),
         "ucd_conv_wgrad");
   return dw.permute({0, 3, 1, 2});      // [N, K, kh, kw] with channels-last strides: the weight's own memory order
 }
@@ -466,7 +468,11 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                c10::optional<at::Tensor> wflip_, bool own_dgrad, int64_t wgrad_conv, bool make_link,
                                c10::optional<at::Tensor> lk_z_, c10::optional<at::Tensor> lk_buf_,
                                c10::optional<at::Tensor> lk_bias_, c10::optional<at::Tensor> lk_partial_,
-                               c10::optional<at::Tensor> lk_flag_, int64_t lk_act, double lk_slope, int64_t lk_kind) {
+                               c10::optional<at::Tensor> lk_flag_, int64_t lk_act, double lk_slope, int64_t lk_kind,
+                               int64_t stride) {
+    // stride > 1: the strided layers of the first block of a stage (conv2 3x3 stride 2 with padding = dilation, proj_conv 1x1
+    // stride 2): forward and weight gradient on the own kernels (the strided row gather / implicit GEMM, ucd_conv_wgrad_strided),
+    // input gradient through the library's backward-data solver; no shortcut fold, no link consumed (it may still MAKE one).
     // Backward link between two nodes of a chain  A (conv + ABN) -> B (conv + ABN)  where A's output feeds B only:
     // B's input-gradient product applies A's activation derivative and accumulates A's two backward sums in its epilogue
     // (ucd_conv1x1 out_mode 3), so A's backward skips its reduction pass (ucd_abn_bwd_reduce: two reads of the map).
@@ -489,14 +495,17 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     at::Tensor residual = residual_.has_value() ? *residual_ : at::Tensor();
     const bool has_res = residual.defined();
     const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0);
-    const int64_t HW = H * W, M = B * HW;
+    if (stride < 1) stride = 1;
+    TORCH_CHECK(stride == 1 || (!with_skip && !lk_z_.has_value()), "ucd conv+abn node: a strided layer takes no shortcut fold / link");
+    const int64_t OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    const int64_t HW = OH * OW, M = B * HW;                     // rows of the OUTPUT map
     if (has_res)
-      TORCH_CHECK(dense_channels_last(residual) && residual.size(1) == N && residual.size(0) == B && residual.size(2) == H &&
-                      residual.size(3) == W && residual.scalar_type() == at::kBFloat16,
+      TORCH_CHECK(dense_channels_last(residual) && residual.size(1) == N && residual.size(0) == B && residual.size(2) == OH &&
+                      residual.size(3) == OW && residual.scalar_type() == at::kBFloat16,
                   "ucd conv+abn node: residual must match the output");
     const bool sync = comm != 0;
     auto opts = x.options().memory_format(at::MemoryFormat::ChannelsLast);
-    at::Tensor z = at::empty({B, N, H, W}, opts), y = at::empty({B, N, H, W}, opts);
+    at::Tensor z = at::empty({B, N, OH, OW}, opts), y = at::empty({B, N, OH, OW}, opts);
     at::Tensor buf = at::empty({(sync ? 8 + 2 * world : 6) * N}, x.options().dtype(at::kFloat));
     float* b = buf.data_ptr<float>();
     const size_t ws_bytes = ucd_abn_workspace_bytes((int)M, (int)N);
@@ -509,6 +518,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       d.a = x.data_ptr(); d.lda = (int)K; d.w = w4.data_ptr(); d.ldw = (int)(conv3 ? 9 * K : K); d.y = z.data_ptr(); d.ldy = (int)N;
       d.M = (int)M; d.N = (int)N; d.K = (int)K; d.out_mode = 2; d.partial = partial;
       if (conv3) { d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation; }
+      if (stride > 1) { d.H = (int)H; d.W = (int)W; d.stride = (int)stride; }
       check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
       if (!sync) {
         check(ucd_conv1x1_stats_finalize(partial, (int)M, (int)N, fptr(weight), running_mean.data_ptr<float>(),
@@ -531,8 +541,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
               "ucd_abn_sync_forward");
       }
     } else {
-      if (conv3) {
-        z = at::conv2d(x, w4, {}, {1, 1}, {dilation, dilation}, {dilation, dilation}, 1);
+      if (conv3 || stride > 1) {
+        const int64_t pad = conv3 ? dilation : 0, dil = conv3 ? dilation : 1;
+        z = at::conv2d(x, w4, {}, {stride, stride}, {pad, pad}, {dil, dil}, 1);
         if (!dense_channels_last(z)) z = z.contiguous(at::MemoryFormat::ChannelsLast);
       } else {
         const size_t wsb = ucd_gemm_workspace_bytes();
@@ -584,6 +595,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     ctx->saved_data["param_grad"] = param_grad;
     ctx->saved_data["with_skip"] = with_skip;
     ctx->saved_data["dilation"] = dilation;
+    ctx->saved_data["stride"] = stride;
     ctx->saved_data["own_dgrad"] = own_dgrad;
     ctx->saved_data["wgrad_conv"] = wgrad_conv;
     if (make_link) {   // outputs: y, [x], z, buf, partial, flag
@@ -610,7 +622,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     const double slope = ctx->saved_data["slope"].toDouble();
     const bool has_res = ctx->saved_data["has_res"].toBool(), with_skip = ctx->saved_data["with_skip"].toBool();
     float* param_grad = reinterpret_cast<float*>(ctx->saved_data["param_grad"].toInt());
-    const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0), HW = H * W, M = B * HW;
+    const int64_t stride = ctx->saved_data["stride"].toInt();
+    const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0);
+    const int64_t HW = z.size(2) * z.size(3), M = B * HW;       // rows of the output map (smaller than x's when strided)
     at::Tensor dy = grads[0];
     at::Tensor dskip = with_skip ? grads[1] : at::Tensor();
     at::Tensor none;
@@ -685,6 +699,21 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         if (!param_grad) { dbias = sums.narrow(0, 0, N); dweight = sums.narrow(0, N, N); }
       }
     }
+    if (stride > 1) {
+      const int64_t pad = conv3 ? dilation : 0, dil = conv3 ? dilation : 1;
+      if (ctx->needs_input_grad(0) && dz.defined())
+        dx = std::get<0>(at::convolution_backward(dz, x, w4, c10::nullopt, {stride, stride}, {pad, pad}, {dil, dil}, false, {0, 0}, 1,
+                                                  {true, false, false}));
+      if (ctx->needs_input_grad(1) && dz.defined()) {
+        if (ctx->saved_data["wgrad_conv"].toInt() == 2 && own_wgrad_ok(dz, x, w4, conv3 ? dilation : 0) && N % 128 == 0 && K % 128 == 0)
+          dw = own_wgrad(dz, x, w4, conv3 ? dilation : 0, stream, stride);
+        else
+          dw = std::get<1>(at::convolution_backward(dz, x, w4, c10::nullopt, {stride, stride}, {pad, pad}, {dil, dil}, false, {0, 0}, 1,
+                                                    {false, true, false}));
+      }
+      return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
+              none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+    }
     if (conv3) {
       // 3x3: input gradient = the same convolution on the flipped + transposed weight (own implicit GEMM, or MIOpen's
       // FORWARD solver when the cached weight is missing / the map is too small to fill the chip); weight gradient: MIOpen
@@ -712,7 +741,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                                     {0, 0}, 1, {false, true, false}));
       }
       return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-              none, none, none, none, none, none, none, none, none, none, none, none, none};
+              none, none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
     const size_t wsb = ucd_gemm_workspace_bytes();
     void* gws = workspace(x, wsb, stream, 1);
@@ -777,7 +806,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       dw = dw.as_strided(w4.sizes(), w4.strides());
     }
     return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -788,10 +817,11 @@ std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor w
                                        c10::optional<at::Tensor> wflip, bool own_dgrad, int64_t wgrad_conv, bool make_link,
                                        c10::optional<at::Tensor> lk_z, c10::optional<at::Tensor> lk_buf,
                                        c10::optional<at::Tensor> lk_bias, c10::optional<at::Tensor> lk_partial,
-                                       c10::optional<at::Tensor> lk_flag, int64_t lk_act, double lk_slope, int64_t lk_kind) {
+                                       c10::optional<at::Tensor> lk_flag, int64_t lk_act, double lk_slope, int64_t lk_kind,
+                                       int64_t stride) {
   return ConvABNTrainNode::apply(x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world,
                                  stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad, wgrad_conv, make_link, lk_z,
-                                 lk_buf, lk_bias, lk_partial, lk_flag, lk_act, lk_slope, lk_kind);
+                                 lk_buf, lk_bias, lk_partial, lk_flag, lk_act, lk_slope, lk_kind, stride);
 }
 
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,

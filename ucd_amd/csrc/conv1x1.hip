@@ -64,6 +64,8 @@ struct Args {
   int tiles_m, tiles_n;
   int param_off;     // byte offset of the input-transform constants in LDS
   int iH, iW, dil;   // CONV3: spatial size of the [B, H, W, K] map behind A and the dilation (= padding) of the 3x3 taps
+  int stride, oW, ohw;   // stride > 1 (1x1 and CONV3): output row m = (b, oy, ox) of the [B, oH, oW] map reads input pixel (oy, ox) * stride
+  int a_rows;        // rows of A (= M unless strided: B * iH * iW)
 };
 
 // The fused transforms take leaky_relu(slope) only; identity arrives as slope = 1 (elu layers keep the separate ABN
@@ -142,14 +144,16 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
     const int row = 8 * (wave * CA + i) + (lane >> 3);
     const int slot = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
     ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + slot;
-    if (CONV3) {
-      const int m = m0 + row, hw = p.iH * p.iW;
+    if (CONV3 || p.stride > 1) {
+      const int m = m0 + row;
       const int mm = min(m, p.M - 1);
-      const int b = mm / hw, rem = mm - b * hw;
-      py[i] = m < p.M ? rem / p.iW : -(1 << 20);           // rows past M: never inside the map -> zeros
-      px[i] = rem - (rem / p.iW) * p.iW;
-      pimg[i] = b * hw;
+      const int b = mm / p.ohw, rem = mm - b * p.ohw;
+      const int oy = rem / p.oW, ox = rem - oy * p.oW;
+      py[i] = m < p.M ? oy * p.stride : -(1 << 20);        // rows past M: never inside the map -> zeros
+      px[i] = ox * p.stride;
+      pimg[i] = b * p.iH * p.iW;
       pslot[i] = slot;
+      if (!CONV3) ga[i] = p.A + (size_t)(pimg[i] + oy * p.stride * p.iW + px[i]) * p.lda + slot;   // strided 1x1: a row gather
     }
   }
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
   // Every LDS-DMA goes through a buffer descriptor: a per-lane 32-bit byte offset computed once (row, swizzled slot) plus a
   // SCALAR offset for the K position - no vector arithmetic per load in the K loop.
   const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((size_t)p.N * p.ldw * 2), 0x00020000);
-  const auto rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((size_t)p.M * p.lda * 2), 0x00020000);
+  const auto rsA1 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((size_t)p.a_rows * p.lda * 2), 0x00020000);
   unsigned boff[CB], a1off[CA];
 #pragma unroll
   for (int i = 0; i < CB; ++i) boff[i] = (unsigned)((const char*)gb[i] - (const char*)p.W);
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
   // pixel, bounds test); pixels outside the map carry an out-of-range offset, which the descriptor's range check zero-fills
   // (tools/lds_dma_oob_probe.hip) - the K steps inside a tap only add k0 (the first version re-derived tap, shift, bounds and a
   // 64-bit select per load and step: 36 % of the wave's cycles were instruction issue, tools/prof_kernel.sh)
-  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, CONV3 ? (int)((size_t)p.M * p.lda * 2) : 0, 0x00020000);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, CONV3 ? (int)((size_t)p.a_rows * p.lda * 2) : 0, 0x00020000);
   constexpr unsigned kOOB = 0x7FFFFFF0u;
   unsigned aoff[CA];
   int atap = -1;
@@ -732,10 +736,15 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   UCD_REQUIRE(d->K % kBK == 0 && d->N % 64 == 0, UCD_EUNSUPPORTED, "%s: K (%d) and N (%d) must be multiples of 64", fn, d->K, d->N);
   const bool conv3 = d->taps == 9;
   UCD_REQUIRE(d->taps == 0 || d->taps == 1 || conv3, UCD_EINVAL, "%s: taps must be 1 (1x1) or 9 (3x3)", fn);
-  UCD_REQUIRE(!conv3 || (d->H > 0 && d->W > 0 && d->dilation >= 1 && (long long)d->M % ((long long)d->H * d->W) == 0 &&
-                         d->ldw >= 9 * d->K && !d->in_scale),
-              UCD_EINVAL, "%s: 3x3 mode needs H, W, dilation, M = B*H*W, ldw >= 9 K, no input transform", fn);
-  UCD_REQUIRE((size_t)d->M * d->lda * 2 < 0x7FFFFFF0u && (size_t)d->N * d->ldw * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
+  const int stride = d->stride > 1 ? d->stride : 1;
+  const bool mapped = conv3 || stride > 1;                 // rows are pixels of a [B, H, W, K] map
+  const int oH = mapped && d->H > 0 ? (d->H - 1) / stride + 1 : 0, oW = mapped && d->W > 0 ? (d->W - 1) / stride + 1 : 0;
+  UCD_REQUIRE(!mapped || (d->H > 0 && d->W > 0 && (long long)d->M % ((long long)oH * oW) == 0 && !d->in_scale), UCD_EINVAL,
+              "%s: the 3x3 / strided modes need H, W, M = B*OH*OW (OH = (H - 1) / stride + 1) and no input transform", fn);
+  UCD_REQUIRE(!conv3 || (d->dilation >= 1 && d->ldw >= 9 * d->K), UCD_EINVAL, "%s: 3x3 mode needs a dilation and ldw >= 9 K", fn);
+  UCD_REQUIRE(stride == 1 || d->out_mode <= 2, UCD_EUNSUPPORTED, "%s: a strided product takes out_mode 0, 1 or 2", fn);
+  const long long a_rows = mapped ? (long long)(d->M / (oH * oW)) * d->H * d->W : d->M;
+  UCD_REQUIRE((size_t)a_rows * d->lda * 2 < 0x7FFFFFF0u && (size_t)d->N * d->ldw * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
               "%s: an operand beyond 2 GiB exceeds the 32-bit offsets of the staging loads", fn);
   UCD_REQUIRE(aligned16(d->a) && aligned16(d->w) && aligned16(d->y) && d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldy % 8 == 0 &&
                   d->lda >= d->K && d->ldw >= d->K && d->ldy >= d->N,
@@ -764,6 +773,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   a.out_act = d->out_act & UCD_ACT_MASK; a.out_slope = a.out_act == UCD_ACT_IDENTITY ? 1.f : d->out_slope;
   a.partial = d->partial; a.accumulate = d->accumulate;
   a.iH = d->H; a.iW = d->W; a.dil = d->dilation;
+  a.stride = stride; a.oW = oW > 0 ? oW : 1; a.ohw = oH * oW > 0 ? oH * oW : 1; a.a_rows = (int)a_rows;
   const int BN = d->N % 128 == 0 ? 128 : 64;
   a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
   const int grid = ceil_div(a.tiles_m, 8) * 8 * a.tiles_n;

@@ -47,6 +47,10 @@ struct WArgs {
   int tiles_n, tiles_k, ksplit;     // ksplit: k-tile groups of one chunk that go to different XCDs (large outputs, few chunks)
   float* partial;                   // [chunks][N][taps * K]
   float inv_w, inv_hw;
+  // strided layers (STR): dZ rows are the pixels of the [B, oH, oW] output map, X the [B, H, W, K] input map (x_rows rows);
+  // output pixel (oy, ox) meets input pixel (oy, ox) * stride + the tap's shift
+  int stride, oH, oW, x_rows;
+  float inv_ow, inv_ohw;
 };
 
 // slot of logical 16-byte chunk c of row r in an LDS image with SLOTS chunks per row (see the header comment)
@@ -115,7 +119,7 @@ __device__ __forceinline__ void compute_stage(f32x16 (&acc)[TNW][TKW], const uns
   mma_group<TNW, TKW, 0>(acc, by, bx);
 }
 
-template <int BNO, int BKO, bool T9>
+template <int BNO, int BKO, bool T9, bool STR = false>
 __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
   constexpr int SY = BNO / 8, SX = BKO / 8;                 // 16-byte chunks per LDS row
   constexpr int YB = kRows * BNO * 2, XB = kRows * BKO * 2;  // bytes of the two tiles of a stage
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
   // Rows that do not exist (past the chunk, or shifted off the map) fetch through an OUT-OF-RANGE offset of a buffer descriptor:
   // the range check zero-fills the LDS bytes (tools/lds_dma_oob_probe.hip) - no branch around a load, no 64-bit select
   const auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.dZ, 0, (int)((size_t)p.M * p.ldz * 2), 0x00020000);
-  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((size_t)p.M * p.ldx * 2), 0x00020000);
+  const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((size_t)(STR ? p.x_rows : p.M) * p.ldx * 2), 0x00020000);
   constexpr int kOOB = 0x7FFFFFF0;
   // per-lane byte offsets inside a 64-row step, computed once; the step's first row enters as a SCALAR offset.  Only a step
   // that crosses the chunk's end (the last one) or a shifted tap tests rows.
@@ -178,16 +182,23 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
   for (int i = 0; i < CX; ++i) xbase[i] = (unsigned)((xrow[i] * p.ldx + xcol[i]) * 2);
   // T9: pixel coordinates of this lane's X rows, advanced by 64 rows per step instead of two divisions per row and step
   // (the kernel spent 45-48 % of its cycles issuing instructions, tools/prof_wgrad.sh); fill() is called for s = 0, 1, 2, ...
-  int xy[CX], xx[CX];
-  const int q64 = T9 ? kRows / p.W : 0, r64 = T9 ? kRows - q64 * p.W : 0;
-  const bool incremental = T9 && q64 + 1 <= p.H;            // one wrap per step is enough (always, for real maps)
-  if (T9) {
+  // STR: the coordinates are those of the OUTPUT pixel (the dZ row) and xb its image's first X row; the X row of a step is then
+  // a per-lane offset of its own (not m + shift)
+  int xy[CX], xx[CX], xb[STR ? CX : 1];
+  const int cw = STR ? p.oW : p.W, chh = STR ? p.oH : p.H;  // the map the rows m walk over
+  const int q64 = (T9 || STR) ? kRows / cw : 0, r64 = (T9 || STR) ? kRows - q64 * cw : 0;
+  const bool incremental = (T9 || STR) && q64 + 1 <= chh;   // one wrap per step is enough (always, for real maps)
+  if (T9 || STR) {
+    const int chw = STR ? p.oH * p.oW : hw;
+    const float icw = STR ? p.inv_ow : p.inv_w, ichw = STR ? p.inv_ohw : p.inv_hw;
 #pragma unroll
     for (int i = 0; i < CX; ++i) {
       const int m = mb + xrow[i];
-      const int pix = m - fdiv(m, hw, p.inv_hw) * hw;
-      xy[i] = fdiv(pix, p.W, p.inv_w);
-      xx[i] = pix - xy[i] * p.W;
+      const int b = fdiv(m, chw, ichw);
+      const int pix = m - b * chw;
+      xy[i] = fdiv(pix, cw, icw);
+      xx[i] = pix - xy[i] * cw;
+      if (STR) xb[i] = b * hw;
     }
   }
   auto fill = [&](int s, unsigned char* stage) {
@@ -206,19 +217,29 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
     for (int i = 0; i < CX; ++i) {
       const int m = m0 + xrow[i];
       bool ok = whole || m < me;
-      if (T9) {
-        int y, x;
+      int y = 0, x = 0, img = 0;
+      if (T9 || STR) {
         if (incremental) {
           y = xy[i]; x = xx[i];
           int nx = x + r64, ny = y + q64;                    // the next step's coordinates
-          if (nx >= p.W) { nx -= p.W; ++ny; }
-          if (ny >= p.H) ny -= p.H;
+          if (nx >= cw) { nx -= cw; ++ny; }
+          if (STR) img = xb[i];
+          if (ny >= chh) { ny -= chh; if (STR) xb[i] += hw; }
           xx[i] = nx; xy[i] = ny;
+        } else if (STR) {
+          const int chw = p.oH * p.oW, b = fdiv(m, chw, p.inv_ohw), pix = m - b * chw;
+          y = fdiv(pix, cw, p.inv_ow); x = pix - y * cw; img = b * hw;
         } else {
           const int pix = m - fdiv(m, hw, p.inv_hw) * hw;
           y = fdiv(pix, p.W, p.inv_w); x = pix - y * p.W;
         }
+        if (STR) { y = y * p.stride; x = x * p.stride; }
         ok = ok && (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
+      }
+      if (STR) {   // the whole row address rides on the lane offset
+        const unsigned off = ok ? (unsigned)(((img + (y + dy) * p.W + x + dx) * p.ldx + xcol[i]) * 2) : (unsigned)kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(stage + YB + (wave * CX + i) * 1024), 16, (int)off, 0, 0, 0);
+        continue;
       }
       const unsigned off = ok ? (unsigned)((int)xbase[i] + xadj) : (unsigned)kOOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(stage + YB + (wave * CX + i) * 1024), 16, (int)off, xs, 0, 0);
@@ -407,14 +428,25 @@ size_t ucd_conv_wgrad_workspace_bytes(int M, int N, int K, int taps) {
 
 int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
                    void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, ucd_stream_t stream) {
+  return ucd_conv_wgrad_strided(dz, ld_dz, x, ld_x, M, N, K, taps, H, W, dilation, 1, dw, dw32, accumulate32, workspace, workspace_bytes,
+                                stream);
+}
+
+int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W,
+                           int dilation, int stride, void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes,
+                           ucd_stream_t stream) {
   static const char* fn = "ucd_conv_wgrad";
   UCD_REQUIRE(dz && x && (dw || dw32) && workspace, UCD_EINVAL, "%s: NULL argument", fn);
   UCD_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, UCD_EUNSUPPORTED, "%s: N (%d) and K (%d) must be multiples of 64", fn, N, K);
   UCD_REQUIRE(taps == 1 || taps == 9, UCD_EINVAL, "%s: taps must be 1 or 9", fn);
-  UCD_REQUIRE(taps == 1 || (H > 0 && W > 0 && dilation >= 1 && (long long)M % ((long long)H * W) == 0 && H < 32768 && W < 32768),
-              UCD_EINVAL, "%s: the 3x3 form needs H, W, dilation and M = B*H*W", fn);
+  const bool str = stride > 1;
+  const int oH = str && H > 0 ? (H - 1) / stride + 1 : H, oW = str && W > 0 ? (W - 1) / stride + 1 : W;
+  UCD_REQUIRE((taps == 1 && !str) || (H > 0 && W > 0 && dilation >= 1 && (long long)M % ((long long)oH * oW) == 0 && H < 32768 && W < 32768),
+              UCD_EINVAL, "%s: the 3x3 / strided forms need H, W, dilation and M = B*OH*OW", fn);
+  UCD_REQUIRE(!str || (N % 128 == 0 && K % 128 == 0), UCD_EUNSUPPORTED, "%s: the strided form takes N and K multiples of 128", fn);
   UCD_REQUIRE(M < (1 << 22), UCD_EUNSUPPORTED, "%s: M = %d rows exceed the index arithmetic of the 3x3 form (2^22)", fn, M);
-  UCD_REQUIRE((size_t)M * ld_dz * 2 < 0x7FFFFFF0u && (size_t)M * ld_x * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
+  const long long x_rows = str ? (long long)(M / (oH * oW)) * H * W : M;
+  UCD_REQUIRE((size_t)M * ld_dz * 2 < 0x7FFFFFF0u && (size_t)x_rows * ld_x * 2 < 0x7FFFFFF0u, UCD_EUNSUPPORTED,
               "%s: operands beyond 2 GiB exceed the 32-bit offsets of the staging loads", fn);
   UCD_REQUIRE(aligned16(dz) && aligned16(x) && (!dw || aligned16(dw)) && (!dw32 || aligned16(dw32)) && ld_dz % 8 == 0 && ld_x % 8 == 0 &&
                   ld_dz >= N && ld_x >= K,
@@ -424,7 +456,9 @@ int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, in
   UCD_REQUIRE(workspace_bytes >= (size_t)pl.chunks * total * sizeof(float), UCD_EWORKSPACE, "%s: workspace too small", fn);
   WArgs a;
   a.dZ = (const bf16*)dz; a.ldz = ld_dz; a.X = (const bf16*)x; a.ldx = ld_x;
-  a.M = M; a.N = N; a.K = K; a.taps = taps; a.H = taps == 9 ? H : 1; a.W = taps == 9 ? W : M; a.dil = dilation;
+  a.M = M; a.N = N; a.K = K; a.taps = taps; a.H = (taps == 9 || str) ? H : 1; a.W = (taps == 9 || str) ? W : M; a.dil = dilation;
+  a.stride = str ? stride : 1; a.oH = str ? oH : a.H; a.oW = str ? oW : a.W; a.x_rows = (int)x_rows;
+  a.inv_ow = 1.f / (float)a.oW; a.inv_ohw = 1.f / ((float)a.oH * (float)a.oW);
   a.chunks = pl.chunks; a.rows_per_chunk = pl.rows; a.tiles_n = pl.tiles_n; a.tiles_k = pl.tiles_k; a.ksplit = pl.ksplit;
   a.partial = (float*)workspace;
   a.inv_w = 1.f / (float)a.W; a.inv_hw = 1.f / ((float)a.H * (float)a.W);
@@ -443,7 +477,15 @@ int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, in
       wgrad_kernel<BN_, BK_, false><<<grid, kThreads, lds, s>>>(a);                         \
     }                                                                                       \
   }
-  if (pl.bno == 128 && pl.bko == 128) UCD_WG_LAUNCH(128, 128)
+  if (str) {
+    if (taps == 9) {
+      UCD_TRY_LDS((wgrad_kernel<128, 128, true, true>), (int)lds);
+      wgrad_kernel<128, 128, true, true><<<grid, kThreads, lds, s>>>(a);
+    } else {
+      UCD_TRY_LDS((wgrad_kernel<128, 128, false, true>), (int)lds);
+      wgrad_kernel<128, 128, false, true><<<grid, kThreads, lds, s>>>(a);
+    }
+  } else if (pl.bno == 128 && pl.bko == 128) UCD_WG_LAUNCH(128, 128)
   else if (pl.bno == 128) UCD_WG_LAUNCH(128, 64)
   else if (pl.bko == 128) UCD_WG_LAUNCH(64, 128)
   else UCD_WG_LAUNCH(64, 64)

@@ -48,7 +48,7 @@ class Conv1x1Desc(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("out_act", C.c_int), ("out_slope", C.c_float),
                 ("partial", C.c_void_p), ("accumulate", C.c_int),
                 ("taps", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dilation", C.c_int),
-                ("side2", C.c_void_p), ("ld2", C.c_int)]
+                ("side2", C.c_void_p), ("ld2", C.c_int), ("stride", C.c_int)]
 
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -109,6 +109,7 @@ SIGNATURES = {
     "ucd_stem_pool_backward": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _z, _i, _p]),
     "ucd_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "ucd_conv_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
+    "ucd_conv_wgrad_strided": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
     "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
     "ucd_sgd_chunk": (_i, []),
@@ -510,19 +511,24 @@ def attmap(x, ld_x, y, ld_y, B, HW, Cc):
 # 1x1 convolutions as fused GEMMs (csrc/conv1x1.hip)
 # ---------------------------------------------------------------------------------------------
 def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, partial=None, accumulate=False, conv3=None,
-            side2=None):
+            side2=None, strided=None):
     """y[M, N] = out(in(a)[M, K] . w[N, K]^T).  ``in_norm`` = (mean, scale, shift, act, slope) of the producer's ABN or None;
     ``out_norm`` = (mean, scale, shift, invstd, act, slope) for out_mode 1 / 3.  All 2-D bf16 row matrices.
     ``conv3 = (H, W, dilation)``: 3x3 convolution (stride 1, padding = dilation) of the [B, H, W, K] map behind ``a`` with the
-    channels-last weight ``w`` given as its [N, 9 K] row matrix."""
+    channels-last weight ``w`` given as its [N, 9 K] row matrix; ``conv3 = (H, W, dilation, stride)`` / ``strided = (H, W, stride)``
+    (1x1): the strided layers, ``a`` the [B*H*W, K] rows of the input map and ``y`` the [B*OH*OW, N] rows of the output."""
     lib = load()
     d = Conv1x1Desc()
-    M, K = a.shape
+    M, K = y.shape[0], a.shape[1]           # strided: a holds the (larger) input map, y has the product's rows
     N = w.shape[0]
     d.a, d.lda, d.w, d.ldw, d.y, d.ldy = a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0), y.data_ptr(), y.stride(0)
     d.M, d.N, d.K = M, N, K
     if conv3 is not None:
         d.taps, d.H, d.W, d.dilation = 9, int(conv3[0]), int(conv3[1]), int(conv3[2])
+        if len(conv3) > 3:
+            d.stride = int(conv3[3])
+    elif strided is not None:
+        d.H, d.W, d.stride = int(strided[0]), int(strided[1]), int(strided[2])
     if in_norm is not None:
         mean, scale, shift, act, slope = in_norm
         d.in_mean, d.in_scale, d.in_shift, d.in_act, d.in_slope = ptr(mean), ptr(scale), ptr(shift), act & ACT_MASK, slope
@@ -595,22 +601,28 @@ def stem_pool_backward(z, dpool, idx, mean, invstd, scale, beta, weight, sums, c
                                           int(phase), stream()), "ucd_stem_pool_backward")
 
 
-def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False):
+def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, strided=None):
     """Weight gradient of a stride-1 convolution (ucd_conv_wgrad): ``dz`` [M, N] and ``x`` [M, K] bf16 row matrices ->
     ``dw`` [N, taps * K] bf16 (channels-last weight order [N][kh][kw][K]) and / or ``dw32`` fp32 (+= when ``accumulate32``);
-    ``conv3 = (H, W, dilation)`` selects the 3x3 form over the [B, H, W, K] map behind ``x``."""
+    ``conv3 = (H, W, dilation)`` selects the 3x3 form over the [B, H, W, K] map behind ``x``; ``conv3 = (H, W, dilation, stride)`` /
+    ``strided = (H, W, stride)`` the strided layers (``x`` the input map's rows, ``dz`` the smaller output map's)."""
     lib = load()
     M, N = dz.shape
     K = x.shape[1]
     taps = 9 if conv3 is not None else 1
     H, W, d = (int(conv3[0]), int(conv3[1]), int(conv3[2])) if conv3 is not None else (0, 0, 1)
+    stride = 1
+    if conv3 is not None and len(conv3) > 3:
+        stride = int(conv3[3])
+    elif strided is not None:              # 1x1 with a stride: (H, W, stride) of the input map behind x
+        H, W, stride = int(strided[0]), int(strided[1]), int(strided[2])
     nbytes = lib.ucd_conv_wgrad_workspace_bytes(M, N, K, taps)
     ws = workspace(nbytes, dz.device, "wgrad")
     # MFMA-bound for the 3x3 layers, HBM / L2-bound for the 1x1 layers: flop for one, algorithmic bytes for the other
     work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * N + M * K)
     with _timed("ucd_conv3x3_wgrad" if conv3 is not None else "ucd_conv1x1_wgrad", work):
-        _check(lib.ucd_conv_wgrad(ptr(dz), dz.stride(0), ptr(x), x.stride(0), M, N, K, taps, H, W, d, ptr(dw), ptr(dw32),
-                                  1 if accumulate32 else 0, ptr(ws), nbytes, stream()), "ucd_conv_wgrad")
+        _check(lib.ucd_conv_wgrad_strided(ptr(dz), dz.stride(0), ptr(x), x.stride(0), M, N, K, taps, H, W, d, stride, ptr(dw),
+                                          ptr(dw32), 1 if accumulate32 else 0, ptr(ws), nbytes, stream()), "ucd_conv_wgrad")
     return dw if dw is not None else dw32
 
 
