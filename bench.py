@@ -51,6 +51,7 @@ import torch.distributed as dist
 PEAK_HBM_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TF = 157.3    # dense fp32 matrix peak
 PEAK_F16_MFMA_TF = 2500.0   # dense fp16/bf16 matrix peak
+MFMA_CALLS = ("ucd_conv3x3", "ucd_conv3x3_wgrad")     # 9 K deep implicit GEMMs: priced in flop (hip.py _timed work)
 E_PER_IMAGE_513 = 98.44e6   # ABN activation elements per image per pass at 513^2
 
 
@@ -246,14 +247,14 @@ def main():
         ev_us = kernels.pop("_event_pair_overhead_us")
         for kname, kv in kernels.items():                    # per-call-type roofline fractions
             secs = max(kv["ms_total"] * 1e-3, 1e-12)
-            if kname.startswith("ucd_pixcon_loss") or kname == "ucd_conv3x3":
+            if kname.startswith("ucd_pixcon_loss") or kname in MFMA_CALLS:
                 pk = PEAK_F32_MFMA_TF if "f32" in kname else PEAK_F16_MFMA_TF      # bf16 and fp16 share the dense peak
                 kv.update(bound="mfma", achieved=kv["work"] / secs / 1e12, unit="TFLOP/s", frac=kv["work"] / secs / 1e12 / pk)
             else:
                 kv.update(bound="hbm", achieved=kv["work"] / secs / 1e9, unit="GB/s", frac=kv["work"] / secs / 1e9 / PEAK_HBM_GBS)
         name = max(kernels, key=lambda k: kernels[k]["ms_total"])
         k = kernels[name]
-        if name.startswith("ucd_pixcon_loss") or name == "ucd_conv3x3":
+        if name.startswith("ucd_pixcon_loss") or name in MFMA_CALLS:
             ach = k["work"] / (k["ms_total"] * 1e-3) / 1e12
             peak = PEAK_F32_MFMA_TF if "f32" in name else PEAK_F16_MFMA_TF
             roof = {"kernel": name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
@@ -267,13 +268,16 @@ def main():
         roof["launches_per_step"] = k["launches"] / min(args.steps, 3)
         # HBM traffic of that kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_to_json.py); null if absent
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
-        if os.path.exists(pmc):
+        for rnd in ("r03", "r02"):                          # the newest committed collection that has this call
+            pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench.json")
+            if not os.path.exists(pmc):
+                continue
             try:
                 rec = json.load(open(pmc)).get(name.split("[")[0])
                 if rec and rec.get("global_batch") == args.global_batch and world == 1:
                     roof["traffic"] = rec["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/r02_pmc_bench.json"
+                    roof["traffic_source"] = f"profiles/{rnd}_pmc_bench.json"
+                    break
             except (OSError, ValueError):
                 pass
 

@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
 # every profiler / probe call under its own timeout: a hung collection must not eat the box's time limit
 cd $R
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/gputests.log
@@ -8,13 +8,17 @@ for gb in 12 6 3; do python bench.py --steps 10 --warmup 3 --global_batch $gb --
 (for mode in torch hip; do for gb in 24 3; do UCD_SGD=$mode timeout 120 python bench.py --steps 12 --warmup 4 --global_batch $gb --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('UCD_SGD=$mode', 'global_batch', $gb, 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))"; done; done) > $O/sgd_ab.txt 2>&1
 timeout 300 python tools/conv1x1_probe.py > $O/conv1x1_probe.txt 2>&1
 timeout 300 python tools/conv3x3_probe.py > $O/conv3x3_probe.txt 2>&1
+timeout 200 python tools/conv_strided_probe.py > $O/conv_strided_probe.txt 2>&1
+timeout 300 python tools/wgrad_probe2.py > $O/wgrad_probe.txt 2>&1
 timeout 120 python tools/pixcon_pairs.py > $O/pixcon_pairs.txt 2>&1
 (for m in f16 f16_split; do timeout 100 python tools/pixcon_bench.py $m | tail -2; timeout 100 python tools/pixcon_bench.py $m dom | tail -2; done) > $O/pixcon_bench.txt 2>&1
 timeout 100 python tools/seglosses_bench.py > $O/seglosses_bench.txt 2>&1
+timeout 100 python tools/seglosses_bench.py ade >> $O/seglosses_bench.txt 2>&1
+(for sw in UCD_STEM_FOLD UCD_BLOCK_LINK UCD_OWN_WGRAD UCD_OWN_STRIDED; do env $sw=0 timeout 120 python bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=0', 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))"; done; timeout 120 python bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default', 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))") > $O/switch_ab.txt 2>&1
 timeout 200 python tools/abn_bench.py > $O/abn_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_kernel_timing > /tmp/prof.log 2>&1
-python $R/tools/trace_summary.py /tmp/prof/t_kernel_trace.csv $O/step_kernel_summary_final.txt "timeout 400 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 2 (round-2 final)" > /dev/null
+python $R/tools/trace_summary.py /tmp/prof/t_kernel_trace.csv $O/step_kernel_summary_final.txt "timeout 400 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 2 (round-3 final)" > /dev/null
 head -40 /tmp/prof/t_kernel_stats.csv > $O/kernel_stats_final.csv
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof3 -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --global_batch 3 --no_cpu_baseline --no_kernel_timing > /tmp/prof3.log 2>&1
 python $R/tools/trace_summary.py /tmp/prof3/t_kernel_trace.csv $O/step_kernel_summary_b3.txt "same, --global_batch 3 (per-rank batch of the 8-GPU run)" > /dev/null

@@ -9,11 +9,13 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(pixcon16p_\w+kernel|pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|window_\w+kernel|tile_stats_reduce_kernel)", r["Kernel_Name"])
+        m = re.search(r"(pixcon16p_\w+kernel|pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|window_\w+kernel|tile_stats_reduce_kernel|wgrad_kernel|wgrad_sum_kernel|stem_\w+kernel|sgd_step_kernel)", r["Kernel_Name"])
         if m:
             k = m.group(1)
             if k == "conv1x1_kernel" and re.search(r"conv1x1_kernel<\d+, \w+, \d+, true", r["Kernel_Name"]):
                 k = "conv3x3_kernel"          # the CONV3 instances of the same template: the 3x3 implicit GEMM
+            if k == "wgrad_kernel":
+                k = "wgrad3x3_kernel" if re.search(r"wgrad_kernel<\d+, \d+, true", r["Kernel_Name"]) else "wgrad1x1_kernel"
             agg[k].append(float(r["Counter_Value"]))
     return agg
 
@@ -34,7 +36,9 @@ if calls:
 # HBM-stream calls: one dominant kernel each (the stage-2 reduce_bands launches move a few KB)
 for call, k in (("ucd_abn_apply", "abn_apply_kernel"), ("ucd_abn_stats", "abn_stats_kernel"),
                 ("ucd_abn_bwd_reduce", "abn_bwd_reduce_kernel"), ("ucd_abn_bwd_apply", "abn_bwd_apply_kernel"),
-                ("ucd_seg_losses", "seg_losses_kernel"), ("ucd_conv1x1", "conv1x1_kernel"), ("ucd_conv3x3", "conv3x3_kernel")):
+                ("ucd_seg_losses", "seg_losses_kernel"), ("ucd_conv1x1", "conv1x1_kernel"), ("ucd_conv3x3", "conv3x3_kernel"),
+                ("ucd_conv1x1_wgrad", "wgrad1x1_kernel"), ("ucd_conv3x3_wgrad", "wgrad3x3_kernel"),
+                ("ucd_stem_apply_pool", "stem_apply_pool_kernel"), ("ucd_sgd_step", "sgd_step_kernel")):
     if k in kern:
         out[call] = {"global_batch": int(sys.argv[4]), "bytes_per_launch": kern[k]["bytes"], "kernels": [k]}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
