@@ -101,14 +101,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // whose interleaving hides the fill latency of the single-stage form - the 9 K deep, MFMA-bound 3x3 products most of all: the
 // fill of step k+1 is issued (LDS-DMA: no registers to carry) before the MFMAs of step k and waited for with a counted
 // vmcnt, so it lands under them.  64 KB of LDS, two workgroups per CU.
-// BN = 256 (3x3 form, double-buffered): the wave tile grows to 64 x 128, so a K step reads 2 A + 4 B fragments for 8 MFMAs
-// instead of 2 + 2 for 4 - a quarter less LDS traffic per MFMA (the 128 x 128 tile is bound by its LDS reads: 64 KB per K step and
-// workgroup, 128 B/clk against 16 MFMAs per wave) - and the A tile of a row strip is staged once instead of once per column
-// tile.  96 KB of LDS, one workgroup per CU, 128 accumulator registers.
 template <int BN, bool PRO, int OUT, bool CONV3 = false, bool DB = false>
-__global__ __launch_bounds__(kThreads, BN == 256 ? 1 : (DB ? 2 : ((PRO || OUT >= 3) && BN == 128 ? 3 : 4))) void conv1x1_kernel(Args p) {
+__global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
   static_assert(!DB || !PRO, "the double-buffered form has no input transform");
-  static_assert(BN != 256 || (DB && CONV3), "the 256-wide tile exists for the double-buffered 3x3 form");
   constexpr int kStage = (kBM + BN) * 128;   // bytes of one LDS stage (A tile + W tile)
   constexpr int WN = BN / 2;           // columns per wave
   constexpr int TN = WN / 32;          // 32-wide accumulator tiles per wave along N
@@ -453,8 +448,8 @@ __global__ __launch_bounds__(kThreads, BN == 256 ? 1 : (DB ? 2 : ((PRO || OUT >=
       red[(r0 * 2 + 1) * BN + c8 * 8 + e] = s2[e];
     }
     __syncthreads();
-    for (int tt = tid; tt < 2 * BN; tt += kThreads) {
-      const int which = tt / BN, col = tt % BN;
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
       float t = 0.f;
 #pragma unroll 8
       for (int q = 0; q < RSTEP; ++q) t += red[(q * 2 + which) * BN + col];
@@ -779,11 +774,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   a.partial = d->partial; a.accumulate = d->accumulate;
   a.iH = d->H; a.iW = d->W; a.dil = d->dilation;
   a.stride = stride; a.oW = oW > 0 ? oW : 1; a.ohw = oH * oW > 0 ? oH * oW : 1; a.a_rows = (int)a_rows;
-  int BN = d->N % 128 == 0 ? 128 : 64;
-  // 3x3 products whose 128-wide grid leaves the chip with at most ~2.5 workgroups per CU: the 256-wide tile (see the kernel)
-  static const int wide_mode = getenv("UCD_CONV3_BN256") ? atoi(getenv("UCD_CONV3_BN256")) : 1;
-  if (conv3 && wide_mode && d->N % 256 == 0 && d->out_mode <= 3 && (long long)ceil_div(d->M, kBM) * (d->N / 128) <= 640 * (wide_mode > 1 ? 100 : 1))
-    BN = 256;
+  const int BN = d->N % 128 == 0 ? 128 : 64;
   a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
   const int grid = ceil_div(a.tiles_m, 8) * 8 * a.tiles_n;
   // 3x3 with a grid that leaves a CU one or two workgroups (N = 256 at 33^2: 410; tools/conv3x3_probe.py): the
@@ -792,7 +783,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   // (the 1x1 products of such grids gain too: 1024 -> 256 23.3 -> 21.7 us, with statistics 25.1 -> 23.6)
   // out_mode 4 keeps three side tiles in registers next to the accumulators: 168 VGPRs + 96 B of scratch in the single-stage
   // form at three workgroups per CU, 194 VGPRs and no scratch in the double-buffered form (two per CU) - it always takes that
-  const bool db = ((conv3 || !d->in_scale) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640) || (d->out_mode == 4 && BN == 128) || BN == 256;
+  const bool db = ((conv3 || !d->in_scale) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640) || (d->out_mode == 4 && BN == 128);
   const size_t lds_main = (size_t)(kBM + BN) * 128 * (db ? 2 : 1), lds_out = (size_t)64 * (BN + 4) * 4;
   size_t lds = lds_main > lds_out ? lds_main : lds_out;
   const size_t lds_red = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;       // statistics reduction scratch
@@ -800,23 +791,8 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   const bool pro = d->in_scale != nullptr;
   a.param_off = (int)align_up(lds, 16);
   if (pro) lds = a.param_off + (size_t)3 * d->K * sizeof(float);
-  UCD_REQUIRE(lds <= (BN == 256 ? 160 : 64) * 1024, UCD_EUNSUPPORTED, "%s: K = %d is too wide for the fused input transform", fn, d->K);
+  UCD_REQUIRE(lds <= 64 * 1024, UCD_EUNSUPPORTED, "%s: K = %d is too wide for the fused input transform", fn, d->K);
   hipStream_t s = (hipStream_t)stream;
-  if (BN == 256) {
-#define UCD_C3W(OUTV)                                                                \
-    {                                                                                \
-      UCD_TRY_LDS((conv1x1_kernel<256, false, OUTV, true, true>), (int)lds);         \
-      conv1x1_kernel<256, false, OUTV, true, true><<<grid, kThreads, lds, s>>>(a);   \
-    }
-    switch (d->out_mode) {
-      case 0: UCD_C3W(0) break;
-      case 1: UCD_C3W(1) break;
-      case 2: UCD_C3W(2) break;
-      default: UCD_C3W(3) break;
-    }
-#undef UCD_C3W
-    return check_launch(fn);
-  }
 #define UCD_C1_LAUNCH(BNV, PROV, OUTV)                                          \
   {                                                                             \
     if (!PROV && db)                                                            \
