@@ -21,4 +21,4 @@ torch.cuda.synchronize(); print("ms/step", (time.perf_counter() - t0) * 100, " h
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): trainer.train_step(images, labels, optimizer, scheduler)
 torch.cuda.synchronize(); pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000]); s2 = io.StringIO(); pstats.Stats(pr, stream=s2).sort_stats("cumulative").print_stats(45); print(s2.getvalue()[:9000])

@@ -40,10 +40,27 @@ def _wgrad_split(M: int) -> int:
     return 1
 
 
+_ENV_RAW = getattr(os.environ, "_data", None)       # CPython: the dict behind os.environ (encoded keys and values)
+_ENV_KEYS = {}
+
+
+def _env(name, default):
+    """``os.environ.get(name, default)`` for the A/B switches read on every layer call, without encoding the key each time (620
+    reads per step were 4 % of the host time of the 3-images-per-GPU step); sees ``monkeypatch.setenv`` / ``os.environ[...] =``
+    like the mapping itself, and falls back to it on an interpreter without ``_data``."""
+    if _ENV_RAW is None:
+        return os.environ.get(name, default)
+    k = _ENV_KEYS.get(name)
+    if k is None:
+        k = _ENV_KEYS[name] = os.environ.encodekey(name)
+    v = _ENV_RAW.get(k)
+    return default if v is None else os.environ.decodevalue(v)
+
+
 def _own_wgrad() -> bool:
     """Weight gradients on the own kernel (csrc/wgrad.hip: ucd_conv_wgrad) instead of MIOpen's weight-gradient solvers / the
     batched split-M library products; ``UCD_OWN_WGRAD=0`` restores those (the A/B reference of the tests and probes)."""
-    return os.environ.get("UCD_OWN_WGRAD", "1") != "0"
+    return _env("UCD_OWN_WGRAD", "1") != "0"
 
 
 def _lib_gemm():
@@ -223,7 +240,7 @@ def _own3x3_ok(conv, x):
     return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and conv.bias is None and conv.stride == (1, 1)
             and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1] and conv.groups == 1
             and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[2] > 1 and x.shape[3] > 1
-            and x.is_contiguous(memory_format=torch.channels_last) and os.environ.get("UCD_FUSED_CONV1X1", "1") != "0")
+            and x.is_contiguous(memory_format=torch.channels_last) and _env("UCD_FUSED_CONV1X1", "1") != "0")
 
 
 def _stride_one_conv(x, w, d, wt=None, own_fwd=False, own_dgrad=False):
@@ -243,7 +260,7 @@ class Conv3x3(Conv2d):
         M = x.shape[0] * x.shape[2] * x.shape[3] if x.dim() == 4 else 0
         own = _own3x3_ok(self, x) and self.weight.is_contiguous(memory_format=torch.channels_last)
         if (x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is None
-                and x.dtype == torch.bfloat16 and M >= 8192 and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
+                and x.dtype == torch.bfloat16 and M >= 8192 and _env("UCD_DGRAD_VIA_FWD", "1") != "0"):
             own_fwd = own and _own_conv3x3(M, self.in_channels, self.out_channels)
             own_dgrad = own and _own_conv3x3(M, self.out_channels, self.in_channels)
             w = self.working_weight()
@@ -292,7 +309,7 @@ class Conv1x1(Conv2d):
         if not (self.as_gemm and x.is_cuda and x.dim() == 4 and (x.dtype != torch.float32 or torch.is_autocast_enabled())):
             if (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and self.bias is None
                     and self.weight.requires_grad and x.shape[0] * x.shape[2] * x.shape[3] >= 8192
-                    and os.environ.get("UCD_DGRAD_VIA_FWD", "1") != "0"):
+                    and _env("UCD_DGRAD_VIA_FWD", "1") != "0"):
                 w = self.working_weight()
                 if w is None:
                     return _stride_one_conv(x, self.weight.to(x.dtype), 1)
@@ -352,7 +369,7 @@ def _own_gemm_with_stats(K, N):
     kernel is level or ahead on every layer of the network, the two large products included (2048 -> 512: 59.6 against 43.5 + 16;
     1024 -> 2048: 110.8 against 93.1 + 30), so every aligned 1x1 layer takes it; ``UCD_LIB_GEMM_WIDE=1`` restores the library
     for those two (A/B)."""
-    if os.environ.get("UCD_LIB_GEMM_WIDE", "0") == "1":
+    if _env("UCD_LIB_GEMM_WIDE", "0") == "1":
         return not (K * N >= (1 << 20) and K >= 1024)
     return True
 
@@ -363,7 +380,7 @@ def _own_stride(conv):
     channels - else 0.  MIOpen needs 209-263 us for each of the four forward products at B = 24 (tools/aten_ops.py), 5-15x their
     traffic / MFMA time.  ``UCD_OWN_STRIDED=0`` keeps the library (A/B)."""
     if not (isinstance(conv, Conv2d) and conv.stride[0] == conv.stride[1] and conv.stride[0] > 1 and conv.groups == 1
-            and conv.in_channels % 128 == 0 and conv.out_channels % 128 == 0 and os.environ.get("UCD_OWN_STRIDED", "1") != "0"):
+            and conv.in_channels % 128 == 0 and conv.out_channels % 128 == 0 and _env("UCD_OWN_STRIDED", "1") != "0"):
         return 0
     if conv.kernel_size == (1, 1) and conv.padding == (0, 0):
         return conv.stride[0]
@@ -381,9 +398,9 @@ def _own_conv3x3(M, K, N):
     zero fills / casts and the separate statistics passes - kernel time per step 16.0 -> 14.3 ms at 3 images, 20.0 -> 17.5 at 6
     (profiles/r03_small_batch.txt).  ``UCD_OWN3X3_MIN_TILES=256`` restores the library below 256 tiles (A/B)."""
     tiles = ((M + 127) // 128) * max(1, N // 128)
-    if K >= 512 and N >= 512 and os.environ.get("UCD_OWN3X3_WIDE", "1") == "0":      # A/B switch: the 512 -> 512 layers on MIOpen
+    if K >= 512 and N >= 512 and _env("UCD_OWN3X3_WIDE", "1") == "0":      # A/B switch: the 512 -> 512 layers on MIOpen
         return False
-    return tiles >= int(os.environ.get("UCD_OWN3X3_MIN_TILES", "1"))
+    return tiles >= int(_env("UCD_OWN3X3_MIN_TILES", "1"))
 
 
 class _ConvABNFunction(torch.autograd.Function):
@@ -543,15 +560,15 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
     carries the link (``y._ucd_link``) through which that consumer's input-gradient product does this ABN's backward reduction
     in its epilogue (csrc/abn_node.cpp; under SyncBN the producer all-reduces the combined sums; ``UCD_BWD_LINK=0`` switches it
     off)."""
-    if os.environ.get("UCD_FUSED_CONV1X1", "1") == "0":
+    if _env("UCD_FUSED_CONV1X1", "1") == "0":
         return None
-    link = getattr(x, "_ucd_link", None) if os.environ.get("UCD_BWD_LINK", "1") != "0" else None
+    link = getattr(x, "_ucd_link", None) if _env("UCD_BWD_LINK", "1") != "0" else None
     # block link (csrc/abn_node.cpp: block_link_epilogue): x is the output of a residual block whose last node offers its
     # backward reduction to the first convolution of THIS identity-shortcut block (UCD_BLOCK_LINK=0 switches only this kind off)
-    blink = (getattr(x, "_ucd_blink", None) if (with_skip and os.environ.get("UCD_BWD_LINK", "1") != "0"
-                                                and os.environ.get("UCD_BLOCK_LINK", "1") != "0") else None)
-    make_link = make_link and os.environ.get("UCD_BWD_LINK", "1") != "0"
-    if residual is not None and os.environ.get("UCD_BLOCK_LINK", "1") == "0":
+    blink = (getattr(x, "_ucd_blink", None) if (with_skip and _env("UCD_BWD_LINK", "1") != "0"
+                                                and _env("UCD_BLOCK_LINK", "1") != "0") else None)
+    make_link = make_link and _env("UCD_BWD_LINK", "1") != "0"
+    if residual is not None and _env("UCD_BLOCK_LINK", "1") == "0":
         make_link = False
     is3 = isinstance(conv, Conv3x3)
     stride = _own_stride(conv) if not (with_skip or residual is not None) else 0
@@ -728,7 +745,7 @@ class ResidualBlock(nn.Module):
         chans = (c.conv1.in_channels, c.conv1.out_channels, c.conv3.in_channels, c.conv3.out_channels)
         st = x.stride()
         return (all(v % 64 == 0 for v in chans) and "dropout" not in c._modules
-                and st[1] == 1 and st[3] == x.shape[1] and os.environ.get("UCD_FUSED_CONV1X1", "1") != "0")
+                and st[1] == 1 and st[3] == x.shape[1] and _env("UCD_FUSED_CONV1X1", "1") != "0")
 
     @staticmethod
     def _eval_norm(m, act=None, slope=None):
