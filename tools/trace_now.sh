@@ -4,4 +4,4 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_kernel_timing "$@" > /tmp/prof_$TAG.log 2>&1
 python $R/tools/trace_summary.py /tmp/prof_$TAG/t_kernel_trace.csv $O/step_kernel_summary.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 2 $*" > /dev/null
-head -60 $O/step_kernel_summary.txt
+head -4 $O/step_kernel_summary.txt; tail -16 $O/step_kernel_summary.txt

@@ -37,6 +37,15 @@ for s_, e_ in iv[1:]:
     else:
         cur_e = max(cur_e, e_)
 busy += cur_e - cur_s
+# the largest gaps with the kernels on either side (where does the GPU wait for the host?)
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in win), key=lambda t: t[0])
+big, reach, last = [], ev[0][1], ev[0][2]
+for s_, e_, n_ in ev[1:]:
+    if s_ > reach:
+        big.append((s_ - reach, last, n_))
+    if e_ > reach:
+        reach, last = e_, n_
+big.sort(reverse=True)
 gaps.sort()
 with open(sys.argv[2], "w") as f:
     f.write("# %s\n" % (sys.argv[3] if len(sys.argv) > 3 else ""))
@@ -49,4 +58,7 @@ with open(sys.argv[2], "w") as f:
     f.write("%10s %10s %10s  %s\n" % ("ms/step", "calls/step", "avg_us", "kernel"))
     for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
         f.write("%10.3f %10.1f %10.2f  %s\n" % (d / 2e6, c / 2, d / c / 1e3, k))
-print(open(sys.argv[2]).read()[:6000])
+    f.write("# largest idle gaps of the two steps (us: after kernel -> before kernel)\n")
+    for g_, a_, b_ in big[:14]:
+        f.write("#   %8.1f  %s  ->  %s\n" % (g_ / 1e3, a_[:60], b_[:60]))
+print(open(sys.argv[2]).read()[:9000])
