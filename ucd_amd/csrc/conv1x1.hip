@@ -299,17 +299,43 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's ds_writes of the A tile have landed
       __builtin_amdgcn_s_barrier();                      // raw barrier: __syncthreads() would drain the A prefetch too
     }
+    if (DB) {
+      // double-buffered form (two waves per SIMD): the fragment reads run ONE 16-deep slice ahead of the MFMAs that consume them
+      // (two register sets) - left to itself the compiler issues the reads of slice kk + 1 behind the MFMAs of slice kk.  ASPP
+      // branches 245-256 -> 219-238 us; the single-stage forms (128-register cap) lose 5-15 % to the extra registers and keep the
+      // plain loop.  (Also measured and dropped: four LDS stages at one workgroup per CU - 256->256 57 vs 40 us.)
+      bf16x8 af[2][2], bfr[2][TN];
+      auto read_slice = [&](int set, int kk) {
 #pragma unroll
-    for (int kk = 0; kk < kBK / 16; ++kk) {
-      bf16x8 af[2], bfr[TN];
+        for (int a = 0; a < 2; ++a) af[set][a] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * 64 + a * 32 + fr, 2 * kk + fh));
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * 64 + a * 32 + fr, 2 * kk + fh));
+        for (int b = 0; b < TN; ++b) bfr[set][b] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WN + b * 32 + fr, 2 * kk + fh));
+      };
+      read_slice(0, 0);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WN + b * 32 + fr, 2 * kk + fh));
+      for (int kk = 0; kk < kBK / 16; ++kk) {
+        if (kk + 1 < kBK / 16) read_slice((kk + 1) & 1, kk + 1);
+        __builtin_amdgcn_sched_barrier(0);                   // the reads above stay above these MFMAs
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][a], bfr[kk & 1][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < kBK / 16; ++kk) {
+        bf16x8 af[2], bfr[TN];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * 64 + a * 32 + fr, 2 * kk + fh));
+#pragma unroll
+        for (int b = 0; b < TN; ++b) bfr[b] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WN + b * 32 + fr, 2 * kk + fh));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+      }
     }
   }
 
