@@ -829,22 +829,32 @@ class ResidualBlock(nn.Module):
     def forward(self, x):
         if not self.training and not torch.is_grad_enabled() and self._eval_fusable(x):
             return self._forward_eval_fused(x)
-        if hasattr(self, "proj_conv"):
-            residual = _conv_abn_train(self.proj_conv, self.proj_bn, x) if self.training else None
-            if residual is None:
-                residual = self.proj_bn(self.proj_conv(x))
-        else:
-            residual = x
         act, slope = self.convs.bn1.activation, self.convs.bn1.activation_param
         last = getattr(self.convs, self._last_bn)
-        if (self.training and _is_fused_abn(last) and last.activation == "identity" and self._last_bn == "bn3"
-                and "dropout" not in self.convs._modules and x.is_cuda and x.dtype == torch.bfloat16):
+        fused_train = (self.training and _is_fused_abn(last) and last.activation == "identity" and self._last_bn == "bn3"
+                       and "dropout" not in self.convs._modules and x.is_cuda and x.dtype == torch.bfloat16)
+
+        def project(t):
+            r = _conv_abn_train(self.proj_conv, self.proj_bn, t) if self.training else None
+            return r if r is not None else self.proj_bn(self.proj_conv(t))
+
+        has_proj = hasattr(self, "proj_conv")
+        # projection blocks in training: the block input feeds conv1 AND the projection; like the identity blocks, conv1's node
+        # returns an alias of x for the second consumer, so x has ONE consumer and the projection's input gradient arrives as
+        # the accumulate operand of conv1's input-gradient product instead of a separate 3-pass add (UCD_PROJ_ALIAS=0: A/B)
+        defer = has_proj and fused_train and x.requires_grad and _env("UCD_PROJ_ALIAS", "1") != "0"
+        residual = x if not has_proj else (None if defer else project(x))
+        if fused_train:
             # wide bottleneck in training: every 1x1 convolution and its ABN are one node (statistics in the GEMM epilogue)
             c = self.convs
-            skip = residual is x and x.requires_grad
+            skip = (residual is x or defer) and x.requires_grad
             first = _conv_abn_train(c.conv1, c.bn1, x, with_skip=skip, make_link=True)      # h1 feeds conv2 only
+            if first is None and defer:
+                residual = project(x)
             if first is not None:
                 h1, res = first if skip else (first, residual)
+                if defer:
+                    res = project(res)                       # the alias of x: the shortcut's only path to the block input
                 h2 = _conv_abn_train(c.conv2, c.bn2, h1, make_link=True)      # 3x3 as implicit GEMM + statistics; h2 feeds conv3 only
                 if h2 is None:
                     h2 = c.bn2(c.conv2(h1))
