@@ -895,3 +895,43 @@ def test_strided_forward_statistics_and_weight_gradient(B, H, W, K, N, taps, d):
             assert torch.equal(dw32, gw) and torch.equal(dw.float(), gw)
         else:
             assert _rel(dw, gw) < 3e-3 and _rel(dw32, gw) < 1e-4
+
+
+@pytest.mark.parametrize("cin,chans,stride,hw", [(256, (128, 128, 512), 2, 65), (1024, (512, 512, 2048), 1, 33), (64, (64, 64, 256), 1, 65)])
+def test_projection_block_alias_equals_the_separate_gradient_add(cin, chans, stride, hw):
+    """Projection blocks (stride and / or channel change; modules/residual.py:79-87): with UCD_PROJ_ALIAS (default) proj_conv reads an
+    alias of the block input that conv1's node returns, so the block input has one consumer, the projection's input gradient is the
+    accumulate operand of conv1's input-gradient product and the block in front can offer its block link.  Same forward bit for
+    bit and the same gradients (up to the bf16 rounding of one sum) as with the two consumers and autograd's add."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    from ucd_amd.ddp import DistributedDataParallel
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    B = 24 if hw <= 33 else 6
+    front = (chans[2] // 4 if stride == 1 and cin == chans[2] else max(64, cin // 4))
+    x0 = synth.t_normal(21, (B, cin, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    res = {}
+    for alias in ("1", "0"):
+        os.environ["UCD_PROJ_ALIAS"] = alias
+        try:
+            # an identity block in front (its bn3 offers the block link), the projection block, an identity block behind
+            net = torch.nn.Sequential(blocks.ResidualBlock(cin, (front, front, cin), norm_act=norm),
+                                      blocks.ResidualBlock(cin, chans, norm_act=norm, stride=stride),
+                                      blocks.ResidualBlock(chans[2], chans, norm_act=norm))
+            net.load_state_dict(synth.fill_state_dict(net.state_dict(), 7))
+            net = net.to(DEV).to(memory_format=torch.channels_last).train()
+            mod = DistributedDataParallel(net, bf16_weights=True)
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = mod(x * 1.0)
+            dy = synth.t_normal(22, tuple(y.shape), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+            y.backward(dy)
+            mod.finish_grad_sync()
+            res[alias] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in net.parameters()]
+        finally:
+            os.environ.pop("UCD_PROJ_ALIAS", None)
+    a, b = res["1"], res["0"]
+    assert torch.equal(a[0], b[0])
+    worst = max(_rel(a[i], b[i]) for i in range(1, len(a)) if b[i].abs().max() > 0)
+    print("projection alias", cin, chans, stride, hw, "worst gradient difference on / off", worst)
+    assert worst < 3e-2, worst
