@@ -497,6 +497,11 @@ int ucd_abn_sync_finalize(const float* gathered, int world, int M, int C, const 
  *                           phase 2: dz [B, H, W, C] = the norm's input gradient for every position (count = B H W x ranks);
  *                           phase 3: both.  SyncBN all-reduces sums between the phases.  workspace:
  *                           ucd_stem_pool_workspace_bytes(C).  leaky_relu / identity only. */
+/* The stem's convolution itself (models/resnet.py:58: Conv2d(3, 64, 7, stride 2, padding 3, bias False)): x fp32 [B, 3, H, W] with
+ * element strides (sb, sc, sh, sw) - the loader's image in either memory format, converted to bf16 while it is staged -, w the
+ * bf16 weight in channels-last memory order [64][7][7][3], z [B, OH, OW, 64] dense channels-last bf16, OH = (H - 1) / 2 + 1. */
+int ucd_stem_conv7x7(const float* x, long long sb, long long sc, long long sh, long long sw, int B, int H, int W, const void* w,
+                     void* z, ucd_stream_t stream);
 int ucd_stem_pooled_size(int n);
 size_t ucd_stem_pool_workspace_bytes(int C);
 int ucd_stem_apply_pool(const void* z, int B, int H, int W, int C, const float* mean, const float* scale, const float* beta, int act,

@@ -596,3 +596,36 @@ def test_stem_norm_pool_fused_equals_the_two_layers(B, C, H, W, slope):
     sgn = torch.where(bn32.weight < 0, -1.0, 1.0)
     assert rel(a[2], g.grad * sgn) < 1e-2 and rel(a[3], beta.grad) < 1e-2
     del w
+
+
+@pytest.mark.parametrize("B,H,W,nchw", [(2, 65, 65, False), (3, 129, 97, True), (24, 513, 513, False), (1, 7, 9, False)])
+def test_stem_conv7x7_matches_conv2d(B, H, W, nchw):
+    """ucd_stem_conv7x7 (models/resnet.py:58 conv1: 7x7, stride 2, padding 3, 3 -> 64, no bias) against F.conv2d: exact on small
+    integers (every product and partial sum is exactly representable), then against the fp32 convolution of the bf16-rounded
+    operands; image in either memory format, map sizes whose last tile holds one column."""
+    from ucd_amd import hip
+    DEV = "cuda:0"
+    g = torch.Generator(DEV).manual_seed(B * H + W)
+    cl = torch.channels_last
+    xi = torch.randint(-3, 4, (B, 3, H, W), device=DEV, generator=g).float()
+    wi = torch.randint(-2, 3, (64, 3, 7, 7), device=DEV, generator=g).float()
+    if not nchw:
+        xi = xi.contiguous(memory_format=cl)
+    z = hip.stem_conv7x7(xi, wi.bfloat16().contiguous(memory_format=cl))
+    if B * H * W <= 40000:
+        # the reference on the CPU in float64 (the library's fp32 solvers - Winograd / FFT forms - are not exact on integers)
+        ref = F.conv2d(xi.cpu().double(), wi.cpu().double(), None, 2, 3).float().to(DEV)
+        assert z.shape == ref.shape and z.is_contiguous(memory_format=cl)
+        assert torch.equal(z.float(), ref.bfloat16().float())
+    else:
+        ref = F.conv2d(xi, wi, None, 2, 3)
+        assert z.shape == ref.shape and z.is_contiguous(memory_format=cl)
+        assert ((z.float() - ref).norm() / ref.norm()).item() < 3e-3
+    x = torch.randn(B, 3, H, W, device=DEV, generator=g) * 1.5 + 0.3
+    w = torch.randn(64, 3, 7, 7, device=DEV, generator=g) * 0.1
+    if not nchw:
+        x = x.contiguous(memory_format=cl)
+    z = hip.stem_conv7x7(x, w.bfloat16().contiguous(memory_format=cl))
+    ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, 2, 3)
+    err = ((z.float() - ref).norm() / ref.norm()).item()
+    assert err < 3e-3, err

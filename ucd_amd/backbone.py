@@ -12,6 +12,7 @@ import sys
 from collections import OrderedDict
 from functools import partial
 
+import torch
 import torch.nn as nn
 
 from .blocks import Conv2d, ResidualBlock, try_index
@@ -68,7 +69,7 @@ class ResNet(nn.Module):
             pool = m.pool1
             if (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False):
                 from .abn import stem_norm_pool
-                z = m.conv1(x)
+                z = _stem_conv(m.conv1, x)
                 y = stem_norm_pool(m.bn1, z)
                 return y if y is not None else pool(m.bn1(z))
         return m(x)
@@ -80,6 +81,45 @@ class ResNet(nn.Module):
         if hasattr(self, "classifier"):
             outs.append(self.classifier(outs[-1]))
         return outs if self.keep_outputs else outs[-1]
+
+
+class _StemConvFunction(torch.autograd.Function):
+    """conv1 of the stem on the own kernel (csrc/stem.hip::stem_conv7x7_kernel: the fp32 image is converted while it is staged,
+    no cast / layout kernels); the weight gradient stays with the library (the image needs no gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        from . import hip
+        ctx.save_for_backward(x, w)
+        return hip.stem_conv7x7(x, w)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        dw = None
+        if ctx.needs_input_grad[1]:
+            xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+            dw = torch.ops.aten.convolution_backward(dz.contiguous(memory_format=torch.channels_last), xb, w, None, [2, 2], [3, 3],
+                                                     [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        return None, dw
+
+
+def _stem_conv(conv, x):
+    """``conv(x)`` of the stem: the own 7x7 / 2 kernel for an fp32 image under bf16 autocast (what bench.py / run.py
+    --opt_level O1 build; working weight or autocast's per-call cast; ``UCD_OWN_STEM=0`` keeps MIOpen), else the module."""
+    import os
+    w = conv.working_weight() if hasattr(conv, "working_weight") else None
+    if w is None and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        w = conv.weight.to(torch.bfloat16)              # autocast's per-call cast (the mode without working weights)
+    if (w is None or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32 or x.requires_grad or conv.bias is not None
+            or tuple(conv.weight.shape) != (64, 3, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3)
+            or conv.dilation != (1, 1) or w.dtype != torch.bfloat16 or not w.is_contiguous(memory_format=torch.channels_last)
+            or os.environ.get("UCD_OWN_STEM", "1") == "0"):
+        return conv(x)
+    if torch.is_grad_enabled() and w.requires_grad:
+        return _StemConvFunction.apply(x, w)
+    from . import hip
+    return hip.stem_conv7x7(x, w)
 
 
 _NETS = {

@@ -243,6 +243,123 @@ __global__ __launch_bounds__(kThreads) void stem_sum_partials_kernel(const float
   }
 }
 
+// ---- the stem's 7x7 / 2 convolution (models/resnet.py:58: conv1 = Conv2d(3, 64, 7, stride 2, padding 3), no bias) ---------------------
+// z[b, oy, ox, n] = sum_{ky, kx, c} x[b, c, 2 oy - 3 + ky, 2 ox - 3 + kx] * w[n, c, ky, kx]   fp32 image in (any strides), bf16 out.
+// An implicit GEMM with K = 7 rows x (7 x 3 = 21 -> 24) = 168 -> 176: a workgroup stages the (2 TH + 5) x (2 TW + 5) x 3 patch of
+// its TH x TW = 8 x 32 output pixels in LDS as bf16 [row][pixel][channel] - the 21 values of one kernel row of one output pixel
+// are CONTIGUOUS there (6 ox elements from the row start), so an MFMA operand (8 consecutive k of one pixel) is four aligned
+// 32-bit LDS reads - and the weights as [n][ky * 24 + kx * 3 + c] (zero where kx * 3 + c >= 21).  Operands are swapped (A =
+// weights, B = pixels): a lane then holds 4 consecutive channels of one pixel per accumulator group and stores 8 bytes at a time.
+// Persistent workgroups (the 22 KB weight image is built once per workgroup), one tile per iteration.
+constexpr int kSTH = 8, kSTW = 32;                    // output tile
+constexpr int kSIR = 2 * kSTH + 5;                    // 21 input rows
+constexpr int kSIP = 216;                             // bf16 pitch of an input row: (2 * 32 + 5) * 3 = 207, + the over-read of the last pixel
+constexpr int kSWP = 184;                             // bf16 pitch of a weight row: 176 + 8 (an odd number of 16-byte slots)
+constexpr int kSK = 176;
+
+struct StemConvArgs {
+  const float* x; long long sb, sc, sh, sw;           // element strides of the fp32 image [B, 3, H, W]
+  const bf16* w;                                      // [64][7][7][3] (channels-last memory order of the [64, 3, 7, 7] weight)
+  bf16* z;                                            // [B, OH, OW, 64]
+  int B, H, W, OH, OW, tiles_y, tiles_x, ntiles;
+};
+
+__global__ __launch_bounds__(kThreads) void stem_conv7x7_kernel(StemConvArgs p) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  __shared__ __attribute__((aligned(16))) unsigned short Wl[64 * kSWP];
+  __shared__ __attribute__((aligned(16))) unsigned short In[kSIR * kSIP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // weights: zero image, then the 147 real values of every output channel
+  for (int i = tid; i < 64 * kSWP; i += kThreads) Wl[i] = 0;
+  __syncthreads();
+  for (int i = tid; i < 64 * 147; i += kThreads) {
+    const int n = i / 147, r = i - n * 147, ky = r / 21, j = r - ky * 21;
+    Wl[n * kSWP + ky * 24 + j] = reinterpret_cast<const unsigned short*>(p.w)[i];
+  }
+  const int col = lane & 31, h = lane >> 5;
+  // The patch of a tile: thread e < 216 owns column element e (pixel e / 3, channel e % 3 - constants of the thread) of all 21
+  // rows; ALL loads are issued before the first use - and issued for the NEXT tile before this tile's MFMAs, so they land under
+  // them (the first version loaded and stored element by element: 18 exposed round trips per tile, 20 us per tile and workgroup).
+  const int fe = tid < kSIP ? tid : kSIP - 1, fpx = fe / 3, fc = fe - fpx * 3;
+  float pre[kSIR];
+  auto fetch = [&](int tile) {
+    const int b = tile / (p.tiles_y * p.tiles_x), rem = tile - b * p.tiles_y * p.tiles_x;
+    const int oy0 = (rem / p.tiles_x) * kSTH, ox0 = (rem % p.tiles_x) * kSTW;
+    const int ix = 2 * ox0 - 3 + fpx;
+    const bool colok = fpx < 2 * kSTW + 5 && (unsigned)ix < (unsigned)p.W;
+    const float* src = p.x + b * p.sb + fc * p.sc + (colok ? ix : 0) * p.sw;
+#pragma unroll
+    for (int r = 0; r < kSIR; ++r) {
+      const int iy = 2 * oy0 - 3 + r;
+      const bool ok = colok && (unsigned)iy < (unsigned)p.H;        // clamped address + select: no branch around the load
+      const float v = src[(ok ? iy : 0) * p.sh];
+      pre[r] = ok ? v : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int b = tile / (p.tiles_y * p.tiles_x), rem = tile - b * p.tiles_y * p.tiles_x;
+    const int oy0 = (rem / p.tiles_x) * kSTH, ox0 = (rem % p.tiles_x) * kSTW;
+    __syncthreads();                                   // the previous tile's reads are done (and the weight image is complete)
+    if (tid < kSIP) {
+#pragma unroll
+      for (int r = 0; r < kSIR; ++r) {
+        const bf16 v = __float2bfloat16(pre[r]);
+        In[r * kSIP + tid] = *reinterpret_cast<const unsigned short*>(&v);
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+    f32x16 acc[2][2];                                  // [output row of this wave][channel block]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < kSK / 16; ++s) {
+      // this lane's 8 k: slot t = 2 s + h of the 22 eight-wide slots; kernel row t / 3, offset 8 (t % 3) inside its 24
+      const int t0 = 2 * s, t1 = 2 * s + 1;
+      // (slot 21 is all padding - zero weights - and must still read FINITE patch values: kernel row clamped to 6)
+      const int ky = h ? (t1 / 3 > 6 ? 6 : t1 / 3) : t0 / 3, j0 = h ? 8 * (t1 % 3) : 8 * (t0 % 3);
+      bf16x8 wf[2], pf[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wf[c] = *reinterpret_cast<const bf16x8*>(&Wl[(c * 32 + col) * kSWP + 16 * s + 8 * h]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int orow = wave * 2 + a;
+        const unsigned* src = reinterpret_cast<const unsigned*>(&In[(2 * orow + ky) * kSIP + 6 * col + j0]);
+        union { unsigned u[4]; bf16x8 v; } f;
+        f.u[0] = src[0]; f.u[1] = src[1]; f.u[2] = src[2]; f.u[3] = src[3];
+        pf[a] = f.v;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c], pf[a], acc[a][c], 0, 0, 0);
+    }
+    // accumulator (row = channel, column = pixel): register r of lane l = channel (r & 3) + 8 (r >> 2) + 4 (l >> 5), pixel l & 31
+    const int ox = ox0 + col;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int oy = oy0 + wave * 2 + a;
+      if (oy >= p.OH || ox >= p.OW) continue;
+      bf16* dst = p.z + (((size_t)b * p.OH + oy) * p.OW + ox) * 64;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          union { bf16 v[4]; uint2 u; } o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o.v[e] = __float2bfloat16(acc[a][c][g * 4 + e]);
+          *reinterpret_cast<uint2*>(dst + c * 32 + 8 * g + 4 * h) = o.u;
+        }
+    }
+  }
+}
+
 bool stem_args_ok(const void* z, int B, int H, int W, int C) {
   return z && B > 0 && B < 65536 && H > 1 && H < 65536 && W > 1 && C >= 8 && (C & (C - 1)) == 0 && C <= 2048 && aligned16(z);
 }
@@ -270,6 +387,20 @@ int ucd_stem_apply_pool(const void* z, int B, int H, int W, int C, const float* 
   p.mean = mean; p.scale = scale; p.beta = beta; p.slope = a == UCD_ACT_IDENTITY ? 1.f : slope;
   p.cg_shift = __builtin_ctz(C / 8);
   stem_apply_pool_kernel<<<dim3(ceil_div(p.PW * (C / 8), kThreads), p.PH, B), kThreads, 0, (hipStream_t)stream>>>(p, (bf16*)out, idx);
+  return check_launch(fn);
+}
+
+int ucd_stem_conv7x7(const float* x, long long sb, long long sc, long long sh, long long sw, int B, int H, int W, const void* w,
+                     void* z, ucd_stream_t stream) {
+  static const char* fn = "ucd_stem_conv7x7";
+  UCD_REQUIRE(x && w && z && B > 0 && H > 0 && W > 0 && aligned16(z) && (reinterpret_cast<uintptr_t>(w) & 1) == 0, UCD_EINVAL,
+              "%s: bad arguments", fn);
+  StemConvArgs p{};
+  p.x = x; p.sb = sb; p.sc = sc; p.sh = sh; p.sw = sw; p.w = (const bf16*)w; p.z = (bf16*)z;
+  p.B = B; p.H = H; p.W = W; p.OH = (H + 6 - 7) / 2 + 1; p.OW = (W + 6 - 7) / 2 + 1;
+  p.tiles_y = ceil_div(p.OH, kSTH); p.tiles_x = ceil_div(p.OW, kSTW); p.ntiles = B * p.tiles_y * p.tiles_x;
+  const int grid = p.ntiles < 768 ? p.ntiles : 768;          // three resident workgroups per CU, each walking its tiles
+  stem_conv7x7_kernel<<<grid, kThreads, 0, (hipStream_t)stream>>>(p);
   return check_launch(fn);
 }
 

@@ -109,6 +109,7 @@ SIGNATURES = {
     "ucd_stem_pool_backward": (_i, [_p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _f, _i, _f, _p, _p, _z, _i, _p]),
     "ucd_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "ucd_conv_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
+    "ucd_stem_conv7x7": (_i, [_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p, _p]),
     "ucd_conv_wgrad_strided": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
     "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
@@ -573,6 +574,19 @@ def abn_sync_finalize(gathered, world, M, Cc, weight, running_mean, running_var,
     _check(load().ucd_abn_sync_finalize(ptr(gathered), world, M, Cc, ptr(weight), ptr(running_mean), ptr(running_var),
                                         float(momentum), float(eps), ptr(buf), int(flags) & NORM_ABS_GAMMA, stream()),
            "ucd_abn_sync_finalize")
+
+
+def stem_conv7x7(x, w):
+    """The stem's convolution (ucd_stem_conv7x7): ``x`` fp32 [B, 3, H, W] in any memory format, ``w`` the bf16 [64, 3, 7, 7]
+    weight in channels-last memory order -> z [B, 64, OH, OW] dense channels-last bf16."""
+    lib = load()
+    B, Cc, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    z = torch.empty((B, 64, OH, OW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    sb, sc, sh, sw = x.stride()
+    with _timed("ucd_stem_conv7x7", x.numel() * 4 + z.numel() * 2):
+        _check(lib.ucd_stem_conv7x7(ptr(x), sb, sc, sh, sw, B, H, W, ptr(w), ptr(z), stream()), "ucd_stem_conv7x7")
+    return z
 
 
 def stem_apply_pool(z, mean, scale, beta, act, slope, want_idx):
