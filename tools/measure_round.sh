@@ -9,12 +9,14 @@ for gb in 12 6 3; do python bench.py --steps 10 --warmup 3 --global_batch $gb --
 timeout 300 python tools/conv1x1_probe.py > $O/conv1x1_probe.txt 2>&1
 timeout 300 python tools/conv3x3_probe.py > $O/conv3x3_probe.txt 2>&1
 timeout 200 python tools/conv_strided_probe.py > $O/conv_strided_probe.txt 2>&1
+(timeout 100 python tools/stem_conv_probe.py | tail -1; timeout 100 python tools/stem_conv_probe.py 3 | tail -1) > $O/stem_conv_probe.txt 2>&1
+timeout 100 python tools/blocklink_probe.py > $O/blocklink_probe.txt 2>&1
 timeout 300 python tools/wgrad_probe2.py > $O/wgrad_probe.txt 2>&1
 timeout 120 python tools/pixcon_pairs.py > $O/pixcon_pairs.txt 2>&1
 (for m in f16 f16_split; do timeout 100 python tools/pixcon_bench.py $m | tail -2; timeout 100 python tools/pixcon_bench.py $m dom | tail -2; done) > $O/pixcon_bench.txt 2>&1
 timeout 100 python tools/seglosses_bench.py > $O/seglosses_bench.txt 2>&1
 timeout 100 python tools/seglosses_bench.py ade >> $O/seglosses_bench.txt 2>&1
-(for sw in UCD_STEM_FOLD UCD_BLOCK_LINK UCD_OWN_WGRAD UCD_OWN_STRIDED; do env $sw=0 timeout 120 python bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=0', 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))"; done; timeout 120 python bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default', 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))") > $O/switch_ab.txt 2>&1
+(for sw in UCD_STEM_FOLD UCD_BLOCK_LINK UCD_OWN_WGRAD UCD_OWN_STRIDED UCD_PROJ_ALIAS UCD_OWN_STEM; do env $sw=0 timeout 120 python bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$sw=0', 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))"; done; timeout 120 python bench.py --steps 12 --warmup 4 --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('default', 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1))") > $O/switch_ab.txt 2>&1
 timeout 200 python tools/abn_bench.py > $O/abn_bench.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_kernel_timing > /tmp/prof.log 2>&1
