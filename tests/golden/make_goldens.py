@@ -91,8 +91,11 @@ def import_reference_model():
     return models, modules, segmentation_module
 
 
+OUT_DIR = os.environ.get("UCD_GOLDEN_OUT", HERE)      # the regeneration test writes into a scratch directory
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name)
+    path = os.path.join(OUT_DIR, name)
     np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
     print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -254,14 +257,8 @@ def gold_model():
         out_old, feat_old = teacher(img)
     opt.zero_grad()
     outp, feat = student(img)
-    if max_label is None:
-        a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
-                                                         f_o=feat_old["pre_logits"])
-    else:
-        from oracle import contrastive as OC
-        prep = OC.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), feat_old["sem"], feat_old["pre_logits"],
-                                        max_label=max_label)
-        a, c, la, lc, P = prep["a"], prep["c"], prep["la"], prep["lc"], prep["P"]
+    a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
+                                                     f_o=feat_old["pre_logits"])
     ce = ref_loss.UnbiasedCrossEntropy(old_cl=16, ignore_index=255, reduction="none")(outp, labels.clone()).mean()
     con = ref_loss.PixelConLossV2(temperature=0.07)(a, c, la, lc, P)
     loss = ce + con / 100
@@ -452,9 +449,45 @@ def gold_aspp_eval():
     save("aspp_eval.npz", **out)
 
 
+def gold_traj513(steps=20):
+    """``steps`` consecutive iterations of train.py:95-151 (as intended) on ONE fixed batch - configs[1] at its real crop, 2 x 513^2,
+    calibrated checkpoint, SGD-Nesterov lr 1e-3 / wd 1e-4 in the reference's three groups, no scheduler - through the reference's
+    own classes in fp32: the per-step losses are the golden the product's multi-step tests are held to (fp32 mode tightly over
+    the first steps, the benchmarked bf16 mode along the whole trajectory)."""
+    models, modules, segm = import_reference_model()
+    student, teacher = _build_pair(models, modules, segm, [16, 5], calibrated=True)
+    img = synth.images(502, 2, 513)
+    labels = synth.seg_labels(502, 2, 513, 513, range(16, 21))
+    groups = [{"params": [p for p in m.parameters() if p.requires_grad], "weight_decay": 1e-4}
+              for m in (student.body, student.head, student.cls)]
+    opt = torch.optim.SGD(groups, lr=1e-3, momentum=0.9, nesterov=True)
+    with torch.no_grad():
+        out_old, feat_old = teacher(img)
+    rec = {k: [] for k in ("ce", "con", "lkd", "A", "C")}
+    for it in range(steps):
+        opt.zero_grad()
+        outp, feat = student(img)
+        a, c, la, lc, P = ref_loss.pre_contrastive_pixel(feat["pre_logits"], labels.clone(), l_po=feat_old["sem"],
+                                                         f_o=feat_old["pre_logits"])
+        ce = ref_loss.UnbiasedCrossEntropy(old_cl=16, ignore_index=255, reduction="none")(outp, labels.clone()).mean()
+        con = ref_loss.PixelConLossV2(temperature=0.07)(a, c, la, lc, P)
+        lkd = 10 * ref_loss.UnbiasedKnowledgeDistillationLoss(alpha=1.0)(outp, out_old)
+        (ce + con / 100 + lkd).backward()
+        opt.step()
+        for k, v in (("ce", ce.item()), ("con", con.item()), ("lkd", lkd.item()), ("A", a.shape[0]), ("C", c.shape[0])):
+            rec[k].append(v)
+        print(f"traj step {it}: ce {ce.item():.6f} con {con.item():.6f} lkd {lkd.item():.6f} A {a.shape[0]} C {c.shape[0]}", flush=True)
+    save("ucd_traj_513_cal.npz", cfg=np.array([502, 2, 513, steps]), ce=np.array(rec["ce"]), con=np.array(rec["con"]),
+         lkd=np.array(rec["lkd"]), A=np.array(rec["A"]), C=np.array(rec["C"]),
+         running_mean_after=student.body.mod1.bn1.running_mean.numpy().copy(),
+         cls1_bias_after=dict(student.named_parameters())["cls.1.bias"].detach().numpy().copy())
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["pixcon", "logit", "v1", "model", "cfg0", "step513", "heads", "aspp_eval", "step513_cal", "cfg3_ade",
-                             "cfg4_city"]
+                             "cfg4_city", "traj513"]
+    if "traj513" in which:
+        gold_traj513()
     if "cfg0" in which:
         gold_cfg0()
     if "pixcon" in which:

@@ -7,7 +7,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from ucd_amd import synth
+from ucd_amd import switches, synth
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -145,12 +145,12 @@ def test_residual_block_eval_fused_equals_layer_by_layer(stride, dil, cin):
             xb = x.bfloat16()
             assert blk._eval_fusable(xb)
             fused = blk(xb.clone())
-            os.environ["UCD_FUSED_CONV1X1"] = "0"
+            switches.set("UCD_FUSED_CONV1X1", "0")
             try:
                 assert not blk._eval_fusable(xb)
                 plain = blk(xb.clone())
             finally:
-                del os.environ["UCD_FUSED_CONV1X1"]
+                switches.unset("UCD_FUSED_CONV1X1")
     assert fused.dtype == torch.bfloat16 and fused.shape == ref32.shape
     e_f, e_p = _rel(fused, ref32), _rel(plain, ref32)
     assert e_f < 1e-2 and e_f < 1.5 * e_p + 1e-3, (e_f, e_p)       # no worse than the unfused bf16 path
@@ -177,7 +177,7 @@ def test_residual_block_training_fused_node_equals_module_path(cin, chans, with_
         blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
         mod = DistributedDataParallel(blk, bf16_weights=True) if with_ddp else blk
         if not fused:
-            os.environ["UCD_FUSED_CONV1X1"] = "0"
+            switches.set("UCD_FUSED_CONV1X1", "0")
         try:
             x = x0.clone().requires_grad_(True)
             with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -186,7 +186,7 @@ def test_residual_block_training_fused_node_equals_module_path(cin, chans, with_
             if with_ddp:
                 mod.finish_grad_sync()
         finally:
-            os.environ.pop("UCD_FUSED_CONV1X1", None)
+            switches.unset("UCD_FUSED_CONV1X1")
         grads = {n: p.grad.float().clone() for n, p in blk.named_parameters()}
         outs.append((y.detach().float(), x.grad.float(), grads, blk.convs.bn3.running_var.clone(), blk.convs.bn1.running_mean.clone()))
     (yf, gxf, gf, rvf, rmf), (yp, gxp, gp, rvp, rmp) = outs
@@ -350,7 +350,7 @@ def test_residual_block_training_with_own_3x3(cin, chans, dil, hw):
         blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
         mod = DistributedDataParallel(blk, bf16_weights=True) if mode != "fp32" else blk
         if mode == "module":
-            os.environ["UCD_FUSED_CONV1X1"] = "0"
+            switches.set("UCD_FUSED_CONV1X1", "0")
         try:
             if mode == "fp32":
                 x = x0.float().clone().requires_grad_(True)
@@ -363,7 +363,7 @@ def test_residual_block_training_with_own_3x3(cin, chans, dil, hw):
                 y.backward(dy)
                 mod.finish_grad_sync()
         finally:
-            os.environ.pop("UCD_FUSED_CONV1X1", None)
+            switches.unset("UCD_FUSED_CONV1X1")
         grads = {n: p.grad.float().clone() for n, p in blk.named_parameters()}
         outs.append((y.detach().float(), x.grad.float(), grads, blk.convs.bn2.running_var.clone()))
     (yf, gxf, gf, rvf), (yp, gxp, gp, rvp), (y32, gx32, g32, rv32) = outs
@@ -398,7 +398,7 @@ def test_backward_link_moves_the_abn_reduction_into_the_input_gradient_product(c
             def counting(*a, **k):
                 calls[0] += 1
                 return real_reduce(*a, **k)
-            os.environ["UCD_BWD_LINK"] = link
+            switches.set("UCD_BWD_LINK", link)
             blocks._node_cache[0] = node if use_node else None
             hip.abn_bwd_reduce = counting
             saved_timing = hip._timing
@@ -417,7 +417,7 @@ def test_backward_link_moves_the_abn_reduction_into_the_input_gradient_product(c
                 res[(use_node, link)] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in blk.parameters()]
                 counts[(use_node, link)] = calls[0]
             finally:
-                os.environ.pop("UCD_BWD_LINK", None)
+                switches.unset("UCD_BWD_LINK")
                 blocks._node_cache[0] = node
                 hip.abn_bwd_reduce = real_reduce
                 hip._timing = saved_timing
@@ -485,7 +485,7 @@ def test_backward_link_parity_through_the_model_with_intermediate_features_read(
     torch.backends.cudnn.deterministic = True
     try:
         for link in ("1", "0"):
-            os.environ["UCD_BWD_LINK"] = link
+            switches.set("UCD_BWD_LINK", link)
             opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
                 ["--method", "UCD", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained", "--norm_act", "iabn_sync",
                  "--opt_level", "O1", "--loss_de", "1"]))
@@ -502,7 +502,7 @@ def test_backward_link_parity_through_the_model_with_intermediate_features_read(
             res[link] = ({k: v.item() for k, v in r.items()},
                          {n: p.grad.float().clone() for n, p in model.named_parameters() if p.grad is not None})
     finally:
-        os.environ.pop("UCD_BWD_LINK", None)
+        switches.unset("UCD_BWD_LINK")
         torch.backends.cudnn.deterministic = False
     (la, ga), (lb, gb) = res["1"], res["0"]
     assert la["lde"] > 0
@@ -724,7 +724,7 @@ def test_block_link_moves_bn3_backward_into_the_next_blocks_first_product(cin, c
             def counting(*a, **k):
                 calls[0] += 1
                 return real_reduce(*a, **k)
-            os.environ["UCD_BLOCK_LINK"] = link
+            switches.set("UCD_BLOCK_LINK", link)
             blocks._node_cache[0] = node if use_node else None
             hip.abn_bwd_reduce = counting
             saved_timing = hip._timing
@@ -745,7 +745,7 @@ def test_block_link_moves_bn3_backward_into_the_next_blocks_first_product(cin, c
                 res[(use_node, link)] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in net.parameters()]
                 counts[(use_node, link)] = calls[0]
             finally:
-                os.environ.pop("UCD_BLOCK_LINK", None)
+                switches.unset("UCD_BLOCK_LINK")
                 blocks._node_cache[0] = node
                 hip.abn_bwd_reduce = real_reduce
                 hip._timing = saved_timing
@@ -912,7 +912,7 @@ def test_projection_block_alias_equals_the_separate_gradient_add(cin, chans, str
     x0 = synth.t_normal(21, (B, cin, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
     res = {}
     for alias in ("1", "0"):
-        os.environ["UCD_PROJ_ALIAS"] = alias
+        switches.set("UCD_PROJ_ALIAS", alias)
         try:
             # an identity block in front (its bn3 offers the block link), the projection block, an identity block behind
             net = torch.nn.Sequential(blocks.ResidualBlock(cin, (front, front, cin), norm_act=norm),
@@ -929,7 +929,7 @@ def test_projection_block_alias_equals_the_separate_gradient_add(cin, chans, str
             mod.finish_grad_sync()
             res[alias] = [y.detach().float(), x.grad.float()] + [p.grad.float().clone() for p in net.parameters()]
         finally:
-            os.environ.pop("UCD_PROJ_ALIAS", None)
+            switches.unset("UCD_PROJ_ALIAS")
     a, b = res["1"], res["0"]
     assert torch.equal(a[0], b[0])
     worst = max(_rel(a[i], b[i]) for i in range(1, len(a)) if b[i].abs().max() > 0)

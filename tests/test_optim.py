@@ -210,8 +210,15 @@ def test_launcher_builds_the_hip_step_by_default(monkeypatch):
     opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
         ["--method", "UCD", "--task", "15-5", "--step", "0", "--no_pretrained"]))
     model = build_models(opts, torch.device("cuda:0"), tasks.get_per_task_classes("voc", "15-5", 0))[0]
+    from ucd_amd import switches
     monkeypatch.delenv("UCD_SGD", raising=False)
+    switches.reload()
     opt = make_optimizer(opts, model)
     assert isinstance(opt, optim.SGD) and len(opt.param_groups) == 3       # the one-launch step is what run.py:175-186 builds
     monkeypatch.setenv("UCD_SGD", "torch")
-    assert type(make_optimizer(opts, model)) is torch.optim.SGD             # the A/B reference
+    switches.reload()
+    try:
+        assert type(make_optimizer(opts, model)) is torch.optim.SGD         # the A/B reference
+    finally:
+        monkeypatch.delenv("UCD_SGD", raising=False)
+        switches.reload()

@@ -1,6 +1,8 @@
 """CPU: the oracle (oracle/) reproduces the golden vectors captured from the reference's own Python
 (tests/golden/make_goldens.py).  This is what pins the oracle; the GPU tests then compare the HIP
 path with the pinned oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -113,3 +115,53 @@ def test_v1_losses_match_reference():
     # the v1 loss is the V2 form's special case P = 1, c = a, no row-max shift (what the HIP kernel runs for it)
     v2 = OC.pixcon_loss(f.double(), f.double(), lab, lab, None, 0.07, shift=False)
     assert v2.item() == pytest.approx(float(g["pixcon_T007"]), rel=1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists only in the build container")
+def test_golden_recipe_runs_and_reproduces_the_committed_fixtures(tmp_path):
+    """VERDICT r3 / ADVICE r3: the committed generator must run as committed.  Its fast entry points (contrastive, logit losses,
+    the dead-file losses, the model-level goldens incl. the 2 x 129^2 step) are re-run into a scratch directory and every array must
+    equal the committed .npz bit for bit; the slow entry points are at least compiled and checked for undefined names."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    script = os.path.join(here, "golden", "make_goldens.py")
+    env = dict(os.environ, UCD_GOLDEN_OUT=str(tmp_path))
+    r = subprocess.run([sys.executable, script, "pixcon", "logit", "v1", "model"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".npz"))
+    assert {"pixcon_voc_15_5.npz", "logit_losses.npz", "v1_losses.npz", "model_full.npz", "model_blocks.npz", "ucd_step.npz"} <= set(made), made
+    for f in made:
+        new, old = np.load(os.path.join(tmp_path, f)), np.load(os.path.join(here, "golden", f))
+        assert sorted(new.files) == sorted(old.files), f
+        for k in new.files:
+            assert np.array_equal(new[k], old[k]), (f, k)
+    # every gold_* entry point: names resolve (the r3 bug was a NameError in a function the default run reaches late)
+    import ast
+    import builtins
+    tree = ast.parse(open(script).read())
+    top = {n.name for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))}
+    for n in tree.body:
+        if isinstance(n, (ast.Import, ast.ImportFrom)):
+            top |= {(a.asname or a.name).split(".")[0] for a in n.names}
+        elif isinstance(n, ast.Assign):
+            top |= {t.id for t in n.targets if isinstance(t, ast.Name)}
+    for fn in (n for n in tree.body if isinstance(n, ast.FunctionDef)):
+        bound = {a.arg for a in fn.args.args + fn.args.kwonlyargs} | ({fn.args.vararg.arg} if fn.args.vararg else set()) \
+            | ({fn.args.kwarg.arg} if fn.args.kwarg else set())
+        for sub in ast.walk(fn):
+            if isinstance(sub, ast.Name) and isinstance(sub.ctx, (ast.Store, ast.Del)):
+                bound.add(sub.id)
+            elif isinstance(sub, (ast.FunctionDef, ast.ClassDef)):
+                bound.add(sub.name)
+                if isinstance(sub, ast.FunctionDef):
+                    bound |= {a.arg for a in sub.args.args + sub.args.kwonlyargs}
+            elif isinstance(sub, (ast.Import, ast.ImportFrom)):
+                bound |= {(a.asname or a.name).split(".")[0] for a in sub.names}
+            elif isinstance(sub, ast.arg):
+                bound.add(sub.arg)
+            elif isinstance(sub, ast.ExceptHandler) and sub.name:
+                bound.add(sub.name)
+        for sub in ast.walk(fn):
+            if isinstance(sub, ast.Name) and isinstance(sub.ctx, ast.Load):
+                assert sub.id in bound or sub.id in top or hasattr(builtins, sub.id), (fn.name, sub.id, sub.lineno)

@@ -492,3 +492,89 @@ def test_aspp_eval_pooling_on_the_gpu_matches_reference_golden(tag):
             yb = head(x.clone())
     ref = y.float()
     assert ((yb.float() - ref).norm() / ref.norm()).item() < 2e-2
+
+
+# ---- several consecutive steps: training BEHAVIOUR of the benchmarked mode ---------------------------
+TRAJ_UPDATE_NAMES = ("body.mod1.conv1.weight", "body.mod2.block1.convs.conv1.weight", "body.mod3.block2.convs.conv2.weight",
+                     "body.mod4.block10.convs.conv3.weight", "body.mod5.block3.convs.conv3.weight", "head.map_convs.2.weight",
+                     "head.red_conv.weight", "cls.1.weight")
+
+
+def _trajectory(opt_level, steps, step_graph="0"):
+    """``steps`` iterations of the product on the fixed 2 x 513^2 batch of tests/golden/make_goldens.py::gold_traj513 (calibrated
+    checkpoint, lr 1e-3, no scheduler); returns the per-step losses and the accumulated update of a few parameters."""
+    from ucd_amd import switches
+    from ucd_amd.ddp import DistributedDataParallel
+    from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+    from ucd_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    extra = () if opt_level == "O0" else ("--opt_level", opt_level)
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
+        ["--method", "UCD", "--dataset", "voc", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained",
+         "--norm_act", "iabn_sync", *extra]))
+    classes = tasks.get_per_task_classes("voc", "15-5", 1)
+    torch.backends.cudnn.allow_tf32 = False
+    model, model_old = build_models(opts, dev, classes)
+    state = synth.fill_state_dict({k: v.cpu() for k, v in model_old.state_dict().items()}, 42, calibrated=True)
+    optim = make_optimizer(opts, model)
+    net = model
+    if opt_level != "O0":
+        model = DistributedDataParallel(model, delay_allreduce=True, bf16_weights=True)
+    load_step_checkpoint(opts, model, model_old, state, dev)
+    switches.set("UCD_STEP_GRAPH", step_graph)
+    try:
+        trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+        img = synth.images(502, 2, 513)
+        labels = synth.seg_labels(502, 2, 513, 513, range(16, 21))
+        model.train()
+        params = dict(net.named_parameters())
+        before = {n: params[n].detach().double().cpu().clone() for n in TRAJ_UPDATE_NAMES}
+        rec = {k: [] for k in ("ce", "con", "lkd")}
+        for _ in range(steps):
+            r = trainer.train_step(img, labels, optim, None)
+            for k in rec:
+                rec[k].append(r[k].item())
+        torch.cuda.synchronize()
+        upd = {n: params[n].detach().double().cpu() - before[n] for n in TRAJ_UPDATE_NAMES}
+        extra_out = {"cls1_bias": params["cls.1.bias"].detach().cpu().numpy().copy(),
+                     "running_mean": net.body.mod1.bn1.running_mean.cpu().numpy().copy(),
+                     "graph_steps": getattr(trainer, "graph_steps", 0)}
+    finally:
+        switches.unset("UCD_STEP_GRAPH")
+    return {k: np.asarray(v) for k, v in rec.items()}, upd, extra_out
+
+
+def test_twenty_step_trajectory_fp32_and_bf16_against_the_reference():
+    """20 SGD steps on one fixed batch (configs[1] at 2 x 513^2, calibrated checkpoint).  Golden = the reference's own classes run
+    for 20 steps in fp32 on the CPU (ucd_traj_513_cal.npz).  The fp32 product is held to it at 1e-3 over the first five steps (and a
+    measured bound afterwards: 20 steps of a train-mode network compound the ~3e-4 forward differences of two fp32 implementations),
+    the benchmarked bf16 mode to the fp32 product AND to the reference at 2e-2 at EVERY step; both must train (ce and the
+    distillation term fall like the reference's).  The accumulated parameter updates of eight layers across the network are compared
+    by DIRECTION (cosine) between the two precisions: a gradient kernel with a wrong sign or scale on the composed network cannot
+    hide behind abs-sums here."""
+    g = load_golden("ucd_traj_513_cal.npz")
+    steps = int(g["cfg"][3])
+    f32, up32, ex32 = _trajectory("O0", steps)
+    b16, up16, ex16 = _trajectory("O1", steps)
+    for k in ("ce", "con", "lkd"):
+        rel32 = np.abs(f32[k] - g[k]) / np.abs(g[k])
+        rel16 = np.abs(b16[k] - g[k]) / np.abs(g[k])
+        relab = np.abs(b16[k] - f32[k]) / np.abs(f32[k])
+        print(k, "fp32 vs reference: first 5 max %.2e, all max %.2e | bf16 vs reference max %.2e | bf16 vs fp32 max %.2e"
+              % (rel32[:5].max(), rel32.max(), rel16.max(), relab.max()))
+        assert rel32[:5].max() < 1e-3, (k, rel32)
+        assert rel32.max() < 5e-3, (k, rel32)
+        assert rel16.max() < 2e-2, (k, rel16)
+        assert relab.max() < 2e-2, (k, relab)
+    for traj in (f32, b16):
+        assert traj["ce"][-1] < 0.7 * traj["ce"][0] and traj["lkd"][-1] < 0.95 * traj["lkd"][0]      # reference: 0.61, 0.90
+        assert np.all(np.diff(traj["ce"]) < 0)                                                      # like the reference's
+    np.testing.assert_allclose(ex32["cls1_bias"], g["cls1_bias_after"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(ex16["cls1_bias"], g["cls1_bias_after"], rtol=2e-2, atol=1e-5)
+    np.testing.assert_allclose(ex32["running_mean"], g["running_mean_after"], rtol=1e-3, atol=1e-6)
+    for n in TRAJ_UPDATE_NAMES:
+        a, b = up32[n].flatten(), up16[n].flatten()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
+        ratio = float(b.norm() / (a.norm() + 1e-300))
+        print(f"update over {steps} steps, bf16 vs fp32: {n}: cosine {cos:.4f} length ratio {ratio:.3f}")
+        assert cos > 0.9 and 0.8 < ratio < 1.25, (n, cos, ratio)

@@ -5,7 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch
-from ucd_amd import synth
+from ucd_amd import switches, synth
 from ucd_amd.run import make_optimizer
 from ucd_amd.train import Trainer
 import test_step_gpu as T
@@ -18,7 +18,7 @@ for seed in (502, 503, 504):
     res = {}
     for tag, lvl, env in (("O0", "O0", None), ("O1 fused", "O1", None), ("O1 module", "O1", "0")):
         if env is not None:
-            os.environ["UCD_FUSED_CONV1X1"] = env
+            switches.set("UCD_FUSED_CONV1X1", env)
         try:
             opts = T._opts(["--opt_level", lvl])
             model, model_old, classes = T._build(opts, dev)
@@ -27,6 +27,6 @@ for seed in (502, 503, 504):
             model.train()
             res[tag] = {k: v.item() for k, v in trainer.train_step(img, labels, optim, None).items()}
         finally:
-            os.environ.pop("UCD_FUSED_CONV1X1", None)
+            switches.unset("UCD_FUSED_CONV1X1")
     for tag in ("O1 fused", "O1 module"):
         print("seed", seed, tag, {k: "%+.2f%%" % (100 * (res[tag][k] - res["O0"][k]) / abs(res["O0"][k])) for k in ("ce", "con", "lkd", "loss")})

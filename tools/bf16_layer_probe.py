@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ucd_amd import argparser, synth, tasks  # noqa: E402
+from ucd_amd import argparser, switches, synth, tasks  # noqa: E402
 from ucd_amd.ddp import DistributedDataParallel  # noqa: E402
 from ucd_amd.run import build_models, load_step_checkpoint  # noqa: E402
 
@@ -17,7 +17,7 @@ img = synth.images(502, B, S).to(dev).contiguous(memory_format=torch.channels_la
 
 
 def run(level, fused):
-    os.environ["UCD_FUSED_CONV1X1"] = "1" if fused else "0"
+    switches.set("UCD_FUSED_CONV1X1", "1" if fused else "0")
     opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
         ["--method", "UCD", "--task", "15-5", "--step", "1", "--no_pretrained", "--norm_act", "iabn_sync", "--opt_level", level]))
     classes = tasks.get_per_task_classes("voc", "15-5", 1)

@@ -1,11 +1,17 @@
 # SQ counters (one pass, 8 slots) + durations of the kernels whose name matches $1, for the command after `--`:
-#   bash tools/prof_kernel.sh conv1x1_kernel -- python3 tools/conv3x3_probe.py
+#   bash tools/prof_kernel.sh conv1x1_kernel -- python3 tools/conv3x3_probe.py      (a relative program path is resolved against the repo root)
 # -> gpurun_out/prof_kernel/<pattern>.txt   (put the program itself after --: no env / bash -c hops under rocprofv3)
-R=$GRAFT_REPO_ROOT; PAT=$1; shift; shift; O=$R/gpurun_out/prof_kernel; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; PAT=$1
+if [ -z "$PAT" ] || [ "$2" != "--" ] || [ $# -lt 3 ]; then echo "usage: prof_kernel.sh <kernel-name-pattern> -- <program> [args]" >&2; exit 2; fi
+shift; shift; O=$R/gpurun_out/prof_kernel; mkdir -p $O
+# the profiler runs from /tmp: make every relative path argument that names a file of the repo absolute first
+ARGS=(); for a in "$@"; do if [ "${a#/}" = "$a" ] && [ -e "$R/$a" ]; then a="$R/$a"; fi; ARGS+=("$a"); done; set -- "${ARGS[@]}"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pk_t /tmp/pk_c
 timeout 400 rocprofv3 --kernel-trace -d /tmp/pk_t -o t --output-format csv -- "$@" > /tmp/pk_t.log 2>&1
 timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pk_c -o s --output-format csv -- "$@" > /tmp/pk_c.log 2>&1
+if ! ls /tmp/pk_t/*kernel_trace.csv > /dev/null 2>&1; then echo "prof_kernel.sh: no kernel trace was written:" >&2; tail -20 /tmp/pk_t.log >&2; exit 1; fi
+if ! ls /tmp/pk_c/*counter_collection.csv > /dev/null 2>&1; then echo "prof_kernel.sh: no counter file was written:" >&2; tail -20 /tmp/pk_c.log >&2; exit 1; fi
 PK_PAT="$PAT" python3 - <<'PY' > $O/$PAT.txt
 import csv, collections, glob, os
 pat = os.environ["PK_PAT"]

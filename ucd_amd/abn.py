@@ -30,6 +30,8 @@ from __future__ import annotations
 
 import os
 
+from . import switches as _switches
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -75,7 +77,7 @@ def _abn_node():
     is the complete implementation, the node a faster host path for the training-mode layers."""
     global _node_mod
     if _node_mod is False:
-        if os.environ.get("UCD_ABN_NODE", "1") == "0":
+        if _switches.get("UCD_ABN_NODE", "1") == "0":
             _node_mod = None
         else:
             try:
@@ -419,7 +421,7 @@ def stem_norm_pool(bn, z):
     then runs the two modules): HIP ABN with leaky_relu / identity, dense channels-last bf16 map, channel count a multiple of
     8 dividing 2048; frozen statistics only without gradients (``UCD_STEM_FOLD=0`` switches the fold off)."""
     import os
-    if os.environ.get("UCD_STEM_FOLD", "1") == "0" or not getattr(bn, "ucd_fused_abn", False):
+    if _switches.get("UCD_STEM_FOLD", "1") == "0" or not getattr(bn, "ucd_fused_abn", False):
         return None
     Cc = z.shape[1] if z.dim() == 4 else 0
     if not (z.is_cuda and z.dim() == 4 and z.dtype == torch.bfloat16 and z.is_contiguous(memory_format=torch.channels_last)

@@ -15,6 +15,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from . import switches as _switches
 from .blocks import Conv2d, ResidualBlock, try_index
 
 _STAGE_DILATION = {16: (1, 1, 1, 2), 8: (1, 1, 2, 4)}
@@ -107,14 +108,13 @@ class _StemConvFunction(torch.autograd.Function):
 def _stem_conv(conv, x):
     """``conv(x)`` of the stem: the own 7x7 / 2 kernel for an fp32 image under bf16 autocast (what bench.py / run.py
     --opt_level O1 build; working weight or autocast's per-call cast; ``UCD_OWN_STEM=0`` keeps MIOpen), else the module."""
-    import os
     w = conv.working_weight() if hasattr(conv, "working_weight") else None
     if w is None and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         w = conv.weight.to(torch.bfloat16)              # autocast's per-call cast (the mode without working weights)
     if (w is None or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32 or x.requires_grad or conv.bias is not None
             or tuple(conv.weight.shape) != (64, 3, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3)
             or conv.dilation != (1, 1) or w.dtype != torch.bfloat16 or not w.is_contiguous(memory_format=torch.channels_last)
-            or os.environ.get("UCD_OWN_STEM", "1") == "0"):
+            or _switches.get("UCD_OWN_STEM", "1") == "0"):
         return conv(x)
     if torch.is_grad_enabled() and w.requires_grad:
         return _StemConvFunction.apply(x, w)

@@ -40,21 +40,13 @@ def _wgrad_split(M: int) -> int:
     return 1
 
 
-_ENV_RAW = getattr(os.environ, "_data", None)       # CPython: the dict behind os.environ (encoded keys and values)
-_ENV_KEYS = {}
+from . import switches as _switches
 
 
 def _env(name, default):
-    """``os.environ.get(name, default)`` for the A/B switches read on every layer call, without encoding the key each time (620
-    reads per step were 4 % of the host time of the 3-images-per-GPU step); sees ``monkeypatch.setenv`` / ``os.environ[...] =``
-    like the mapping itself, and falls back to it on an interpreter without ``_data``."""
-    if _ENV_RAW is None:
-        return os.environ.get(name, default)
-    k = _ENV_KEYS.get(name)
-    if k is None:
-        k = _ENV_KEYS[name] = os.environ.encodekey(name)
-    v = _ENV_RAW.get(k)
-    return default if v is None else os.environ.decodevalue(v)
+    """An A/B switch (ucd_amd.switches): resolved once per process, a dict lookup afterwards (the layer code asks ~600 times per
+    step)."""
+    return _switches.get(name, default)
 
 
 def _own_wgrad() -> bool:

@@ -11,6 +11,8 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+
+from . import switches as _switches
 import warnings
 
 import torch
@@ -108,7 +110,7 @@ def direct_comm(group=None):
         return _comms[key]
     comm = None
     usable = (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()
-              and dist.get_backend(group) == "nccl" and os.environ.get("UCD_DIRECT_RCCL", "1") != "0")
+              and dist.get_backend(group) == "nccl" and _switches.get("UCD_DIRECT_RCCL", "1") != "0")
     if usable:
         comm = _create(group)
     _comms[key] = comm

@@ -1,9 +1,11 @@
 """Losses of the ``--method UCD`` step, reference interface (utils/loss.py).
 
 ``UnbiasedCrossEntropy`` (utils/loss.py:89-109) and ``UnbiasedKnowledgeDistillationLoss``
-(utils/loss.py:139-184) act on the full-resolution logits; this round they are a lean PyTorch
-composition on the GPU (SURVEY.md section 8 ranks their fusion with the bilinear up-sampling as the first
-"next" row, f1).  The contrastive loss lives in :mod:`ucd_amd.contrastive`.
+(utils/loss.py:139-184) keep the reference's module interface on full-resolution logits (the unfused path:
+``--alpha`` != 1, plain KD, tests).  The training step itself calls ``fused_seg_losses``: bilinear x16
+up-sampling + UnbiasedCE + UnbiasedKD + the gradient w.r.t. the LOW-resolution logits in one HIP kernel
+(``ucd_seg_losses``, csrc/seglogit_loss.hip) - the ``[B, Ctot, H, W]`` tensors never exist.
+The contrastive loss lives in :mod:`ucd_amd.contrastive`.
 """
 from __future__ import annotations
 

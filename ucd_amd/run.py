@@ -10,6 +10,8 @@ synthetic batches the benchmark uses; a data root without ``splits/`` raises lik
 from __future__ import annotations
 
 import os
+
+from . import switches as _switches
 import random
 
 import numpy as np
@@ -42,7 +44,7 @@ def make_optimizer(opts, model):
         groups.append({"params": [p for p in net.body.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
     groups.append({"params": [p for p in net.head.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
     groups.append({"params": [p for p in net.cls.parameters() if p.requires_grad], "weight_decay": opts.weight_decay})
-    if next(net.parameters()).is_cuda and os.environ.get("UCD_SGD", "hip") != "torch":
+    if next(net.parameters()).is_cuda and _switches.get("UCD_SGD", "hip") != "torch":
         # a torch.optim.SGD subclass (same groups, state_dict, hooks, schedulers) whose step is ONE launch (csrc/sgd.hip) that
         # also writes the bf16 working weights; bit-exact against the rule in float64 (tests/test_optim.py).  UCD_SGD=torch
         # selects torch's fused step (the A/B reference of the tests).

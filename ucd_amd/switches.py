@@ -1,0 +1,63 @@
+"""The ``UCD_*`` A/B switches of the product path, resolved ONCE per process.
+
+Every switch is an environment variable read at its first use and cached in a plain dict (the layer code asks ~600 times per
+step; ``os.environ.get`` encodes the key on every call).  Tests and probes that flip a switch inside one process go through
+``set`` / ``unset`` (which also keep ``os.environ`` in step for child processes) or call ``reload`` after changing the
+environment themselves.  ``snapshot`` is what bench.py prints as ``own_kernels``: a run that lost a kernel family to a switch
+(or to a fallback) is visible in its JSON line.
+"""
+from __future__ import annotations
+
+import os
+
+# name -> default; "1" = the own kernel / fusion is on
+DEFAULTS = {
+    "UCD_FUSED_CONV1X1": "1",      # conv + training-ABN nodes on csrc/conv1x1.hip (0: module path, library kernels)
+    "UCD_BWD_LINK": "1",           # backward links inside a bottleneck (out_mode 3)
+    "UCD_BLOCK_LINK": "1",         # block links across a block boundary (out_mode 4)
+    "UCD_PROJ_ALIAS": "1",         # projection blocks: proj_conv reads the alias returned by conv1's node
+    "UCD_DGRAD_VIA_FWD": "1",      # stride-1 input gradients on forward solvers / the own kernel
+    "UCD_LIB_GEMM_WIDE": "0",      # 1: the two large square 1x1 products on hipBLASLt
+    "UCD_OWN3X3_MIN_TILES": "1",   # own 3x3 below this many tiles -> MIOpen
+    "UCD_OWN3X3_WIDE": "1",        # 0: the 512 -> 512 3x3 layers on MIOpen
+    "UCD_OWN_STRIDED": "1",        # strided conv2 / proj_conv on the own kernels
+    "UCD_OWN_WGRAD": "1",          # weight gradients on csrc/wgrad.hip
+    "UCD_OWN_STEM": "1",           # 7x7/2 stem forward on csrc/stem.hip
+    "UCD_OWN_STEM_WGRAD": "1",     # 7x7/2 stem weight gradient on csrc/stem.hip
+    "UCD_OWN_HEADS": "1",          # classifier heads / pooled-branch 1x1 on the own GEMM (N padded to 64, masked store)
+    "UCD_STEM_FOLD": "1",          # stem norm + max-pool as one pass
+    "UCD_ABN_NODE": "1",           # C++ autograd nodes
+    "UCD_SGD": "hip",              # one-launch optimiser step (torch: torch's fused SGD)
+    "UCD_STEP_GRAPH": "auto",      # whole-step hipGraph: auto = world 1 only, 1 = always try, 0 = never
+    "UCD_DIRECT_RCCL": "1",        # library-owned RCCL communicator for SyncBN
+}
+
+_cache: dict = {}
+
+
+def get(name: str, default: str | None = None) -> str:
+    v = _cache.get(name)
+    if v is None:
+        if default is None:
+            default = DEFAULTS.get(name, "")
+        v = _cache[name] = os.environ.get(name, default)
+    return v
+
+
+def set(name: str, value) -> None:       # noqa: A001 - mirrors os.environ's vocabulary
+    os.environ[name] = str(value)
+    _cache[name] = str(value)
+
+
+def unset(name: str) -> None:
+    os.environ.pop(name, None)
+    _cache.pop(name, None)
+
+
+def reload() -> None:
+    """Forget the cached values (after ``os.environ`` / ``monkeypatch.setenv`` changed a switch)."""
+    _cache.clear()
+
+
+def snapshot() -> dict:
+    return {k: get(k) for k in DEFAULTS}
