@@ -114,9 +114,9 @@ def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
     from ucd_amd import abn, blocks, hip
     # attribution mode: every library call visible and alone on the stream - no C++ nodes (their Python twins issue the
     # same library calls), no teacher graph, no teacher/student overlap (the timed region above ran with all three)
-    saved = (abn._node_mod, trainer.graph_teacher, trainer._side, blocks._node_cache[0])
+    saved = (abn._node_mod, trainer.graph_teacher, trainer._side, blocks._node_cache[0], trainer.step_graph)
     abn._abn_node()
-    abn._node_mod, trainer.graph_teacher, trainer._side = None, False, None
+    abn._node_mod, trainer.graph_teacher, trainer._side, trainer.step_graph = None, False, None, False
     blocks._node_cache[0] = None
     rec = hip.enable_call_timing()
     try:
@@ -125,7 +125,7 @@ def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
         torch.cuda.synchronize()
     finally:
         hip.disable_call_timing()
-        abn._node_mod, trainer.graph_teacher, trainer._side, blocks._node_cache[0] = saved
+        abn._node_mod, trainer.graph_teacher, trainer._side, blocks._node_cache[0], trainer.step_graph = saved
     # an event pair with nothing between it does not read zero (~5 us here); it is REPORTED, not subtracted: a call's
     # events bracket launch gaps too, so the per-call durations are upper bounds of the kernel time (rocprofv3's kernel
     # durations in profiles/ are ~10 % shorter) and the roofline fraction computed from them is conservative
@@ -182,7 +182,8 @@ def cpu_baseline(args, classes):
     A3, C3 = prep["a"].shape[0], prep["c"].shape[0]
     contrastive = {"seconds": tc, "A": A3, "C": C3, "K": 16, "gflops_algorithmic": A3 * C3 * (4 * 256 + 2 * 16) / tc / 1e9,
                    "sample": "pre_contrastive_pixel + PixelConLossV2 forward + backward, 3 images 33x33 maps (cfg3 per-rank shape)"}
-    return {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port", "contrastive": contrastive,
+    return {"value": B / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
+            "contrastive": contrastive,
             "sample": f"1 full UCD step after 1 warm-up step (teacher fwd + student fwd/bwd + CE + contrastive + KD + SGD), {B} images "
                       f"{args.crop}x{args.crop}, fp32 PyTorch-CPU oracle, {dt:.1f} s",
             "loss": float((r["loss"] + r["lkd"]).detach())}
@@ -214,11 +215,13 @@ def main():
         torch.cuda.synchronize()
 
     # one-time work never belongs in the timed region, whatever W is: MIOpen's solver search and the GEMM tuning run in
-    # the first step, the teacher's hipGraph is captured at its third call, the library-owned communicator is created at the
-    # first SyncBN layer - so at least four untimed steps run before the clock starts
-    for _ in range(max(args.warmup, 4)):
+    # the first step, the whole-step hipGraph is captured at the fourth call (the teacher's own graph at the third / fifth
+    # when the step is not captured), the library-owned communicator is created at the first SyncBN layer - so at least six
+    # untimed steps run before the clock starts
+    for _ in range(max(args.warmup, 6)):
         trainer.train_step(images, labels, optimizer, scheduler)
     sync()
+    graph_steps_before = trainer.graph_steps
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.train_step(images, labels, optimizer, scheduler)
@@ -229,6 +232,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     last = {k: float(v) for k, v in trainer.last.items()}
+    from ucd_amd import switches
+    # how the timed iterations actually ran: a silent fallback (capture failed, a kernel family switched off) is visible here
+    execution = {"step_graph": trainer.graph_steps - graph_steps_before == args.steps,
+                 "step_graph_error": trainer.step_graph_error,
+                 "teacher_graph": bool(trainer._sg is not None or trainer._tg is not None),
+                 "teacher_graph_error": getattr(trainer, "teacher_graph_error", None),
+                 "teacher_overlap": trainer._side is not None}
+    own_kernels = switches.snapshot()
     lockstep = None
     if args.check_lockstep and world > 1:
         # data parallelism keeps every replica identical: after the timed steps all ranks must hold the same parameters AND
@@ -268,7 +279,7 @@ def main():
         roof["launches_per_step"] = k["launches"] / min(args.steps, 3)
         # HBM traffic of that kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_to_json.py); null if absent
-        for rnd in ("r03", "r02"):                          # the newest committed collection that has this call
+        for rnd in ("r04", "r03", "r02"):                   # the newest committed collection that has this call
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench.json")
             if not os.path.exists(pmc):
                 continue
@@ -300,7 +311,8 @@ def main():
                                    f"({per_rank}/GPU), random-init weights via a synthetic step-0 checkpoint",
                        "parallelism": f"dp{world}", "opt_level": args.opt_level,
                        "contrastive_dtype": trainer.pixcon_precision},
-            "losses": last, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "losses": last, "execution": execution, "own_kernels": own_kernels,
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
         }
         if lockstep is not None:
             out["lockstep"] = bool(lockstep)

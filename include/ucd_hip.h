@@ -561,6 +561,13 @@ typedef struct ucd_sgd_hyper {
 } ucd_sgd_hyper;
 int ucd_sgd_chunk(void);
 int ucd_sgd_step(const ucd_sgd_tensor* table, const int* blocks, int n_blocks, const ucd_sgd_hyper* hyper, ucd_stream_t stream);
+/* The same step with the hyper-parameters in DEVICE memory (device_hyper): the form a captured hipGraph of the whole training
+ * iteration (train.py:95-151) replays while PolyLR changes the learning rate every iteration (train.py:150-151) - a by-value
+ * kernel argument would be frozen into the graph.  ucd_sgd_hyper_store writes host values into that device struct in stream
+ * order (the values travel as a kernel argument: no pinned staging buffer that a later step could overwrite early). */
+int ucd_sgd_hyper_store(ucd_sgd_hyper* device_hyper, const ucd_sgd_hyper* hyper, ucd_stream_t stream);
+int ucd_sgd_step_dev(const ucd_sgd_tensor* table, const int* blocks, int n_blocks, const ucd_sgd_hyper* device_hyper,
+                     ucd_stream_t stream);
 
 #ifdef __cplusplus
 }

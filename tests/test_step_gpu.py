@@ -578,3 +578,66 @@ def test_twenty_step_trajectory_fp32_and_bf16_against_the_reference():
         ratio = float(b.norm() / (a.norm() + 1e-300))
         print(f"update over {steps} steps, bf16 vs fp32: {n}: cosine {cos:.4f} length ratio {ratio:.3f}")
         assert cos > 0.9 and 0.8 < ratio < 1.25, (n, cos, ratio)
+
+
+def _scheduled_steps(step_graph, steps=8, batch=3, crop=257):
+    """``steps`` iterations of the benchmarked mode with PolyLR stepping every iteration (train.py:150-151), with or without the
+    whole-step graph; returns losses per step, a few parameters afterwards and the number of replayed iterations."""
+    from ucd_amd import switches
+    from ucd_amd.ddp import DistributedDataParallel
+    from ucd_amd.run import build_models, load_step_checkpoint, make_optimizer
+    from ucd_amd.scheduler import PolyLR
+    from ucd_amd.train import Trainer
+    dev = torch.device("cuda:0")
+    opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
+        ["--method", "UCD", "--dataset", "voc", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained",
+         "--norm_act", "iabn_sync", "--opt_level", "O1"]))
+    classes = tasks.get_per_task_classes("voc", "15-5", 1)
+    model, model_old = build_models(opts, dev, classes)
+    state = synth.fill_state_dict({k: v.cpu() for k, v in model_old.state_dict().items()}, 42, calibrated=True)
+    optim = make_optimizer(opts, model)
+    sched = PolyLR(optim, max_iters=steps + 2, power=0.9)        # a steep schedule: a frozen learning rate would show at once
+    net = model
+    model = DistributedDataParallel(model, delay_allreduce=True, bf16_weights=True)
+    load_step_checkpoint(opts, model, model_old, state, dev)
+    switches.set("UCD_STEP_GRAPH", step_graph)
+    torch.backends.cudnn.deterministic = True
+    try:
+        trainer = Trainer(model, model_old, device=dev, opts=opts, classes=classes)
+        model.train()
+        rec, lrs = [], []
+        for it in range(steps):
+            img = synth.images(700 + it % 2, batch, crop)             # two alternating batches: the static inputs must be refreshed
+            labels = synth.seg_labels(700 + it % 2, batch, crop, crop, range(16, 21))
+            lrs.append(optim.param_groups[0]["lr"])
+            r = trainer.train_step(img, labels, optim, sched)
+            rec.append([r[k].item() for k in ("ce", "con", "lkd", "loss")])
+        torch.cuda.synchronize()
+        params = dict(net.named_parameters())
+        after = {n: params[n].detach().float().cpu().clone() for n in TRAJ_UPDATE_NAMES}
+        after["running_var"] = net.body.mod4.block5.convs.bn2.running_var.cpu().clone()
+        return np.asarray(rec), after, trainer.graph_steps, lrs, trainer.step_graph_error
+    finally:
+        torch.backends.cudnn.deterministic = False
+        switches.unset("UCD_STEP_GRAPH")
+
+
+def test_whole_step_graph_replays_the_eager_iteration():
+    """The captured iteration (Trainer._graph_step: teacher + student forward, losses, backward, bucket hand-over, one-launch
+    optimiser with its hyper-parameters on the device) is the eager iteration: same losses at every step, same parameters and
+    running statistics after 8 steps on two alternating batches under a steep PolyLR - the learning rate reaches the replayed
+    optimiser kernel, the inputs reach the static buffers, and nothing that ran on the host during the capture is missing from
+    the replay."""
+    eager, pe, n_e, lrs_e, _ = _scheduled_steps("0")
+    graph, pg, n_g, lrs_g, err = _scheduled_steps("1")
+    assert err is None, err
+    assert n_e == 0 and n_g == 8 - 3, (n_e, n_g)          # three eager warm-up iterations, then replays only
+    assert lrs_e == lrs_g and lrs_e[-1] < 0.35 * lrs_e[0]
+    print("eager vs graph losses, max rel:", np.abs(eager - graph).max(0) / np.abs(eager).max(0))
+    np.testing.assert_allclose(graph, eager, rtol=2e-3)
+    for n in pe:
+        d = ((pe[n] - pg[n]).norm() / pe[n].norm()).item()
+        assert d < 1e-4, (n, d)
+    # and the update itself took the schedule: against a run whose optimiser never saw the decay the weights differ visibly
+    first = eager[0]
+    assert np.all(np.isfinite(graph)) and graph[-1][3] < first[3]

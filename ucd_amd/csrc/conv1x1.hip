@@ -78,6 +78,12 @@ __device__ __forceinline__ float act_grad_rt(float z, float slope) { return z > 
 // (rows 0-3,12-15,20-27 / 4-11,16-19,28-31 of a 32-row fragment) hit 16 different slots: conflict-free without padding,
 // which is what lets the tile be filled by global_load_lds (lane-linear destination, swizzle on the SOURCE address).
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+// The same for K steps of 32 (64-byte rows, four rows per 256-byte bank row): slot s of row r at s ^ ((r >> 2) & 3) - the rows
+// of one ds_read_b128 group that share r & 3 (the same 64-byte quarter of a bank row) differ in (r >> 2) & 3.
+template <int BK>
+__device__ __forceinline__ int swz_fn(int row) { return BK == 64 ? ((row >> 1) & 7) : ((row >> 2) & 3); }
+template <int BK>
+__device__ __forceinline__ int swzk(int row, int slot) { return row * (BK * 2) + ((slot ^ swz_fn<BK>(row)) << 4); }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -101,17 +107,27 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // whose interleaving hides the fill latency of the single-stage form - the 9 K deep, MFMA-bound 3x3 products most of all: the
 // fill of step k+1 is issued (LDS-DMA: no registers to carry) before the MFMAs of step k and waited for with a counted
 // vmcnt, so it lands under them.  64 KB of LDS, two workgroups per CU.
-template <int BN, bool PRO, int OUT, bool CONV3 = false, bool DB = false>
-__global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
+// barriers executed by the epilogue (conv1x1_epilogue.inc): waves that only load run as many
+template <int OUT> constexpr int kEpilogueBarriers = 4 + (OUT >= 2 ? 2 : 0);
+
+// Pipeline depth of the DB form (round 4): NST stages of K steps of BK columns, fills NST - 1 steps ahead behind counted vmcnt
+// waits.  <64, 2> is the original double buffer (64 KB, two workgroups per CU); <32, 4> keeps two workgroups per CU (4 x 16 KB
+// stages each: 96 KB of fills in flight per CU instead of 64, three steps of latency cover instead of one) for the grids of
+// 257 .. 640 workgroups (every 33 x 33 layer at B = 24); <64, 4> (128 KB, ONE workgroup per CU) is for grids that give a CU at most
+// one workgroup anyway (the 3 - 6 images per GPU of the multi-GPU split: 26 - 104 workgroups, where a K step is one exposed
+// memory round trip - 36 of them in a row for a 256-channel 3x3 layer).
+template <int BN, bool PRO, int OUT, bool CONV3 = false, bool DB = false, int BK = 64, int NST = 2>
+__global__ __launch_bounds__(kThreads, DB ? (BK * NST >= 256 ? 1 : 2) : ((PRO || OUT >= 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
   static_assert(!DB || !PRO, "the double-buffered form has no input transform");
-  constexpr int kStage = (kBM + BN) * 128;   // bytes of one LDS stage (A tile + W tile)
+  static_assert(DB || (BK == 64 && NST == 2), "pipeline parameters belong to the DB form");
+  static_assert(BK == 64 || BK == 32, "K steps of 64 or 32");
+  static_assert(NST == 2 || NST == 4, "two or four stages");
+  constexpr int kStage = (kBM + BN) * BK * 2;   // bytes of one LDS stage (A tile + W tile)
   constexpr int WN = BN / 2;           // columns per wave
   constexpr int TN = WN / 32;          // 32-wide accumulator tiles per wave along N
-  constexpr int CP = BN + 4;           // fp32 pitch of the (half) output tile in LDS
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* As = smem;                            // [128][64] bf16, swizzled
-  unsigned char* Bs = smem + kBM * 128;                // [BN][64]
-  float* Cs = reinterpret_cast<float*>(smem);          // [64][CP] per epilogue half
+  unsigned char* Bs = smem + kBM * BK * 2;             // [BN][BK]
   float* Ps = reinterpret_cast<float*>(smem + p.param_off);   // PRO: [3][K] input-transform constants, loaded once
 
   // tile of this workgroup: column tiles of one strip on the same XCD
@@ -135,14 +151,15 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
   // ---- staging addresses -------------------------------------------------------------------------------------------
   // LDS-DMA: wave-instruction c covers tile rows 8c .. 8c+7 (1 KiB); lane l lands on (row 8c + l/8, slot l%8) and
   // therefore FETCHES logical slot (l%8) ^ ((row >> 1) & 7) of that row.  Rows past M are clamped (never stored).
-  constexpr int CA = 4, CB = BN / 32;                  // chunks per wave: A 16 chunks, B BN/8 chunks, 4 waves
+  constexpr int RPC = 1024 / (BK * 2), SPR = BK / 8;    // rows per 1 KiB chunk (8 | 16), 16-byte slots per row (8 | 4)
+  constexpr int CA = kBM / RPC / 4, CB = BN / RPC / 4;  // chunks per wave: A kBM / RPC chunks, B BN / RPC chunks, 4 waves
   const bf16* ga[CA];
   const bf16* gb[CB];
   int py[CA], px[CA], pimg[CA], pslot[CA];              // CONV3: pixel coordinates of this lane's staged rows
 #pragma unroll
   for (int i = 0; i < CA; ++i) {
-    const int row = 8 * (wave * CA + i) + (lane >> 3);
-    const int slot = ((lane & 7) ^ ((row >> 1) & 7)) << 3;
+    const int row = RPC * (wave * CA + i) + lane / SPR;
+    const int slot = ((lane % SPR) ^ swz_fn<BK>(row)) << 3;
     ga[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + slot;
     if (CONV3 || p.stride > 1) {
       const int m = m0 + row;
@@ -158,8 +175,8 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
   }
 #pragma unroll
   for (int i = 0; i < CB; ++i) {
-    const int row = 8 * (wave * CB + i) + (lane >> 3);
-    gb[i] = p.W + (size_t)(n0 + row) * p.ldw + (((lane & 7) ^ ((row >> 1) & 7)) << 3);
+    const int row = RPC * (wave * CB + i) + lane / SPR;
+    gb[i] = p.W + (size_t)(n0 + row) * p.ldw + (((lane % SPR) ^ swz_fn<BK>(row)) << 3);
   }
   // register path of A (PRO): thread -> 16-byte slot ks of rows srow + 32 i
   const int ks = tid & 7, srow = tid >> 3;
@@ -177,7 +194,8 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
     __syncthreads();
   }
   const int fr = lane & 31, fh = lane >> 5;
-  const int kpt = p.K / kBK;                           // K steps per tap
+  static_assert(!PRO || BK == 64, "the register-staged input transform walks K in steps of 64");
+  const int kpt = p.K / BK;                            // K steps per tap
   const int nk = CONV3 ? 9 * kpt : kpt;
   uint4 ra[4];
   if (PRO) {
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
   };
   auto fill3 = [&](int kb, unsigned char* Ad, unsigned char* Bd) {   // LDS-DMA fill of step kb (double-buffered form)
     const int tap = CONV3 ? kb / kpt : 0;
-    const int k0 = (kb - tap * kpt) * kBK;
+    const int k0 = (kb - tap * kpt) * BK;
     if (CONV3) {
       if (tap != atap) set_tap(tap);
 #pragma unroll
@@ -228,10 +246,14 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
     for (int i = 0; i < CB; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bd + (wave * CB + i) * 1024), 16, (int)boff[i], (tap * p.K + k0) * 2, 0, 0);
   };
-  if (DB) fill3(0, As, Bs);
+  if (DB) {
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+      if (st < nk) fill3(st, As + st * kStage, Bs + st * kStage);
+  }
   for (int kb = 0; kb < nk; ++kb) {
     const int tap = CONV3 ? kb / kpt : 0;
-    const int k0 = (kb - tap * kpt) * kBK;
+    const int k0 = (kb - tap * kpt) * BK;
     const int wk0 = CONV3 ? tap * p.K + k0 : k0;       // column offset inside a weight row (pitch 9 K)
     if (kb) {                                          // the previous step's fragment reads are done
       if (DB) {   // raw barrier: __syncthreads() would wait for the fill in flight as well
@@ -241,15 +263,20 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
         __syncthreads();
       }
     }
-    const unsigned char* Ac = As + (DB ? (kb & 1) * kStage : 0);
-    const unsigned char* Bc = Bs + (DB ? (kb & 1) * kStage : 0);
+    const unsigned char* Ac = As + (DB ? (kb & (NST - 1)) * kStage : 0);
+    const unsigned char* Bc = Bs + (DB ? (kb & (NST - 1)) * kStage : 0);
     if (DB) {
-      if (kb + 1 < nk) {
-        fill3(kb + 1, As + ((kb + 1) & 1) * kStage, Bs + ((kb + 1) & 1) * kStage);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB) : "memory");   // this step's fill; the next one stays in flight
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the stage read in step kb - 1 is free (barrier above): the fill of step kb + NST - 1 goes there; then wait until only
+      // the fills BEHIND this step's are still in flight (a counted vmcnt: r younger fills of CA + CB loads each)
+      if (kb + NST - 1 < nk) {
+        const int st = (kb + NST - 1) & (NST - 1);
+        fill3(kb + NST - 1, As + st * kStage, Bs + st * kStage);
       }
+      const int r = min(NST - 1, nk - 1 - kb);          // wave-uniform
+      if (NST == 4 && r >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (CA + CB)) : "memory");
+      else if (NST == 4 && r == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (CA + CB)) : "memory");
+      else if (r >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else if (PRO) {
 #pragma unroll
@@ -307,14 +334,14 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
       bf16x8 af[2][2], bfr[2][TN];
       auto read_slice = [&](int set, int kk) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) af[set][a] = *reinterpret_cast<const bf16x8*>(Ac + swz(wm * 64 + a * 32 + fr, 2 * kk + fh));
+        for (int a = 0; a < 2; ++a) af[set][a] = *reinterpret_cast<const bf16x8*>(Ac + swzk<BK>(wm * 64 + a * 32 + fr, 2 * kk + fh));
 #pragma unroll
-        for (int b = 0; b < TN; ++b) bfr[set][b] = *reinterpret_cast<const bf16x8*>(Bc + swz(wn * WN + b * 32 + fr, 2 * kk + fh));
+        for (int b = 0; b < TN; ++b) bfr[set][b] = *reinterpret_cast<const bf16x8*>(Bc + swzk<BK>(wn * WN + b * 32 + fr, 2 * kk + fh));
       };
       read_slice(0, 0);
 #pragma unroll
-      for (int kk = 0; kk < kBK / 16; ++kk) {
-        if (kk + 1 < kBK / 16) read_slice((kk + 1) & 1, kk + 1);
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        if (kk + 1 < BK / 16) read_slice((kk + 1) & 1, kk + 1);
         __builtin_amdgcn_sched_barrier(0);                   // the reads above stay above these MFMAs
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -339,158 +366,154 @@ __global__ __launch_bounds__(kThreads, DB ? 2 : ((PRO || OUT >= 3) && BN == 128 
     }
   }
 
-  // ---- epilogue: accumulators -> LDS (fp32, [row][col], 64 rows at a time) -> row-contiguous 16-byte global accesses --
-  constexpr int CPR = BN / 8;                       // 8-column chunks per row
-  constexpr int RPT = 64 * CPR / kThreads;          // rows per thread and half (4 for BN = 128, 2 for BN = 64)
-  constexpr int RSTEP = kThreads / CPR;             // row stride between a thread's chunks
-  const int c8 = tid % CPR, r0 = tid / CPR;
-  const int ncol = n0 + c8 * 8;
-  float em[8], es[8], eb[8], ei[8];
-  if (OUT == 1 || OUT == 3) {
+#include "conv1x1_epilogue.inc"
+}
+
+// ---- loader-wave form (round 4) ------------------------------------------------------------------------------------------------
+// What bounds the forms above on the MFMA-bound products (3x3: K = 9 x 256 ... 9 x 2048) is not LDS or HBM but the ISSUE of the
+// LDS-DMA: a `buffer_load_dwordx4 ... lds` piece (1 KiB) holds the issuing wave for 60 - 185 cycles (MI355X_MICROARCH.md, cycle
+// constants), 8 pieces per wave and K step = 800 - 1500 cycles next to 16 MFMAs = 512: a wave of the DB form is ~34 % MFMA-busy, and
+// two per SIMD reach ~67 % (profiles/r03_conv3x3_sq.txt).  Here the roles are split: waves 0 - 3 hold the 2 x 2 wave tiles and do
+// nothing but {barrier; 16 ds_read_b128 + 16 MFMA} per K step; waves 4 - 7 only stage - they issue the fill of step kb + NST - 1
+// right after barrier kb (the stage of step kb - 1 is free then), wait with a counted vmcnt until the fill of step kb + 1 has
+// landed and join barrier kb + 1.  ONE barrier per K step, no DMA issue in an MFMA wave's instruction stream.
+template <int BN, int OUT, bool CONV3, int BK, int NST>
+__global__ __launch_bounds__(2 * kThreads, (kBM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 2) void conv_lw_kernel(Args p) {
+  static_assert(BK == 64 || BK == 32, "K steps of 64 or 32");
+  static_assert(NST >= 3 && NST <= 4, "three or four stages");
+  constexpr int kStage = (kBM + BN) * BK * 2;
+  constexpr int WN = BN / 2, TN = WN / 32;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + kBM * BK * 2;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
+  if (tm >= p.tiles_m) return;
+  const int m0 = tm * kBM, n0 = tn * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kpt = p.K / BK;
+  const int nk = CONV3 ? 9 * kpt : kpt;
+
+  if (wave >= 4) {
+    // ================================ loader waves ================================
+    const int lw = wave - 4;
+    constexpr int RPC = 1024 / (BK * 2), SPR = BK / 8;
+    constexpr int CA = kBM / RPC / 4, CB = BN / RPC / 4;
+    int py[CA], px[CA], pimg[CA], pslot[CA];
+    unsigned a1off[CA], boff[CB];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      em[e] = p.out_mean[ncol + e];
-      es[e] = p.out_scale[ncol + e];
-      eb[e] = p.out_shift[ncol + e];
-      ei[e] = (OUT == 3) ? p.out_invstd[ncol + e] : 0.f;
-    }
-  }
-  if (OUT == 4) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      em[e] = p.out_mean[ncol + e];
-      ei[e] = p.out_invstd[ncol + e];
-      es[e] = 0.f; eb[e] = 0.f;
-    }
-  }
-  float kshift[8], s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { kshift[e] = 0.f; s1[e] = 0.f; s2[e] = 0.f; }
-  const bool has_side = ((OUT == 0 || OUT == 4) && p.accumulate) || (OUT == 1 && p.R != nullptr) || OUT == 3;
-  const bf16* sp = (OUT == 0 || OUT == 4) ? p.Y : p.R;
-  const int lds_ = (OUT == 0 || OUT == 4) ? p.ldy : p.ldr;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    // side input (residual / old y / x) of this half's rows: requested before the LDS round trip, rows past M clamped
-    uint4 side[RPT], side_y[OUT == 4 ? RPT : 1], side_z[OUT == 4 ? RPT : 1];
-    if (has_side) {
-#pragma unroll
-      for (int i = 0; i < RPT; ++i)
-        side[i] = *reinterpret_cast<const uint4*>(sp + (size_t)min(m0 + half * 64 + r0 + RSTEP * i, p.M - 1) * lds_ + ncol);
-    }
-    if (OUT == 4) {
-#pragma unroll
-      for (int i = 0; i < RPT; ++i) {
-        const size_t row = (size_t)min(m0 + half * 64 + r0 + RSTEP * i, p.M - 1);
-        side_y[i] = *reinterpret_cast<const uint4*>(p.R + row * p.ldr + ncol);
-        side_z[i] = *reinterpret_cast<const uint4*>(p.Z + row * p.ldz + ncol);
+    for (int i = 0; i < CA; ++i) {
+      const int row = RPC * (lw * CA + i) + lane / SPR;
+      const int slot = ((lane % SPR) ^ swz_fn<BK>(row)) << 3;
+      a1off[i] = (unsigned)(((size_t)min(m0 + row, p.M - 1) * p.lda + slot) * 2);
+      if (CONV3 || p.stride > 1) {
+        const int m = m0 + row;
+        const int mm = min(m, p.M - 1);
+        const int b = mm / p.ohw, rem = mm - b * p.ohw;
+        const int oy = rem / p.oW, ox = rem - oy * p.oW;
+        py[i] = m < p.M ? oy * p.stride : -(1 << 20);
+        px[i] = ox * p.stride;
+        pimg[i] = b * p.iH * p.iW;
+        pslot[i] = slot;
+        if (!CONV3) a1off[i] = (unsigned)(((size_t)(pimg[i] + oy * p.stride * p.iW + px[i]) * p.lda + slot) * 2);
       }
     }
-    __syncthreads();                                  // main loop reads / previous half's reads are done
-    if (wm == half) {
+#pragma unroll
+    for (int i = 0; i < CB; ++i) {
+      const int row = RPC * (lw * CB + i) + lane / SPR;
+      boff[i] = (unsigned)(((size_t)(n0 + row) * p.ldw + (((lane % SPR) ^ swz_fn<BK>(row)) << 3)) * 2);
+    }
+    const auto rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((size_t)p.N * p.ldw * 2), 0x00020000);
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((size_t)p.a_rows * p.lda * 2), 0x00020000);
+    constexpr unsigned kOOB = 0x7FFFFFF0u;
+    unsigned aoff[CA];
+    int atap = -1;
+    auto set_tap = [&](int tap) {
+      const int dy = (tap / 3 - 1) * p.dil, dx = (tap % 3 - 1) * p.dil;
+#pragma unroll
+      for (int i = 0; i < CA; ++i) {
+        const int yy = py[i] + dy, xx = px[i] + dx;
+        const bool ok = (unsigned)yy < (unsigned)p.iH && (unsigned)xx < (unsigned)p.iW;
+        aoff[i] = ok ? (unsigned)(((pimg[i] + yy * p.iW + xx) * p.lda + pslot[i]) * 2) : kOOB;
+      }
+      atap = tap;
+    };
+    auto fill = [&](int kb, int st) {
+      unsigned char* Ad = As + st * kStage;
+      unsigned char* Bd = Bs + st * kStage;
+      const int tap = CONV3 ? kb / kpt : 0;
+      const int k0 = (kb - tap * kpt) * BK;
+      if (CONV3) {
+        if (tap != atap) set_tap(tap);
+#pragma unroll
+        for (int i = 0; i < CA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ad + (lw * CA + i) * 1024), 16, (int)aoff[i], k0 * 2, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < CA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(Ad + (lw * CA + i) * 1024), 16, (int)a1off[i], k0 * 2, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < CB; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lptr_t)(Bd + (lw * CB + i) * 1024), 16, (int)boff[i], (tap * p.K + k0) * 2, 0, 0);
+    };
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st)
+      if (st < nk) fill(st, st);
+    int wst = NST - 1;                                  // stage the next fill goes to: (kb + NST - 1) % NST
+    for (int kb = 0; kb < nk; ++kb) {
+      // fills issued so far: 0 .. min(kb + NST - 2, nk - 1); the fill of step kb has to have landed: r younger ones stay in flight
+      const int r = min(NST - 2, nk - 1 - kb);
+      if (r >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (CA + CB)) : "memory");
+      else if (r == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CA + CB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                      // barrier kb: the MFMA waves are done with step kb - 1, step kb is in LDS
+      if (kb + NST - 1 < nk) fill(kb + NST - 1, wst);
+      wst = wst + 1 == NST ? 0 : wst + 1;
+    }
+#pragma unroll
+    for (int b = 0; b < kEpilogueBarriers<OUT>; ++b) __syncthreads();
+    return;
+  }
+
+  // ================================ MFMA waves ================================
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  const int fr = lane & 31, fh = lane >> 5;
+  int rst = 0;                                          // stage of step kb: kb % NST
+  for (int kb = 0; kb < nk; ++kb) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous step's fragment reads have returned
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* Ac = As + rst * kStage;
+    const unsigned char* Bc = Bs + rst * kStage;
+    rst = rst + 1 == NST ? 0 : rst + 1;
+    bf16x8 af[2][2], bfr[2][TN];
+    auto read_slice = [&](int set, int kk) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[set][a] = *reinterpret_cast<const bf16x8*>(Ac + swzk<BK>(wm * 64 + a * 32 + fr, 2 * kk + fh));
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bfr[set][b] = *reinterpret_cast<const bf16x8*>(Bc + swzk<BK>(wn * WN + b * 32 + fr, 2 * kk + fh));
+    };
+    read_slice(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      if (kk + 1 < BK / 16) read_slice((kk + 1) & 1, kk + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            Cs[row * CP + wn * WN + b * 32 + (lane & 31)] = acc[a][b][r];
-          }
-    }
-    __syncthreads();
-    if (OUT == 2 && half == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e)   // shift = the tile's first row (rounded like the stored value): sums of small numbers
-        kshift[e] = __bfloat162float(__float2bfloat16(Cs[c8 * 8 + e]));
-    }
-#pragma unroll
-    for (int i = 0; i < RPT; ++i) {
-      const int row = r0 + RSTEP * i;
-      const int grow = m0 + half * 64 + row;
-      const bool live = grow < p.M;
-      const float4 v0 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8);
-      const float4 v1 = *reinterpret_cast<const float4*>(Cs + row * CP + c8 * 8 + 4);
-      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-      Vec<bf16> o, sv;
-      sv.raw = side[i];
-      if (OUT == 0) {
-        if (p.accumulate) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += sv.get(e);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.set(e, v[e]);
-      } else if (OUT == 1) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float z = (v[e] - em[e]) * es[e] + eb[e];
-          if (p.R) z += sv.get(e);
-          o.set(e, act_rt(z, p.out_slope));
-        }
-      } else if (OUT == 2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          o.set(e, v[e]);
-          const float d = live ? o.get(e) - kshift[e] : 0.f;
-          s1[e] += d;
-          s2[e] += d * d;
-        }
-      } else if (OUT == 3) {  // v = d a', x = the fused layer's pre-norm input
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xc = sv.get(e) - em[e];
-          const float dz = v[e] * act_grad_rt(xc * es[e] + eb[e], p.out_slope);
-          o.set(e, dz);
-          const float dzr = live ? o.get(e) : 0.f;   // the stored (rounded) value is what the apply pass will read
-          s1[e] += dzr;
-          s2[e] += dzr * (xc * ei[e]);
-        }
-      } else {  // OUT == 4: v (+ the shortcut's gradient) = d out of a residual block; sign from its output, x-hat from its z
-        Vec<bf16> yv, zv;
-        yv.raw = side_y[OUT == 4 ? i : 0];
-        zv.raw = side_z[OUT == 4 ? i : 0];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float g = v[e];
-          if (p.accumulate) g += sv.get(e);
-          const float dz = g * act_grad_rt(yv.get(e), p.out_slope);
-          o.set(e, dz);
-          const float dzr = live ? o.get(e) : 0.f;
-          s1[e] += dzr;
-          s2[e] += dzr * ((zv.get(e) - em[e]) * ei[e]);
-        }
-      }
-      if (live) o.store(p.Y + (size_t)grow * p.ldy + ncol);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kk & 1][a], bfr[kk & 1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  if (OUT >= 2) {
-    // reduce over the RSTEP threads that share a column chunk: through LDS (the output tile is consumed)
-    __syncthreads();
-    float* red = Cs;                                  // [RSTEP][2][BN]
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      red[(r0 * 2 + 0) * BN + c8 * 8 + e] = s1[e];
-      red[(r0 * 2 + 1) * BN + c8 * 8 + e] = s2[e];
-    }
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid % BN;
-      float t = 0.f;
-#pragma unroll 8
-      for (int q = 0; q < RSTEP; ++q) t += red[(q * 2 + which) * BN + col];
-      if (OUT == 2) {
-        float* dst = p.partial + (size_t)tm * 3 * p.N + n0 + col;
-        dst[(1 + which) * p.N] = t;
-      } else {
-        p.partial[(size_t)tm * 2 * p.N + which * p.N + n0 + col] = t;
-      }
-    }
-    if (OUT == 2 && r0 == 0) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) p.partial[(size_t)tm * 3 * p.N + ncol + e] = kshift[e];
-    }
-  }
+#include "conv1x1_epilogue.inc"
 }
 
 // Per-tile shifted sums (k_t, s1_t, s2_t) -> sums about the common shift K = k_0 -> the usual finalize.
@@ -746,6 +769,76 @@ int pick_wgrad_chunks(int M, int N, int K) {
   return chunks;
 }
 
+
+// Launch of the DB form with one of its three pipelines (see the kernel's header): 0 = <64, 2>, 1 = <32, 4>, 2 = <64, 4>.
+template <int BN, int OUT, bool CONV3>
+int launch_db(int pipe, int grid, hipStream_t s, const Args& a, const char* fn) {
+  constexpr size_t kOut = (size_t)64 * (BN + 4) * 4, kRed = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;
+  auto lds_of = [&](int bk, int nst) {
+    size_t l = (size_t)(kBM + BN) * bk * 2 * nst;
+    if (l < kOut) l = kOut;
+    if (l < kRed) l = kRed;
+    return l;
+  };
+  if (pipe == 4) {                  // loader waves, three 32 KB stages, one workgroup (8 waves) per CU: every epilogue fits
+    const size_t lds = lds_of(64, 3);
+    UCD_TRY_LDS((conv_lw_kernel<BN, OUT, CONV3, 64, 3>), (int)lds);
+    conv_lw_kernel<BN, OUT, CONV3, 64, 3><<<grid, 2 * kThreads, lds, s>>>(a);
+    return 0;
+  }
+  if (pipe == 3) {
+    if constexpr (OUT <= 2) {       // two workgroups per CU: the epilogues of OUT 3 / 4 need more registers than 16 waves leave
+      conv_lw_kernel<BN, OUT, CONV3, 32, 4><<<grid, 2 * kThreads, lds_of(32, 4), s>>>(a);
+      return 0;
+    }
+    pipe = 0;
+  }
+  if (pipe == 1) {
+    conv1x1_kernel<BN, false, OUT, CONV3, true, 32, 4><<<grid, kThreads, lds_of(32, 4), s>>>(a);
+  } else if (pipe == 2) {
+    const size_t lds = lds_of(64, 4);
+    UCD_TRY_LDS((conv1x1_kernel<BN, false, OUT, CONV3, true, 64, 4>), (int)lds);
+    conv1x1_kernel<BN, false, OUT, CONV3, true, 64, 4><<<grid, kThreads, lds, s>>>(a);
+  } else {
+    conv1x1_kernel<BN, false, OUT, CONV3, true, 64, 2><<<grid, kThreads, lds_of(64, 2), s>>>(a);
+  }
+  return 0;
+}
+
+template <int BN, bool CONV3>
+int launch_db_out(int out_mode, int pipe, int grid, hipStream_t s, const Args& a, const char* fn) {
+  switch (out_mode) {
+    case 0: return launch_db<BN, 0, CONV3>(pipe, grid, s, a, fn);
+    case 1: return launch_db<BN, 1, CONV3>(pipe, grid, s, a, fn);
+    case 2: return launch_db<BN, 2, CONV3>(pipe, grid, s, a, fn);
+    case 3: return launch_db<BN, 3, CONV3>(pipe, grid, s, a, fn);
+    default:
+      if constexpr (CONV3) {
+        set_error("%s: out_mode 4 belongs to the 1x1 products", fn);
+        return UCD_EINVAL;
+      } else {
+        return launch_db<BN, 4, false>(pipe, grid, s, a, fn);
+      }
+  }
+}
+
+// Pipeline of a DB launch: UCD_CONV_PIPE = 2x64 | 4x32 | 4x64 overrides (probes / A-B); else by the grid (measured:
+// tools/conv3x3_probe.py, tools/conv1x1_probe.py, profiles/r04_conv_pipe_probe.txt).
+int pick_pipe(long long workgroups, int nk64, int out_mode) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char* e = getenv("UCD_CONV_PIPE");
+    forced = !e ? -1 : !strcmp(e, "2x64") ? 0 : !strcmp(e, "4x32") ? 1 : !strcmp(e, "4x64") ? 2 : !strcmp(e, "lw32") ? 3 :
+             !strcmp(e, "lw64") ? 4 : -1;
+  }
+  if (forced >= 0) return forced;
+  (void)out_mode;
+  // grids that give a CU at most one workgroup (3 - 6 images per GPU, the multi-GPU split): the loader-wave form - 3x3 256 -> 256 at
+  // 3 images 26.8 -> 17.3 us, 512 -> 512 49 -> 30, the ASPP branches 169 -> 100, 1x1 1024 -> 256 12.2 -> 9.5 (profiles/r04_conv_pipe_probe.txt);
+  // fuller grids (410 workgroups at 24 images) measured level with the double buffer, the four-stage forms slower
+  if (workgroups <= 256 && nk64 >= 4) return 4;
+  return 0;
+}
 }  // namespace
 }  // namespace ucd
 
@@ -819,39 +912,29 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   if (pro) lds = a.param_off + (size_t)3 * d->K * sizeof(float);
   UCD_REQUIRE(lds <= 64 * 1024, UCD_EUNSUPPORTED, "%s: K = %d is too wide for the fused input transform", fn, d->K);
   hipStream_t s = (hipStream_t)stream;
-#define UCD_C1_LAUNCH(BNV, PROV, OUTV)                                          \
-  {                                                                             \
-    if (!PROV && db)                                                            \
-      conv1x1_kernel<BNV, false, OUTV, false, true><<<grid, kThreads, lds, s>>>(a);   \
-    else                                                                        \
-      conv1x1_kernel<BNV, PROV, OUTV><<<grid, kThreads, lds, s>>>(a);           \
+  const int pipe = db ? pick_pipe((long long)a.tiles_m * a.tiles_n, (conv3 ? 9 : 1) * (d->K / 64), d->out_mode) : 0;
+  if (db && !pro) {
+    int rc;
+    if (conv3) rc = BN == 128 ? launch_db_out<128, true>(d->out_mode, pipe, grid, s, a, fn) : launch_db_out<64, true>(d->out_mode, pipe, grid, s, a, fn);
+    else rc = BN == 128 ? launch_db_out<128, false>(d->out_mode, pipe, grid, s, a, fn) : launch_db_out<64, false>(d->out_mode, pipe, grid, s, a, fn);
+    if (rc) return rc;
+    return check_launch(fn);
   }
 #define UCD_C1_OUT(BNV, PROV)                                                   \
   switch (d->out_mode) {                                                        \
-    case 0: UCD_C1_LAUNCH(BNV, PROV, 0) break;                                  \
-    case 1: UCD_C1_LAUNCH(BNV, PROV, 1) break;                                  \
-    case 2: UCD_C1_LAUNCH(BNV, PROV, 2) break;                                  \
-    case 3: UCD_C1_LAUNCH(BNV, PROV, 3) break;                                  \
-    default:                                                                    \
-      if (db) conv1x1_kernel<BNV, false, 4, false, true><<<grid, kThreads, lds, s>>>(a); \
-      else conv1x1_kernel<BNV, false, 4><<<grid, kThreads, lds, s>>>(a);         \
-      break;                                                                    \
+    case 0: conv1x1_kernel<BNV, PROV, 0><<<grid, kThreads, lds, s>>>(a); break; \
+    case 1: conv1x1_kernel<BNV, PROV, 1><<<grid, kThreads, lds, s>>>(a); break; \
+    case 2: conv1x1_kernel<BNV, PROV, 2><<<grid, kThreads, lds, s>>>(a); break; \
+    case 3: conv1x1_kernel<BNV, PROV, 3><<<grid, kThreads, lds, s>>>(a); break; \
+    default: conv1x1_kernel<BNV, false, 4><<<grid, kThreads, lds, s>>>(a); break; \
   }
 #define UCD_C3_OUT(BNV)                                                                        \
   switch (d->out_mode) {                                                                       \
-    case 0: if (db) conv1x1_kernel<BNV, false, 0, true, true><<<grid, kThreads, lds, s>>>(a);  \
-            else conv1x1_kernel<BNV, false, 0, true, false><<<grid, kThreads, lds, s>>>(a);    \
-            break;                                                                             \
-    case 1: if (db) conv1x1_kernel<BNV, false, 1, true, true><<<grid, kThreads, lds, s>>>(a);  \
-            else conv1x1_kernel<BNV, false, 1, true, false><<<grid, kThreads, lds, s>>>(a);    \
-            break;                                                                             \
-    case 2: if (db) conv1x1_kernel<BNV, false, 2, true, true><<<grid, kThreads, lds, s>>>(a);  \
-            else conv1x1_kernel<BNV, false, 2, true, false><<<grid, kThreads, lds, s>>>(a);    \
-            break;                                                                             \
+    case 0: conv1x1_kernel<BNV, false, 0, true, false><<<grid, kThreads, lds, s>>>(a); break;  \
+    case 1: conv1x1_kernel<BNV, false, 1, true, false><<<grid, kThreads, lds, s>>>(a); break;  \
+    case 2: conv1x1_kernel<BNV, false, 2, true, false><<<grid, kThreads, lds, s>>>(a); break;  \
     case 4: UCD_REQUIRE(false, UCD_EINVAL, "%s: out_mode 4 belongs to the 1x1 products", fn);  \
-    default: if (db) conv1x1_kernel<BNV, false, 3, true, true><<<grid, kThreads, lds, s>>>(a); \
-             else conv1x1_kernel<BNV, false, 3, true, false><<<grid, kThreads, lds, s>>>(a);   \
-             break;                                                                            \
+    default: conv1x1_kernel<BNV, false, 3, true, false><<<grid, kThreads, lds, s>>>(a); break; \
   }
   if (conv3) {
     if (BN == 128) { UCD_C3_OUT(128) } else { UCD_C3_OUT(64) }
@@ -862,7 +945,6 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   }
 #undef UCD_C3_OUT
 #undef UCD_C1_OUT
-#undef UCD_C1_LAUNCH
   return check_launch(fn);
 }
 

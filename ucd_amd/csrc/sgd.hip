@@ -33,8 +33,8 @@ struct SgdUpdate {
   }
 };
 
-__global__ __launch_bounds__(kSgdThreads) void sgd_step_kernel(const ucd_sgd_tensor* __restrict__ table,
-                                                              const int* __restrict__ blocks, ucd_sgd_hyper hyper) {
+__device__ __forceinline__ void sgd_step_block(const ucd_sgd_tensor* __restrict__ table, const int* __restrict__ blocks,
+                                               const ucd_sgd_hyper& hyper) {
   const int t = blocks[2 * blockIdx.x], chunk = blocks[2 * blockIdx.x + 1];
   const ucd_sgd_tensor e = table[t];
   const int gi = e.group;
@@ -82,6 +82,22 @@ __global__ __launch_bounds__(kSgdThreads) void sgd_step_kernel(const ucd_sgd_ten
   }
 }
 
+
+__global__ __launch_bounds__(kSgdThreads) void sgd_step_kernel(const ucd_sgd_tensor* __restrict__ table,
+                                                              const int* __restrict__ blocks, ucd_sgd_hyper hyper) {
+  sgd_step_block(table, blocks, hyper);
+}
+
+// The same step with the hyper-parameters read from device memory: the form a captured hipGraph replays while the learning
+// rate changes every iteration (PolyLR, train.py:150-151) - a by-value kernel argument would be frozen into the graph.
+__global__ __launch_bounds__(kSgdThreads) void sgd_step_dev_kernel(const ucd_sgd_tensor* __restrict__ table,
+                                                                  const int* __restrict__ blocks,
+                                                                  const ucd_sgd_hyper* __restrict__ hyper) {
+  sgd_step_block(table, blocks, *hyper);
+}
+
+__global__ void sgd_hyper_store_kernel(ucd_sgd_hyper* dst, ucd_sgd_hyper value) { *dst = value; }
+
 }  // namespace
 }  // namespace ucd
 
@@ -100,6 +116,26 @@ int ucd_sgd_step(const ucd_sgd_tensor* table, const int* blocks, int n_blocks, c
     UCD_REQUIRE(hyper->weight_decay[gidx] >= 0.0 && hyper->momentum[gidx] >= 0.0, UCD_EINVAL,
                 "%s: group %d: negative weight decay or momentum", fn, gidx);
   sgd_step_kernel<<<(unsigned)n_blocks, kSgdThreads, 0, (hipStream_t)stream>>>(table, blocks, *hyper);
+  return check_launch(fn);
+}
+
+int ucd_sgd_hyper_store(ucd_sgd_hyper* device_hyper, const ucd_sgd_hyper* hyper, ucd_stream_t stream) {
+  static const char* fn = "ucd_sgd_hyper_store";
+  UCD_REQUIRE(device_hyper && hyper, UCD_EINVAL, "%s: device_hyper / hyper is NULL", fn);
+  for (int gidx = 0; gidx < UCD_SGD_MAX_GROUPS; ++gidx)
+    UCD_REQUIRE(hyper->weight_decay[gidx] >= 0.0 && hyper->momentum[gidx] >= 0.0, UCD_EINVAL,
+                "%s: group %d: negative weight decay or momentum", fn, gidx);
+  sgd_hyper_store_kernel<<<1, 1, 0, (hipStream_t)stream>>>(device_hyper, *hyper);      // the values travel as a kernel argument
+  return check_launch(fn);
+}
+
+int ucd_sgd_step_dev(const ucd_sgd_tensor* table, const int* blocks, int n_blocks, const ucd_sgd_hyper* device_hyper,
+                     ucd_stream_t stream) {
+  static const char* fn = "ucd_sgd_step_dev";
+  UCD_REQUIRE(n_blocks >= 0, UCD_EINVAL, "%s: n_blocks = %d", fn, n_blocks);
+  if (n_blocks == 0) return 0;
+  UCD_REQUIRE(table && blocks && device_hyper, UCD_EINVAL, "%s: table / blocks / device_hyper is NULL", fn);
+  sgd_step_dev_kernel<<<(unsigned)n_blocks, kSgdThreads, 0, (hipStream_t)stream>>>(table, blocks, device_hyper);
   return check_launch(fn);
 }
 

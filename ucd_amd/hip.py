@@ -115,6 +115,8 @@ SIGNATURES = {
     "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
     "ucd_sgd_chunk": (_i, []),
     "ucd_sgd_step": (_i, [_p, _p, _i, _p, _p]),
+    "ucd_sgd_hyper_store": (_i, [_p, _p, _p]),
+    "ucd_sgd_step_dev": (_i, [_p, _p, _i, _p, _p]),
     "ucd_pixcon_prep_workspace_bytes": (_z, [_i, _i]),
     "ucd_pixcon_prep": (_i, [_p, _i, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _z, _p]),
     "ucd_pixcon_gather": (_i, [_p, _i, _p, _i, _i, _i, _i, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p, _p, _p, _p]),

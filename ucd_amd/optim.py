@@ -65,6 +65,9 @@ class SGD(torch.optim.SGD):
         self._plan = None
         self._warned = False
         self.refreshed_working_sets = ()      # Bf16Weights whose bf16 copies THIS step's kernel wrote (ucd_amd/master.py)
+        # hyper-parameters in device memory (ucd_sgd_step_dev): what a captured hipGraph of the whole iteration replays while
+        # the scheduler keeps changing the learning rate on the host (ucd_amd/train.py: Trainer._graph_step)
+        self._hyper_dev = None
 
     # -- plan ----------------------------------------------------------------------------------------------------------
     def _signature(self):
@@ -142,6 +145,39 @@ class SGD(torch.optim.SGD):
         plan.n_blocks = int(blocks.shape[0])
         return plan
 
+    # -- hyper-parameters on the device ---------------------------------------------------------------------------------
+    def _hyper(self):
+        hyper = _SgdHyper()
+        for gi, group in enumerate(self.param_groups):
+            hyper.lr[gi] = float(group["lr"])
+            hyper.momentum[gi] = float(group["momentum"])
+            hyper.weight_decay[gi] = float(group["weight_decay"])
+            hyper.nesterov[gi] = 1 if group["nesterov"] else 0
+        return hyper
+
+    def device_hyper(self, enable=True):
+        """Switch the step to the device-resident hyper-parameter struct (a captured step graph needs it) or back."""
+        if not enable:
+            self._hyper_dev = None
+            return
+        if self._hyper_dev is None:
+            dev = next(p for g in self.param_groups for p in g["params"]).device
+            self._hyper_dev = torch.zeros(C.sizeof(_SgdHyper), dtype=torch.uint8, device=dev)
+        self.push_hyper()
+
+    def push_hyper(self):
+        """Current lr / momentum / weight decay of every group -> the device struct, in stream order (one tiny launch)."""
+        if self._hyper_dev is None:
+            return
+        hyper = self._hyper()
+        with torch.cuda.device(self._hyper_dev.device):
+            hip._check(hip.load().ucd_sgd_hyper_store(self._hyper_dev.data_ptr(), C.byref(hyper), hip.stream()), "ucd_sgd_hyper_store")
+
+    def plan_is_current(self):
+        """True when the next step() would launch the kernel without rebuilding its tables (no host-to-device copies)."""
+        plan = self._plan
+        return plan is not None and plan.signature == self._signature() and self._moms_unchanged(plan)
+
     # -- step ----------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, closure=None):
@@ -153,6 +189,11 @@ class SGD(torch.optim.SGD):
         signature = self._signature()
         plan = self._plan
         if plan is None or plan.signature != signature or not self._moms_unchanged(plan):
+            if torch.cuda.is_current_stream_capturing():
+                # building the tables copies host memory to the device: not capturable - the captured iteration must find the
+                # tensors where the eager warm-up iterations left them (Trainer._graph_step checks plan_is_current() first)
+                raise RuntimeError("ucd_amd.optim.SGD.step under graph capture: parameter / gradient / momentum tensors moved "
+                                   "since the last eager step")
             plan = self._plan = self._build_plan(signature)
         if plan is None:
             if not self._warned:
@@ -163,17 +204,20 @@ class SGD(torch.optim.SGD):
             super().step()
             return loss
         if plan.n_blocks:
-            hyper = _SgdHyper()
-            for gi, group in enumerate(self.param_groups):
-                lr = group["lr"]
-                hyper.lr[gi] = float(lr)
-                hyper.momentum[gi] = float(group["momentum"])
-                hyper.weight_decay[gi] = float(group["weight_decay"])
-                hyper.nesterov[gi] = 1 if group["nesterov"] else 0
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing and self._hyper_dev is None:
+                raise RuntimeError("ucd_amd.optim.SGD.step under graph capture needs device_hyper() first")
             with torch.cuda.device(plan.table.device):
                 with hip._timed("ucd_sgd_step", 22.0 * plan.elements):
-                    hip._check(hip.load().ucd_sgd_step(plan.table.data_ptr(), plan.blocks.data_ptr(), plan.n_blocks,
-                                                       C.byref(hyper), hip.stream()), "ucd_sgd_step")
+                    if self._hyper_dev is not None:
+                        if not capturing:
+                            self.push_hyper()       # a replayed graph gets its values from Trainer._graph_step before the launch
+                        hip._check(hip.load().ucd_sgd_step_dev(plan.table.data_ptr(), plan.blocks.data_ptr(), plan.n_blocks,
+                                                               self._hyper_dev.data_ptr(), hip.stream()), "ucd_sgd_step_dev")
+                    else:
+                        hyper = self._hyper()
+                        hip._check(hip.load().ucd_sgd_step(plan.table.data_ptr(), plan.blocks.data_ptr(), plan.n_blocks,
+                                                           C.byref(hyper), hip.stream()), "ucd_sgd_step")
             self.refreshed_working_sets = tuple(o for o in (ref() for ref in plan.owners) if o is not None)
         return loss
 

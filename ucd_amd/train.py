@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import switches as _switches
 from .contrastive import ucd_contrastive_loss
 from .loss import (KnowledgeDistillationLoss, UnbiasedCrossEntropy, UnbiasedKnowledgeDistillationLoss,
                    fused_seg_losses)
@@ -92,6 +93,20 @@ class Trainer:
             from .master import Bf16Weights
             self._teacher_w16 = Bf16Weights(model_old, trainable=False)
         self.last = {}
+        # The WHOLE iteration (teacher + student forward, losses, backward, gradient buckets, optimiser) as one hipGraph,
+        # captured after the eager warm-up iterations and replayed from then on: at the per-rank batch of the 8-GPU run
+        # (3 images) the host needs ~14 ms to enqueue ~1200 launches of ~12 ms of kernels; a replay needs none of it.
+        # UCD_STEP_GRAPH = auto (default): single-process runs only - a multi-rank capture would put the SyncBN and gradient
+        # collectives into the graph, which no box available to this build can exercise; 1 = always try; 0 = never.
+        sw = _switches.get("UCD_STEP_GRAPH", "auto")
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        self.step_graph = (device.type == "cuda" and bool(getattr(opts, "step_graph", True)) and sw != "0"
+                           and (world == 1 or sw == "1") and not self.lde_flag)
+        self.step_graph_warmup = 3          # eager iterations before the capture (solver search, GEMM tuning, optimiser tables)
+        self._sg = None
+        self._sg_seen = 0
+        self.graph_steps = 0                # iterations served by a graph replay (bench.py reports it)
+        self.step_graph_error = None
 
     # ------------------------------------------------------------------------------------------
     def _autocast(self):
@@ -105,8 +120,8 @@ class Trainer:
         """(outputs_old, features_old); replayed from a captured graph when enabled and the input shape is stable."""
         if self._teacher_w16 is not None:
             self._teacher_w16.refresh_if_stale()
-        if not self.graph_teacher or self.lde_flag:
-            return self._teacher_eager(images, up)
+        if not self.graph_teacher or self.lde_flag or torch.cuda.is_current_stream_capturing():
+            return self._teacher_eager(images, up)          # (inside a whole-step capture the teacher is part of that graph)
         tg = self._tg
         if tg is not None and tg["shape"] == tuple(images.shape) and tg["up"] == bool(up):
             tg["images"].copy_(images)
@@ -115,6 +130,8 @@ class Trainer:
         self._tg_seen += 1
         if self._tg_seen <= 2:                      # eager warm-up: MIOpen solver search, workspaces, constants
             return self._teacher_eager(images, up)
+        if self.step_graph and self._sg is None and self._sg_seen <= self.step_graph_warmup + 1:
+            return self._teacher_eager(images, up)  # the whole-step capture is about to include the teacher: no graph of its own
         try:
             from .segmentation_module import Features
             static = images.clone()
@@ -131,13 +148,76 @@ class Trainer:
         except Exception as e:                      # capture is an optimisation: never lose the step over it
             self.graph_teacher = False
             self._tg = None
+            self.teacher_graph_error = repr(e)[:200]            # bench.py prints it: a run without the graph is marked
             torch.cuda.synchronize()
             import warnings
             warnings.warn(f"teacher graph capture disabled: {e!r}")
             return self._teacher_eager(images, up)
 
+    # -- the whole iteration as one graph --------------------------------------------------------------------------------
+    def _graph_ready(self, optim):
+        """Static preconditions of a capture: the gradient-bucket wrapper (gradients live at fixed addresses) and the
+        one-launch optimiser with its tables in place (its hyper-parameters can then live on the device)."""
+        from .optim import SGD
+        return (hasattr(self.model, "finish_grad_sync") and hasattr(self.model, "zero_grad") and isinstance(optim, SGD)
+                and optim.plan_is_current())
+
+    def _graph_step(self, images, labels, optim, scheduler):
+        """Replay (or capture, then replay) the iteration; None when this call has to run eagerly."""
+        key = (tuple(images.shape), tuple(labels.shape), images.dtype, labels.dtype, id(optim), self.model.training)
+        sg = self._sg
+        if sg is not None and sg["key"] == key:
+            sg["images"].copy_(images, non_blocking=True)
+            sg["labels"].copy_(labels, non_blocking=True)
+            optim.push_hyper()
+            sg["graph"].replay()
+            if scheduler is not None:
+                scheduler.step()
+            self.graph_steps += 1
+            self.last = sg["out"]
+            return self.last
+        if sg is not None:                          # another batch shape (last batch of an epoch, validation crop): eager
+            return None
+        self._sg_seen += 1
+        if self._sg_seen <= self.step_graph_warmup or not self._graph_ready(optim):
+            return None
+        dev = self.device
+        try:
+            static_images = images.to(dev, dtype=torch.float32).contiguous(memory_format=torch.channels_last).clone(
+                memory_format=torch.preserve_format)
+            static_labels = labels.to(dev, dtype=torch.long).clone()
+            optim.device_hyper(True)
+            bw = getattr(self.model, "bf16_weights", None)
+            if bw is not None:
+                bw._flips_dirty = True              # the replayed iteration refreshes the flipped weights its optimiser step staled
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = self._eager_step(static_images, static_labels, optim, None)
+            self._sg = {"graph": graph, "images": static_images, "labels": static_labels, "out": out, "key": key}
+            self._tg = None                         # the separate teacher graph (and its memory pool) is not needed any more
+        except Exception as e:                      # capture is an optimisation: never lose the step over it
+            self.step_graph = False
+            self._sg = None
+            self.step_graph_error = repr(e)[:300]
+            optim.device_hyper(False)
+            torch.cuda.synchronize()
+            import warnings
+            warnings.warn(f"whole-step graph capture disabled: {e!r}")
+            if hasattr(self.model, "zero_grad"):
+                self.model.zero_grad()
+            return None
+        return self._graph_step(images, labels, optim, scheduler)        # nothing ran during the capture: replay it now
+
     def train_step(self, images, labels, optim, scheduler=None):
         """One iteration; returns device scalars (no host synchronisation)."""
+        if self.step_graph and self.model_old is not None and self.model.training:
+            out = self._graph_step(images, labels, optim, scheduler)
+            if out is not None:
+                return out
+        return self._eager_step(images, labels, optim, scheduler)
+
+    def _eager_step(self, images, labels, optim, scheduler=None):
         model, model_old = self.model, self.model_old
         images = images.to(self.device, dtype=torch.float32, non_blocking=True)
         labels = labels.to(self.device, dtype=torch.long, non_blocking=True)
