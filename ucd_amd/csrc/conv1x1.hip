@@ -66,6 +66,7 @@ struct Args {
   int iH, iW, dil;   // CONV3: spatial size of the [B, H, W, K] map behind A and the dilation (= padding) of the 3x3 taps
   int stride, oW, ohw;   // stride > 1 (1x1 and CONV3): output row m = (b, oy, ox) of the [B, oH, oW] map reads input pixel (oy, ox) * stride
   int a_rows;        // rows of A (= M unless strided: B * iH * iW)
+  int tiles128;      // ceil(M / 128): rows of the per-tile partial buffers
 };
 
 // The fused transforms take leaky_relu(slope) only; identity arrives as slope = 1 (elu layers keep the separate ABN
@@ -377,28 +378,36 @@ __global__ __launch_bounds__(kThreads, DB ? (BK * NST >= 256 ? 1 : 2) : ((PRO ||
 // nothing but {barrier; 16 ds_read_b128 + 16 MFMA} per K step; waves 4 - 7 only stage - they issue the fill of step kb + NST - 1
 // right after barrier kb (the stage of step kb - 1 is free then), wait with a counted vmcnt until the fill of step kb + 1 has
 // landed and join barrier kb + 1.  ONE barrier per K step, no DMA issue in an MFMA wave's instruction stream.
-template <int BN, int OUT, bool CONV3, int BK, int NST>
-__global__ __launch_bounds__(2 * kThreads, (kBM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 2) void conv_lw_kernel(Args p) {
+// BM = 256 (round 4): EIGHT MFMA waves (4 x 2 wave tiles of 64 x 64, two per SIMD) and eight loader waves on a 256 x BN workgroup
+// tile, one workgroup per CU: a quarter less staged bytes per MFMA than two 128-row workgroups, and the MFMA waves of a SIMD take
+// turns on its matrix pipe with no DMA issue between their instructions.  For the grids of 257 .. 640 128-row tiles (every 33 x 33
+// layer at 24 images).  The two 128-row halves run the shared epilogue side by side (conv1x1_epilogue.inc, 256 threads and an LDS
+// region each; the per-tile partial rows stay those of 128-row tiles).
+template <int BM, int BN, int OUT, bool CONV3, int BK, int NST>
+__global__ __launch_bounds__(BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 2) void conv_lw_kernel(Args p) {
+  static_assert(BM == 128 || BM == 256, "128- or 256-row workgroup tiles");
+  constexpr int NC = BM / 32, NL = BM / 32;             // MFMA waves (2 per 64 rows), loader waves
   static_assert(BK == 64 || BK == 32, "K steps of 64 or 32");
   static_assert(NST >= 3 && NST <= 4, "three or four stages");
-  constexpr int kStage = (kBM + BN) * BK * 2;
+  constexpr int kStage = (BM + BN) * BK * 2;
   constexpr int WN = BN / 2, TN = WN / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* As = smem;
-  unsigned char* Bs = smem + kBM * BK * 2;
+  unsigned char* Bs = smem + BM * BK * 2;
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-  const int tm = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;
-  if (tm >= p.tiles_m) return;
-  const int m0 = tm * kBM, n0 = tn * BN;
+  const int tmw = (j / p.tiles_n) * 8 + xcd, tn = j % p.tiles_n;      // workgroup tile (BM rows)
+  if (tmw >= p.tiles_m) return;
+  const int m0w = tmw * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kpt = p.K / BK;
   const int nk = CONV3 ? 9 * kpt : kpt;
 
-  if (wave >= 4) {
+  if (wave >= NC) {
     // ================================ loader waves ================================
-    const int lw = wave - 4;
+    const int lw = wave - NC;
+    const int m0 = m0w;
     constexpr int RPC = 1024 / (BK * 2), SPR = BK / 8;
-    constexpr int CA = kBM / RPC / 4, CB = BN / RPC / 4;
+    constexpr int CA = BM / RPC / NL, CB = BN / RPC / NL;
     int py[CA], px[CA], pimg[CA], pslot[CA];
     unsigned a1off[CA], boff[CB];
 #pragma unroll
@@ -477,7 +486,7 @@ __global__ __launch_bounds__(2 * kThreads, (kBM + BN) * BK * 2 * NST > 80 * 1024
   }
 
   // ================================ MFMA waves ================================
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wmw = wave >> 1, wn = wave & 1;            // wave tile: rows 64 wmw .. + 63 of the workgroup tile
   f32x16 acc[2][TN];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(2 * kThreads, (kBM + BN) * BK * 2 * NST > 80 * 1024
     bf16x8 af[2][2], bfr[2][TN];
     auto read_slice = [&](int set, int kk) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[set][a] = *reinterpret_cast<const bf16x8*>(Ac + swzk<BK>(wm * 64 + a * 32 + fr, 2 * kk + fh));
+      for (int a = 0; a < 2; ++a) af[set][a] = *reinterpret_cast<const bf16x8*>(Ac + swzk<BK>(wmw * 64 + a * 32 + fr, 2 * kk + fh));
 #pragma unroll
       for (int b = 0; b < TN; ++b) bfr[set][b] = *reinterpret_cast<const bf16x8*>(Bc + swzk<BK>(wn * WN + b * 32 + fr, 2 * kk + fh));
     };
@@ -513,7 +522,24 @@ __global__ __launch_bounds__(2 * kThreads, (kBM + BN) * BK * 2 * NST > 80 * 1024
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // epilogue: each group of four MFMA waves (one 128-row half of the workgroup tile) runs the shared 256-thread epilogue on its
+  // own LDS region; the barriers inside are workgroup-wide and the groups execute the same sequence of them
+  {
+    const int sub = wmw >> 1;
+    const int tm = tmw * (BM / 128) + sub, m0 = m0w + sub * 128, wm = wmw & 1;
+    constexpr size_t kOutBytes = ((size_t)64 * (BN + 4) * 4 + 1023) / 1024 * 1024;
+    unsigned char* smem_all = smem;
+    {
+      unsigned char* smem = smem_all + sub * kOutBytes;
+      const int tid_all = tid;
+      {
+        const int tid = tid_all & (kThreads - 1);
+#define UCD_EPI_TILE_OK (tm < p.tiles128)
 #include "conv1x1_epilogue.inc"
+#undef UCD_EPI_TILE_OK
+      }
+    }
+  }
 }
 
 // Per-tile shifted sums (k_t, s1_t, s2_t) -> sums about the common shift K = k_0 -> the usual finalize.
@@ -773,6 +799,7 @@ int pick_wgrad_chunks(int M, int N, int K) {
 // Launch of the DB form with one of its three pipelines (see the kernel's header): 0 = <64, 2>, 1 = <32, 4>, 2 = <64, 4>.
 template <int BN, int OUT, bool CONV3>
 int launch_db(int pipe, int grid, hipStream_t s, const Args& a, const char* fn) {
+  (void)fn;
   constexpr size_t kOut = (size_t)64 * (BN + 4) * 4, kRed = (size_t)(kThreads / (BN / 8)) * 2 * BN * 4;
   auto lds_of = [&](int bk, int nst) {
     size_t l = (size_t)(kBM + BN) * bk * 2 * nst;
@@ -780,15 +807,28 @@ int launch_db(int pipe, int grid, hipStream_t s, const Args& a, const char* fn) 
     if (l < kRed) l = kRed;
     return l;
   };
+  if (pipe == 5) {                  // loader waves on 256-row workgroup tiles (16 waves, one workgroup per CU): OUT 0 .. 2
+    if constexpr (OUT <= 2 && BN == 128) {
+      Args b = a;
+      b.tiles_m = ceil_div(a.M, 256);
+      const int grid256 = ceil_div(b.tiles_m, 8) * 8 * b.tiles_n;
+      size_t lds = (size_t)(256 + BN) * 64 * 2 * 3;
+      if (lds < kOut) lds = kOut;
+      UCD_TRY_LDS((conv_lw_kernel<256, BN, OUT, CONV3, 64, 3>), (int)lds);
+      conv_lw_kernel<256, BN, OUT, CONV3, 64, 3><<<grid256, 1024, lds, s>>>(b);
+      return 0;
+    }
+    pipe = 0;
+  }
   if (pipe == 4) {                  // loader waves, three 32 KB stages, one workgroup (8 waves) per CU: every epilogue fits
     const size_t lds = lds_of(64, 3);
-    UCD_TRY_LDS((conv_lw_kernel<BN, OUT, CONV3, 64, 3>), (int)lds);
-    conv_lw_kernel<BN, OUT, CONV3, 64, 3><<<grid, 2 * kThreads, lds, s>>>(a);
+    UCD_TRY_LDS((conv_lw_kernel<128, BN, OUT, CONV3, 64, 3>), (int)lds);
+    conv_lw_kernel<128, BN, OUT, CONV3, 64, 3><<<grid, 2 * kThreads, lds, s>>>(a);
     return 0;
   }
   if (pipe == 3) {
     if constexpr (OUT <= 2) {       // two workgroups per CU: the epilogues of OUT 3 / 4 need more registers than 16 waves leave
-      conv_lw_kernel<BN, OUT, CONV3, 32, 4><<<grid, 2 * kThreads, lds_of(32, 4), s>>>(a);
+      conv_lw_kernel<128, BN, OUT, CONV3, 32, 4><<<grid, 2 * kThreads, lds_of(32, 4), s>>>(a);
       return 0;
     }
     pipe = 0;
@@ -824,21 +864,25 @@ int launch_db_out(int out_mode, int pipe, int grid, hipStream_t s, const Args& a
 
 // Pipeline of a DB launch: UCD_CONV_PIPE = 2x64 | 4x32 | 4x64 overrides (probes / A-B); else by the grid (measured:
 // tools/conv3x3_probe.py, tools/conv1x1_probe.py, profiles/r04_conv_pipe_probe.txt).
-int pick_pipe(long long workgroups, int nk64, int out_mode) {
+int pick_pipe(int M, int tiles_n, int BN, int nk64, int out_mode) {
   static int forced = -2;
   if (forced == -2) {
     const char* e = getenv("UCD_CONV_PIPE");
     forced = !e ? -1 : !strcmp(e, "2x64") ? 0 : !strcmp(e, "4x32") ? 1 : !strcmp(e, "4x64") ? 2 : !strcmp(e, "lw32") ? 3 :
-             !strcmp(e, "lw64") ? 4 : -1;
+             !strcmp(e, "lw64") ? 4 : !strcmp(e, "lw256") ? 5 : -1;
   }
   if (forced >= 0) return forced;
-  (void)out_mode;
+  const long long wg128 = (long long)ceil_div(M, 128) * tiles_n, wg256 = (long long)ceil_div(M, 256) * tiles_n;
   // grids that give a CU at most one workgroup (3 - 6 images per GPU, the multi-GPU split): the loader-wave form - 3x3 256 -> 256 at
-  // 3 images 26.8 -> 17.3 us, 512 -> 512 49 -> 30, the ASPP branches 169 -> 100, 1x1 1024 -> 256 12.2 -> 9.5 (profiles/r04_conv_pipe_probe.txt);
-  // fuller grids (410 workgroups at 24 images) measured level with the double buffer, the four-stage forms slower
-  if (workgroups <= 256 && nk64 >= 4) return 4;
+  // 3 images 26.8 -> 17.3 us, 512 -> 512 49 -> 30, the ASPP branches 169 -> 100, 1x1 1024 -> 256 12.2 -> 9.5 (profiles/r04_conv_pipe_probe.txt)
+  if (wg128 <= 256 && nk64 >= 4) return 4;
+  // 257 .. 640 128-row tiles that fit the chip as 256-row tiles (N = 256 at 33 x 33 and 24 images: 410 -> 206 workgroups): the
+  // loader-wave form on 256-row tiles - 3x3 256 -> 256 + statistics 44.1 -> 38.0 us, the ASPP branches 238 -> 214, 1x1 2048 -> 256
+  // 33.4 -> 31.6; two rounds of it (512 -> 512: 412 workgroups) measured slower (139 vs 132), the four-stage forms slower as well
+  if (BN == 128 && out_mode <= 2 && wg256 <= 256 && nk64 >= 4) return 5;
   return 0;
 }
+
 }  // namespace
 }  // namespace ucd
 
@@ -892,6 +936,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   a.out_act = d->out_act & UCD_ACT_MASK; a.out_slope = a.out_act == UCD_ACT_IDENTITY ? 1.f : d->out_slope;
   a.partial = d->partial; a.accumulate = d->accumulate;
   a.iH = d->H; a.iW = d->W; a.dil = d->dilation;
+  a.tiles128 = ceil_div(d->M, 128);
   a.stride = stride; a.oW = oW > 0 ? oW : 1; a.ohw = oH * oW > 0 ? oH * oW : 1; a.a_rows = (int)a_rows;
   const int BN = d->N % 128 == 0 ? 128 : 64;
   a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
@@ -912,7 +957,7 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   if (pro) lds = a.param_off + (size_t)3 * d->K * sizeof(float);
   UCD_REQUIRE(lds <= 64 * 1024, UCD_EUNSUPPORTED, "%s: K = %d is too wide for the fused input transform", fn, d->K);
   hipStream_t s = (hipStream_t)stream;
-  const int pipe = db ? pick_pipe((long long)a.tiles_m * a.tiles_n, (conv3 ? 9 : 1) * (d->K / 64), d->out_mode) : 0;
+  const int pipe = db ? pick_pipe(d->M, a.tiles_n, BN, (conv3 ? 9 : 1) * (d->K / 64), d->out_mode) : 0;
   if (db && !pro) {
     int rc;
     if (conv3) rc = BN == 128 ? launch_db_out<128, true>(d->out_mode, pipe, grid, s, a, fn) : launch_db_out<64, true>(d->out_mode, pipe, grid, s, a, fn);
