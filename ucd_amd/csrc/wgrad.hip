@@ -311,6 +311,253 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
       }
 }
 
+// ---- 3x3 layers: one kernel ROW (three taps) per workgroup (round 4) ------------------------------------------------------------------
+// The 9-tap form above stages dZ nine times and X nine times per output tile: 32 KB of LDS-DMA per 64 MFMA instructions, and the
+// LDS-DMA path of a CU (~28 B/clk measured, profiles/r04_conv_pipe_probe.txt), not the matrix pipe, sets its time (0.19 - 0.23 of the
+// MFMA peak).  Here a workgroup owns (output tile 128 x 128, kernel row kh, row chunk) and computes the taps kw = 0, 1, 2 of that row
+// from ONE dZ tile and ONE X tile per 64-row step: tap kw pairs dZ row i with the input pixel d (kw - 1) to the right, which is row
+// i + kw d of an X tile that starts d pixels early - 64 + 2 d rows cover all three taps (32.5 KB per 192 MFMA instructions at d = 1).
+//   * rows whose pixel leaves the map vertically (y + dy outside [0, H)) or lies past the chunk depend on (m, kh) only: they are
+//     zero rows of the dZ tile (out-of-range DMA offset, zero-filled) and so vanish from all three taps;
+//   * horizontal validity depends on (m, kw): x + dx in [0, W).  Per step one wave writes, for kw = 0 and kw = 2, a mask dword per
+//     PAIR of dZ rows (0xFFFF per valid row) into LDS; a lane's MFMA operand holds 8 reduction rows = 4 such pairs, so masking the
+//     dZ fragments of a tap is 2 broadcast ds_read_b64 + 4 v_and per fragment (the centre tap reads a row of ones).
+// 6 MFMA waves = (tap kw) x (n half): a 64 x 128 tile of one tap each (2 x 4 accumulators = 128 registers, two fragment sets); 2 LOADER
+// waves that do all the staging (csrc/conv1x1.hip, loader-wave form: the issue of an LDS-DMA piece holds a wave for 60 - 185 cycles -
+// with every wave loading AND multiplying a step took 3900 cycles for 1536 of MFMA; eight MFMA + four loader waves would leave 168
+// registers per lane, which the 96 accumulators + fragments did not fit: 216 B of scratch); THREE LDS stages of 41 - 49 KB ({dZ 16 KB |
+// masks | X 96 or 128 rows}), one barrier per step, one workgroup per CU; fragment reads as in the 9-tap form (asm, counted lgkmcnt).
+constexpr int k3Threads = 512;          // 6 MFMA waves (tap x n-half) + 2 loader waves
+constexpr int k3MaskOff = 16384, k3XOff = 17408;
+constexpr int k3Stages = 3;               // two fills in flight: one workgroup per CU has nobody else to cover a fill's latency
+__host__ __device__ constexpr int k3_stage_bytes(int nx) { return k3XOff + nx * 8 * 1024; }   // {dZ 16 KB | masks 1 KB | X: 8 waves x NX KB}
+
+struct G3 { Frag y[2]; Frag x[4]; u64 m[2]; };
+// reads of 16-row group GI (immediates: 16 rows = 4096 B of a tile, 8 row pairs = 32 B of a mask row): 14 LDS reads.  (Device
+// functions, not statements of the kernel: inline asm with VGPR constraints in a __global__ template keeps the HOST pass from
+// instantiating the kernel's stub.)
+template <int GI>
+__device__ __forceinline__ void w3_read(G3& gs, const unsigned (&yaddr)[2][2], const unsigned (&xaddr)[4][2], unsigned maddr) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gs.y[a].h[0]) : "v"(yaddr[a][0]), "n"(GI * 4096));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gs.y[a].h[1]) : "v"(yaddr[a][1]), "n"(GI * 4096));
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gs.x[b].h[0]) : "v"(xaddr[b][0]), "n"(GI * 4096));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(gs.x[b].h[1]) : "v"(xaddr[b][1]), "n"(GI * 4096));
+  }
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(gs.m[0]) : "v"(maddr), "n"(GI * 32));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(gs.m[1]) : "v"(maddr), "n"(GI * 32 + 16));
+}
+// PENDING = LDS reads issued after this group's (they stay in flight: LDS returns in order); the mask words multiply into the
+// dZ operand (one AND pair per n sub-tile, shared by the four k sub-tiles)
+template <int PENDING>
+__device__ __forceinline__ void w3_mma(f32x16 (&acc)[2][4], G3& gs) {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PENDING) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { gs.y[a].h[0] &= gs.m[0]; gs.y[a].h[1] &= gs.m[1]; }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gs.y[a].v, gs.x[b].v, acc[a][b], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NX>   // X-tile LDS rows = 32 NX (96 or 128 >= 64 + 2 d); a loader wave issues 2 NX X pieces + 4 dZ pieces per step
+__global__ __launch_bounds__(k3Threads, 1) void wgrad3_kernel(WArgs p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  constexpr int kStage = k3_stage_bytes(NX);
+  constexpr int NXL = 4 * NX;                            // X pieces per loader wave and step
+  constexpr int NFILL = 8 + NXL;                         // LDS-DMA instructions of one fill, per loader wave
+  // ---- which (chunk, tile, kernel row) ----------------------------------------------------------------------------------
+  const int tiles_kg = p.tiles_k / p.ksplit;                 // k tiles of one group (few chunks: their k tiles go to several XCDs)
+  const int per_group = p.tiles_n * tiles_kg * 3;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int group = (j / per_group) * 8 + xcd;
+  if (group >= p.chunks * p.ksplit) return;
+  const int chunk = group / p.ksplit, kpart = group - chunk * p.ksplit;
+  int rest = j % per_group;
+  const int kh = rest % 3; rest /= 3;
+  const int tn = rest % p.tiles_n, tk = kpart * tiles_kg + rest / p.tiles_n;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int mb = chunk * p.rows_per_chunk, me = min(p.M, mb + p.rows_per_chunk);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int d = p.dil, dy = (kh - 1) * d;
+  const int W = p.W, H = p.H;
+  const int nsteps = (me - mb + kRows - 1) / kRows;
+
+  if (wave >= 6) {
+    // ================================ loader waves (2) ================================
+    const int lw = wave - 6;
+    const int shift0 = dy * W - d;                      // X tile row 0 = pixel m0 + shift0
+    const int XR = kRows + 2 * d;                       // rows of the X tile the three taps read
+    const auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)p.dZ, 0, (int)((size_t)p.M * p.ldz * 2), 0x00020000);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (int)((size_t)p.M * p.ldx * 2), 0x00020000);
+    constexpr int kOOB = 0x7FFFFFF0;
+    // dZ: 16 pieces of 4 rows; this wave issues 8 lw .. 8 lw + 7
+    int zrow[8], zy[8], zx[8];
+    unsigned zbase[8];
+    const int q64 = kRows / W, r64 = kRows - q64 * W;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      zrow[i] = (lw * 8 + i) * 4 + (lane >> 4);
+      const int col = n0 + swz_slot<16>(zrow[i], lane & 15) * 8;
+      zbase[i] = (unsigned)((zrow[i] * p.ldz + col) * 2);
+      const int m = mb + zrow[i];
+      const int b = fdiv(m, H * W, p.inv_hw), pix = m - b * H * W;
+      zy[i] = fdiv(pix, W, p.inv_w);
+      zx[i] = pix - zy[i] * W;
+    }
+    // X: pieces lw, lw + 2, ...: LDS row xrow, logical chunk by that row's swizzle
+    int xrow[NXL], xlane[NXL];
+#pragma unroll
+    for (int i = 0; i < NXL; ++i) {
+      xrow[i] = (lw + 2 * i) * 4 + (lane >> 4);
+      xlane[i] = (xrow[i] * p.ldx + k0 + swz_slot<16>(xrow[i], lane & 15) * 8) * 2;
+    }
+    // masks: loader 0, lanes 0 .. 31 own the row pairs (2 l, 2 l + 1) of a step; x of row 2 l, advanced by 64 rows per step
+    int mx = 0;
+    {
+      const int m = mb + 2 * (lane & 31);
+      const int b = fdiv(m, H * W, p.inv_hw), pix = m - b * H * W;
+      mx = pix - fdiv(pix, W, p.inv_w) * W;
+    }
+    auto fill = [&](int s, int st) {
+      unsigned char* stage = smem + st * kStage;
+      const int m0 = mb + s * kRows;
+      const int zs = m0 * p.ldz * 2;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int y = zy[i], x = zx[i];
+        int nx = x + r64, ny = y + q64;                   // the next step's coordinates
+        if (nx >= W) { nx -= W; ++ny; }
+        if (ny >= H) ny -= H;
+        zx[i] = nx; zy[i] = ny;
+        const bool ok = m0 + zrow[i] < me && (unsigned)(y + dy) < (unsigned)H;
+        const int off = ok ? (int)zbase[i] : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (lptr_t)(stage + (lw * 8 + i) * 1024), 16, off, zs, 0, 0);
+      }
+      // X rows: pixel m0 + shift0 + row; the scalar part never negative (the remainder rides on the lane offset)
+      const int p0 = m0 + shift0, sx = max(0, p0);
+      const int xs = sx * p.ldx * 2, xadj = (p0 - sx) * p.ldx * 2;
+#pragma unroll
+      for (int i = 0; i < NXL; ++i) {
+        // rows of the tile that no tap reads, pixels in front of the first image and past the last one: out-of-range offset (the
+        // descriptor's range check sees the lane offset only, not the scalar part)
+        const bool ok = xrow[i] < XR && (unsigned)(p0 + xrow[i]) < (unsigned)p.M;
+        const int off = ok ? xlane[i] + xadj : kOOB;   // (a named value: with the conditional written in the call the host pass of this
+                                                       // compiler silently drops the kernel's stub)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lptr_t)(stage + k3XOff + (lw + 2 * i) * 1024), 16, off, xs, 0, 0);
+      }
+      if (lw == 0) {
+        const int x0 = mx;
+        int x1 = x0 + 1;
+        if (x1 >= W) x1 -= W;
+        int nx = x0 + r64;
+        if (nx >= W) nx -= W;
+        mx = nx;
+        if (lane < 32) {
+          const unsigned m_l = (x0 >= d ? 0x0000FFFFu : 0u) | (x1 >= d ? 0xFFFF0000u : 0u);            // kw = 0: x - d >= 0
+          const unsigned m_r = (x0 < W - d ? 0x0000FFFFu : 0u) | (x1 < W - d ? 0xFFFF0000u : 0u);      // kw = 2: x + d < W
+          unsigned* mt = reinterpret_cast<unsigned*>(stage + k3MaskOff);
+          mt[lane] = m_l;
+          mt[32 + lane] = 0xFFFFFFFFu;                 // the centre tap reads a row of ones: one code path for the three taps
+          mt[64 + lane] = m_r;
+        }
+      }
+    };
+    fill(0, 0);
+    if (nsteps > 1) fill(1, 1);
+    int fst = 2;                                         // stage of the next fill: (s + 2) % 3
+    for (int s = 0; s < nsteps; ++s) {
+      // fills issued so far: 0 .. min(s + 1, nsteps - 1); step s's has landed when at most that younger one is in flight
+      if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NFILL) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the mask words this wave wrote
+      __builtin_amdgcn_s_barrier();                      // barrier s: the MFMA waves are done with step s - 1; step s is in LDS
+      if (s + 2 < nsteps) {
+        fill(s + 2, fst);
+        fst = fst + 1 == k3Stages ? 0 : fst + 1;
+      }
+    }
+    return;
+  }
+
+  // ================================ MFMA waves (6) ================================
+  // wave = 3 wn + t: tap kw = t of the kernel row, n half wn: a 64 (n) x 128 (k) tile of ONE tap = 2 x 4 accumulators (128 registers);
+  // per 16-row group 2 dZ fragments (masked with the tap's row masks) and 4 X fragments from the tile rows shifted by t d
+  const int t = wave % 3, wn = wave / 3;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  // ---- fragment addresses (stage 0; advanced by one stage per step, cyclically) ------------------------------------------------------
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int h = lane >> 5, g = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  unsigned yaddr[2][2], xaddr[4][2], maddr;
+#pragma unroll
+  for (int hi = 0; hi < 2; ++hi) {
+    const int row = 4 * h + q + 8 * hi;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int c = (wn * 64 + a * 32 + 16 * g) / 8 + (pp >> 1);
+      yaddr[a][hi] = lds0 + row * 256 + swz_slot<16>(row, c) * 16 + 8 * (pp & 1);
+    }
+    const int r = row + t * d;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int c = (b * 32 + 16 * g) / 8 + (pp >> 1);
+      xaddr[b][hi] = lds0 + k3XOff + r * 256 + swz_slot<16>(r, c) * 16 + 8 * (pp & 1);
+    }
+  }
+  maddr = lds0 + k3MaskOff + t * 128 + 8 * h;          // mask row of tap t; pairs 2 h, 2 h + 1 (rows 4 h .. 4 h + 3) of a 16-row group
+
+  int rst = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (all reads of the previous step were consumed by its last group)
+    __builtin_amdgcn_s_barrier();                      // barrier s
+    G3 ga, gb;
+    w3_read<0>(ga, yaddr, xaddr, maddr);
+    w3_read<1>(gb, yaddr, xaddr, maddr);
+    w3_mma<14>(acc, ga);
+    w3_read<2>(ga, yaddr, xaddr, maddr);
+    w3_mma<14>(acc, gb);
+    w3_read<3>(gb, yaddr, xaddr, maddr);
+    w3_mma<14>(acc, ga);
+    w3_mma<0>(acc, gb);
+    // the next stage (cyclic)
+    rst = rst + 1 == k3Stages ? 0 : rst + 1;
+    const unsigned adv = rst == 0 ? (unsigned)(-(k3Stages - 1) * kStage) : (unsigned)kStage;
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) yaddr[a][hi] += adv;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xaddr[b][hi] += adv;
+    }
+    maddr += adv;
+  }
+
+  // ---- fp32 slab of this (chunk, tile, tap): lanes 0..31 of a register write 32 consecutive k (128 bytes) -----------------------------
+  const size_t ldp = (size_t)9 * p.K;
+  float* dst = p.partial + ((size_t)chunk * p.N + n0) * ldp + (size_t)(kh * 3 + t) * p.K + k0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = wn * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        dst[(size_t)n * ldp + b * 32 + (lane & 31)] = acc[a][b][r];
+      }
+}
+
 // dW (bf16) and / or dW32 (fp32, += when accumulate) = sum over the chunks' slabs in a fixed order.  A thread owns 8
 // consecutive outputs of one chunk lane; CL lanes (1, 4 or 16: small outputs cut into many chunks - 64 x 256 weights over 250
 // chunks would otherwise be eight workgroups walking 250 slabs one after the other) take chunks c = lane, lane + CL, ... and are
@@ -408,6 +655,38 @@ int wgrad_target(int taps, int per_chunk) {
   return per_chunk <= 9 && taps == 9 ? 512 : 1024;
 }
 
+// three-tap form: one workgroup (8 waves) per CU; UCD_WGRAD3_TARGET overrides (probes), UCD_WGRAD3=0 keeps the 9-tap form (A/B)
+struct Plan3 { int tiles_n, tiles_k, chunks, rows, ksplit; };
+Plan3 make_plan3(int M, int N, int K) {
+  Plan3 pl;
+  pl.tiles_n = N / 128; pl.tiles_k = K / 128;
+  const char* e = getenv("UCD_WGRAD3_TARGET");
+  const int target = e && atoi(e) > 0 ? atoi(e) : 256;
+  const int per_chunk = pl.tiles_n * pl.tiles_k * 3;
+  int chunks = target / per_chunk;
+  const int max_chunks = (M + 255) / 256;
+  if (chunks > max_chunks) chunks = max_chunks;
+  pl.ksplit = 1;
+  if (chunks >= 8) {
+    chunks = chunks / 8 * 8;
+  } else {                                                         // few chunks: their k tiles spread over the XCDs
+    if (chunks < 1) chunks = 1;
+    while (chunks & (chunks - 1)) --chunks;                        // 1, 2, 4
+    int ks = 8 / chunks;
+    while (ks > 1 && pl.tiles_k % ks) ks >>= 1;
+    pl.ksplit = ks;
+  }
+  int rows = ceil_div(M, chunks);
+  rows = ceil_div(rows, kRows) * kRows;
+  pl.rows = rows;
+  pl.chunks = ceil_div(M, rows);
+  return pl;
+}
+bool wgrad3_enabled() {
+  const char* e = getenv("UCD_WGRAD3");
+  return !(e && e[0] == '0');
+}
+
 int plan_target(int N, int K, int taps) {
   const int per_chunk = (N / (N % 128 == 0 ? 128 : 64)) * (K / (K % 128 == 0 ? 128 : 64)) * taps;
   return wgrad_target(taps, per_chunk);
@@ -423,7 +702,12 @@ extern "C" {
 size_t ucd_conv_wgrad_workspace_bytes(int M, int N, int K, int taps) {
   if (M <= 0 || N <= 0 || K <= 0 || N % 64 || K % 64 || (taps != 1 && taps != 9)) return 0;
   const Plan pl = make_plan(M, N, K, taps, plan_target(N, K, taps));
-  return (size_t)pl.chunks * N * taps * K * sizeof(float);
+  int chunks = pl.chunks;
+  if (taps == 9 && N % 128 == 0 && K % 128 == 0) {     // the three-tap form may cut the rows differently
+    const Plan3 p3 = make_plan3(M, N, K);
+    if (p3.chunks > chunks) chunks = p3.chunks;
+  }
+  return (size_t)chunks * N * taps * K * sizeof(float);
 }
 
 int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
@@ -451,8 +735,17 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
   UCD_REQUIRE(aligned16(dz) && aligned16(x) && (!dw || aligned16(dw)) && (!dw32 || aligned16(dw32)) && ld_dz % 8 == 0 && ld_x % 8 == 0 &&
                   ld_dz >= N && ld_x >= K,
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
-  const Plan pl = make_plan(M, N, K, taps, plan_target(N, K, taps));
+  Plan pl = make_plan(M, N, K, taps, plan_target(N, K, taps));
   const size_t total = (size_t)N * taps * K;
+  // the three-tap form (wgrad3_kernel): 3x3, stride 1, 128-aligned channels, an X tile of 64 + 2 d rows in 128 LDS rows, maps on
+  // which a 64-row step wraps at most one image row at a time
+  const bool three = taps == 9 && !str && N % 128 == 0 && K % 128 == 0 && dilation <= 18 && dilation < W && kRows / W + 1 <= H &&
+                     M >= 8192 && wgrad3_enabled();      // (small maps, 3 images per GPU: level with the 9-tap form or behind it)
+  Plan3 p3{0, 0, 0, 0, 1};
+  if (three) {
+    p3 = make_plan3(M, N, K);
+    pl.chunks = p3.chunks;
+  }
   UCD_REQUIRE(workspace_bytes >= (size_t)pl.chunks * total * sizeof(float), UCD_EWORKSPACE, "%s: workspace too small", fn);
   WArgs a;
   a.dZ = (const bf16*)dz; a.ldz = ld_dz; a.X = (const bf16*)x; a.ldx = ld_x;
@@ -477,7 +770,17 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
       wgrad_kernel<BN_, BK_, false><<<grid, kThreads, lds, s>>>(a);                         \
     }                                                                                       \
   }
-  if (str) {
+  if (three) {
+    a.chunks = p3.chunks; a.rows_per_chunk = p3.rows; a.tiles_n = p3.tiles_n; a.tiles_k = p3.tiles_k; a.ksplit = p3.ksplit;
+    const int grid3 = ceil_div(p3.chunks * p3.ksplit, 8) * 8 * p3.tiles_n * (p3.tiles_k / p3.ksplit) * 3;
+    if (kRows + 2 * dilation <= 96) {
+      UCD_TRY_LDS((wgrad3_kernel<3>), k3Stages * k3_stage_bytes(3));
+      wgrad3_kernel<3><<<grid3, k3Threads, k3Stages * k3_stage_bytes(3), s>>>(a);
+    } else {
+      UCD_TRY_LDS((wgrad3_kernel<4>), k3Stages * k3_stage_bytes(4));
+      wgrad3_kernel<4><<<grid3, k3Threads, k3Stages * k3_stage_bytes(4), s>>>(a);
+    }
+  } else if (str) {
     if (taps == 9) {
       UCD_TRY_LDS((wgrad_kernel<128, 128, true, true>), (int)lds);
       wgrad_kernel<128, 128, true, true><<<grid, kThreads, lds, s>>>(a);
