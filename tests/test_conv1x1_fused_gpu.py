@@ -820,6 +820,35 @@ def test_conv_wgrad_exact_on_integers_and_against_fp32(M, N, K, sp):
     assert _rel(acc - base, ref) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,sp", [(26136, 256, 256, (33, 33, 1)), (26136, 512, 512, (33, 33, 2)), (26136, 256, 2048, (33, 33, 12)),
+                                      (26136 - 33, 128, 128, (33, 33, 18)), (24 * 65 * 65, 128, 128, (65, 65, 1))])
+def test_three_tap_and_nine_tap_weight_gradients_agree(M, N, K, sp, monkeypatch):
+    """The 3x3 weight gradient has two kernels since round 4: one kernel ROW per workgroup (wgrad3_kernel: shared dZ tile, X tile of
+    64 + 2 d rows, row-pair masks for the horizontal border, loader waves) and the 9-tap form it replaced (UCD_WGRAD3=0, kept for
+    small maps and as the A/B reference).  On sparse small integers both are exact, so they agree bit for bit - in every tap, at
+    the image borders (masks), at the chunk ends and for the dilations of the network (1, 2, 12, 18)."""
+    from ucd_amd import hip
+    g = torch.Generator(DEV).manual_seed(M + N + K + sp[2])
+    dens = min(0.5, (24.0 / M) ** 0.5)
+    zi = (torch.randint(-2, 3, (M, N), device=DEV, generator=g) * (torch.rand(M, N, device=DEV, generator=g) < dens)).bfloat16()
+    xi = (torch.randint(-1, 2, (M, K), device=DEV, generator=g) * (torch.rand(M, K, device=DEV, generator=g) < dens)).bfloat16()
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UCD_WGRAD3", mode)
+        dw32 = torch.full((N, 9 * K), float("nan"), device=DEV)
+        hip.conv_wgrad(zi, xi, None, conv3=sp, dw32=dw32)
+        out[mode] = dw32
+    exact = _wgrad_ref(zi, xi, sp)
+    assert torch.equal(out["1"], exact) and torch.equal(out["0"], exact)
+    z = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    x = (torch.randn(M, K, device=DEV, generator=g) * 1.3 + 0.2).bfloat16()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("UCD_WGRAD3", mode)
+        res[mode] = hip.conv_wgrad(z, x, None, conv3=sp, dw32=torch.empty(N, 9 * K, device=DEV)).clone()
+    assert _rel(res["1"], res["0"].float()) < 1e-5          # fp32 sums of the same products in another order
+
+
 # ---- the strided layers (first block of a stage: conv2 3x3 stride 2, proj_conv 1x1 stride 2; modules/residual.py:57-82) -------
 STRIDED_CASES = [
     # B, H, W, K (in), N (out), taps, dilation

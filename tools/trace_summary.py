@@ -10,7 +10,7 @@ t0, t1 = int(win[0]["Start_Timestamp"]), int(win[-1]["End_Timestamp"])
 def short(n):
     if "ucd" in n and ("N_1" in n or "ucd::" in n):
         m = re.search(r"(pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|plane_sum_kernel|prep_\w+kernel|"
-                      r"gather_normalize_kernel|scatter_grad_kernel|seg_losses\w*kernel|attmap\w+|conv1x1_kernel<[^>]*>|conv1x1_wgrad_kernel|"
+                      r"gather_normalize_kernel|scatter_grad_kernel|seg_losses\w*kernel|attmap\w+|conv1x1_kernel<[^>]*>|conv_lw_kernel<[^>]*>|wgrad3_kernel<[^>]*>|wgrad_kernel<[^>]*>|wgrad_sum_kernel<[^>]*>|sgd_step_dev_kernel|conv1x1_wgrad_kernel|"
                       r"tile_stats_reduce_kernel|window_\w+kernel|flip_weights_kernel|transpose_bf16_kernel|wgrad_reduce_kernel|sgd_step_kernel)", n)
         t = "<bf16>" if "bfloat16" in n else ("<f32>" if "<float" in n or "IfE" in n else "")
         return "UCD   " + (m.group(1) if m else n[:60]) + t

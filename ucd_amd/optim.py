@@ -35,6 +35,11 @@ class _SgdHyper(C.Structure):
                 ("weight_decay", C.c_double * MAX_GROUPS), ("nesterov", C.c_int * MAX_GROUPS)]
 
 
+def _capturing():
+    """Is the current stream being captured into a hipGraph?  (False on a host without a GPU, where asking raises.)"""
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def _dense(t):
     return t.is_contiguous() or (t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last))
 
@@ -189,7 +194,7 @@ class SGD(torch.optim.SGD):
         signature = self._signature()
         plan = self._plan
         if plan is None or plan.signature != signature or not self._moms_unchanged(plan):
-            if torch.cuda.is_current_stream_capturing():
+            if _capturing():
                 # building the tables copies host memory to the device: not capturable - the captured iteration must find the
                 # tensors where the eager warm-up iterations left them (Trainer._graph_step checks plan_is_current() first)
                 raise RuntimeError("ucd_amd.optim.SGD.step under graph capture: parameter / gradient / momentum tensors moved "
@@ -204,7 +209,7 @@ class SGD(torch.optim.SGD):
             super().step()
             return loss
         if plan.n_blocks:
-            capturing = torch.cuda.is_current_stream_capturing()
+            capturing = _capturing()
             if capturing and self._hyper_dev is None:
                 raise RuntimeError("ucd_amd.optim.SGD.step under graph capture needs device_hyper() first")
             with torch.cuda.device(plan.table.device):
