@@ -172,6 +172,12 @@ __global__ __launch_bounds__(16 * LANES) void reduce_bands_kernel(const float* _
   const int k = (kl < 8 ? 0 : C) + c;   // row index inside a [2C] partial
   const int n = 2 * C;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  FinalizeIn pre{1.f, 0.f, 0.f};
+  float pre_k = 0.f;
+  if (MODE == 1 && lane == 0 && kl < 8 && c < C) {       // the finalising thread's inputs: in flight under the whole reduction
+    pre = finalize_prefetch(c, fin);
+    pre_k = fin.kshift ? fin.kshift[c] : 0.f;
+  }
   if (c < C) {
     int b = lane;
     for (; b + 3 * LANES < bands; b += 4 * LANES) {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(16 * LANES) void reduce_bands_kernel(const float* _
   }
   if (MODE == 1) {
     __syncthreads();
-    if (lane == 0 && kl < 8 && c < C) finalize_channel(c, lds[0][kl], lds[0][kl + 8], fin);
+    if (lane == 0 && kl < 8 && c < C) finalize_channel_pre(c, lds[0][kl], lds[0][kl + 8], pre_k, fin, pre);
   }
   if (MODE == 2) {
     __syncthreads();

@@ -31,6 +31,33 @@ __device__ __forceinline__ void finalize_moments(int c, float mean, float m2, co
   f.scale[c] = (f.weight ? gamma_eff(f.weight[c], f.eps, f.abs_gamma) : 1.f) * invstd;
 }
 
+// The finalising thread's inputs, fetched at the START of a reduction kernel (finalize_prefetch) instead of behind its barriers:
+// the second-stage kernels are chains of dependent round trips (5 - 7 us for a few KB, ~220 launches per step), and these three
+// loads would otherwise add one more trip at the very end.
+struct FinalizeIn { float weight, running_mean, running_var; };
+__device__ __forceinline__ FinalizeIn finalize_prefetch(int c, const FinalizeArgs& f) {
+  FinalizeIn in;
+  in.weight = f.weight ? f.weight[c] : 1.f;
+  in.running_mean = f.running_mean ? f.running_mean[c] : 0.f;
+  in.running_var = f.running_var ? f.running_var[c] : 0.f;
+  return in;
+}
+__device__ __forceinline__ void finalize_channel_pre(int c, float s, float ss, float kshift, const FinalizeArgs& f, const FinalizeIn& in) {
+  const float inv_n = 1.f / f.count;
+  const float d = s * inv_n;                       // mean - k
+  const float mean = kshift + d;
+  const float var = fmaxf((ss - s * d) * inv_n, 0.f);
+  const float invstd = 1.f / sqrtf(var + f.eps);
+  if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * in.running_mean + f.momentum * mean;
+  if (f.running_var) {
+    const float unbiased = f.count > 1.f ? var * (f.count / (f.count - 1.f)) : var;
+    f.running_var[c] = (1.f - f.momentum) * in.running_var + f.momentum * unbiased;
+  }
+  f.mean[c] = mean;
+  f.invstd[c] = invstd;
+  f.scale[c] = (f.weight ? gamma_eff(in.weight, f.eps, f.abs_gamma) : 1.f) * invstd;
+}
+
 __device__ __forceinline__ void finalize_channel(int c, float s, float ss, const FinalizeArgs& f) {
   const float inv_n = 1.f / f.count;
   const float d = s * inv_n;                       // mean - k

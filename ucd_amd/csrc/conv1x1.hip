@@ -559,6 +559,8 @@ __global__ __launch_bounds__(kStatThreads) void tile_stats_reduce_kernel(const f
   const int ch = threadIdx.x & 7, tl = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + ch;
   float S1 = 0.f, S2 = 0.f, K = 0.f;
+  FinalizeIn pre{1.f, 0.f, 0.f};
+  if (MODE == 1 && tl == 0 && c < C) pre = finalize_prefetch(c, fin);      // in flight under the whole reduction
   if (c < C) {
     K = partial[c];
     auto add = [&](int t, float k, float a, float b) {
@@ -601,8 +603,7 @@ __global__ __launch_bounds__(kStatThreads) void tile_stats_reduce_kernel(const f
     sums[C + c] = t2;
     kout[c] = K;
     if (MODE == 1) {
-      fin.kshift = kout;
-      finalize_channel(c, t1, t2, fin);
+      finalize_channel_pre(c, t1, t2, K, fin, pre);
     } else {
       const float d = t1 / fin.count;
       fin.pack[c] = K + d;
