@@ -577,7 +577,11 @@ def test_twenty_step_trajectory_fp32_and_bf16_against_the_reference():
         cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
         ratio = float(b.norm() / (a.norm() + 1e-300))
         print(f"update over {steps} steps, bf16 vs fp32: {n}: cosine {cos:.4f} length ratio {ratio:.3f}")
-        assert cos > 0.9 and 0.8 < ratio < 1.25, (n, cos, ratio)
+        # measured on MI355X (three runs, two kernel generations): body layers 0.90 - 0.94 (the rounding chaos of the random-weight
+        # body, see BF16_TRAIN_LOGITS_L2 - a sign or scale error of a gradient kernel would give <= 0 or a ratio far from 1), head and
+        # classifier 0.993 - 0.995; lengths within 7 %
+        floor = 0.85 if n.startswith("body.") else 0.98
+        assert cos > floor and 0.85 < ratio < 1.18, (n, cos, ratio)
 
 
 def _scheduled_steps(step_graph, steps=8, batch=3, crop=257):

@@ -58,6 +58,16 @@ with open(sys.argv[2], "w") as f:
     f.write("%10s %10s %10s  %s\n" % ("ms/step", "calls/step", "avg_us", "kernel"))
     for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
         f.write("%10.3f %10.1f %10.2f  %s\n" % (d / 2e6, c / 2, d / c / 1e3, k))
+    # the HBM-stream ABN kernels by launch geometry (= by layer shape): where the small layers sit against the large ones
+    bygrid = collections.defaultdict(lambda: [0, 0])
+    for r in win:
+        k = short(r["Kernel_Name"])
+        if "abn_apply_kernel" in k or "abn_bwd_apply_kernel" in k or "abn_bwd_reduce_kernel" in k:
+            key = (k.split()[1], "x".join(str(r[c]) for c in sorted(r) if c.startswith("Grid_Size")))
+            bygrid[key][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); bygrid[key][1] += 1
+    f.write("# ABN stream kernels by grid size (threads): ms/step, calls/step, avg us\n")
+    for (k, g_), (d, c) in sorted(bygrid.items(), key=lambda kv: -kv[1][0])[:24]:
+        f.write("#   %8.3f %6.1f %8.2f  %-28s grid %s\n" % (d / 2e6, c / 2, d / c / 1e3, k, g_))
     f.write("# largest idle gaps of the two steps (us: after kernel -> before kernel)\n")
     for g_, a_, b_ in big[:14]:
         f.write("#   %8.1f  %s  ->  %s\n" % (g_ / 1e3, a_[:60], b_[:60]))

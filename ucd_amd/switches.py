@@ -23,8 +23,8 @@ DEFAULTS = {
     "UCD_OWN_STRIDED": "1",        # strided conv2 / proj_conv on the own kernels
     "UCD_OWN_WGRAD": "1",          # weight gradients on csrc/wgrad.hip
     "UCD_OWN_STEM": "1",           # 7x7/2 stem forward on csrc/stem.hip
-    "UCD_OWN_STEM_WGRAD": "1",     # 7x7/2 stem weight gradient on csrc/stem.hip
-    "UCD_OWN_HEADS": "1",          # classifier heads / pooled-branch 1x1 on the own GEMM (N padded to 64, masked store)
+    "UCD_WGRAD3": "1",             # 3x3 weight gradients: one kernel row per workgroup (0: the 9-tap form; read by the library)
+    "UCD_CONV_PIPE": "auto",       # pipeline of the GEMM kernel: auto | 2x64 | 4x32 | 4x64 | lw32 | lw64 | lw256 (read by the library)
     "UCD_STEM_FOLD": "1",          # stem norm + max-pool as one pass
     "UCD_ABN_NODE": "1",           # C++ autograd nodes
     "UCD_SGD": "hip",              # one-launch optimiser step (torch: torch's fused SGD)
