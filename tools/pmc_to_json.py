@@ -9,11 +9,17 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(pixcon16p_\w+kernel|pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|window_\w+kernel|tile_stats_reduce_kernel|wgrad_kernel|wgrad_sum_kernel|stem_\w+kernel|sgd_step_kernel)", r["Kernel_Name"])
+        m = re.search(r"(pixcon16p_\w+kernel|pixcon16_\w+kernel|pixcon_\w+kernel|abn_\w+kernel|reduce_bands_kernel|seg_losses\w*kernel|conv1x1_kernel|conv_lw_kernel|window_\w+kernel|tile_stats_reduce_kernel|wgrad3_kernel|wgrad_kernel|wgrad_sum_kernel|stem_\w+kernel|sgd_step_dev_kernel|sgd_step_kernel)", r["Kernel_Name"])
         if m:
             k = m.group(1)
             if k == "conv1x1_kernel" and re.search(r"conv1x1_kernel<\d+, \w+, \d+, true", r["Kernel_Name"]):
                 k = "conv3x3_kernel"          # the CONV3 instances of the same template: the 3x3 implicit GEMM
+            if k == "conv_lw_kernel":         # the loader-wave forms (round 4) of the same products: <BM, BN, OUT, CONV3, BK, NST>
+                k = "conv3x3_kernel" if re.search(r"conv_lw_kernel<\d+, \d+, \d+, true", r["Kernel_Name"]) else "conv1x1_kernel"
+            if k == "wgrad3_kernel":          # the three-tap form of the 3x3 weight gradient (round 4)
+                k = "wgrad3x3_kernel"
+            if k == "sgd_step_dev_kernel":
+                k = "sgd_step_kernel"
             if k == "wgrad_kernel":
                 k = "wgrad3x3_kernel" if re.search(r"wgrad_kernel<\d+, \d+, true", r["Kernel_Name"]) else "wgrad1x1_kernel"
             agg[k].append(float(r["Counter_Value"]))

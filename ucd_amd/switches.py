@@ -29,6 +29,7 @@ DEFAULTS = {
     "UCD_ABN_NODE": "1",           # C++ autograd nodes
     "UCD_SGD": "hip",              # one-launch optimiser step (torch: torch's fused SGD)
     "UCD_STEP_GRAPH": "auto",      # whole-step hipGraph: auto = world 1 only, 1 = always try, 0 = never
+    "UCD_TEACHER_OVERLAP": "1",    # frozen teacher on a side stream beside the student's forward (0: in front of it, same stream)
     "UCD_DIRECT_RCCL": "1",        # library-owned RCCL communicator for SyncBN
 }
 

@@ -75,7 +75,8 @@ class Trainer:
         self._tg_seen = 0
         # the teacher has no dependence on the student before the losses: it runs on a side stream next to the student's
         # forward, filling the gaps that the small 33x33 layers of either network leave on the GPU
-        self.overlap_teacher = bool(getattr(opts, "overlap_teacher", True)) and device.type == "cuda" and model_old is not None
+        self.overlap_teacher = (bool(getattr(opts, "overlap_teacher", True)) and device.type == "cuda" and model_old is not None
+                                and _switches.get("UCD_TEACHER_OVERLAP", "1") != "0")
         self._side = torch.cuda.Stream(device) if self.overlap_teacher else None
         self.ret_intermediate = self.lde
         self.unce = bool(opts.unce and self.old_classes != 0)
