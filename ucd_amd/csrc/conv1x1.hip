@@ -388,7 +388,7 @@ __global__ __launch_bounds__(BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 
   static_assert(BM == 128 || BM == 256, "128- or 256-row workgroup tiles");
   constexpr int NC = BM / 32, NL = BM / 32;             // MFMA waves (2 per 64 rows), loader waves
   static_assert(BK == 64 || BK == 32, "K steps of 64 or 32");
-  static_assert(NST >= 3 && NST <= 4, "three or four stages");
+  static_assert(NST >= 2 && NST <= 4, "two to four stages");
   constexpr int kStage = (BM + BN) * BK * 2;
   constexpr int WN = BN / 2, TN = WN / 32;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -821,6 +821,13 @@ int launch_db(int pipe, int grid, hipStream_t s, const Args& a, const char* fn) 
     }
     pipe = 0;
   }
+  if (pipe == 6) {                  // loader waves, TWO 32 KB stages, two workgroups (16 waves) per CU: OUT 0 .. 2 (128 registers)
+    if constexpr (OUT <= 2) {
+      conv_lw_kernel<128, BN, OUT, CONV3, 64, 2><<<grid, 2 * kThreads, lds_of(64, 2), s>>>(a);
+      return 0;
+    }
+    pipe = 0;
+  }
   if (pipe == 4) {                  // loader waves, three 32 KB stages, one workgroup (8 waves) per CU: every epilogue fits
     const size_t lds = lds_of(64, 3);
     UCD_TRY_LDS((conv_lw_kernel<128, BN, OUT, CONV3, 64, 3>), (int)lds);
@@ -870,7 +877,7 @@ int pick_pipe(int M, int tiles_n, int BN, int nk64, int out_mode) {
   if (forced == -2) {
     const char* e = getenv("UCD_CONV_PIPE");
     forced = !e ? -1 : !strcmp(e, "2x64") ? 0 : !strcmp(e, "4x32") ? 1 : !strcmp(e, "4x64") ? 2 : !strcmp(e, "lw32") ? 3 :
-             !strcmp(e, "lw64") ? 4 : !strcmp(e, "lw256") ? 5 : -1;
+             !strcmp(e, "lw64") ? 4 : !strcmp(e, "lw256") ? 5 : !strcmp(e, "lw64x2") ? 6 : -1;
   }
   if (forced >= 0) return forced;
   const long long wg128 = (long long)ceil_div(M, 128) * tiles_n, wg256 = (long long)ceil_div(M, 256) * tiles_n;
