@@ -584,7 +584,7 @@ def test_twenty_step_trajectory_fp32_and_bf16_against_the_reference():
         assert cos > floor and 0.85 < ratio < 1.18, (n, cos, ratio)
 
 
-def _scheduled_steps(step_graph, steps=8, batch=3, crop=257):
+def _scheduled_steps(step_graph, steps=8, batch=3, crop=257, reload_at=None):
     """``steps`` iterations of the benchmarked mode with PolyLR stepping every iteration (train.py:150-151), with or without the
     whole-step graph; returns losses per step, a few parameters afterwards and the number of replayed iterations."""
     from ucd_amd import switches
@@ -614,6 +614,8 @@ def _scheduled_steps(step_graph, steps=8, batch=3, crop=257):
             img = synth.images(700 + it % 2, batch, crop)             # two alternating batches: the static inputs must be refreshed
             labels = synth.seg_labels(700 + it % 2, batch, crop, crop, range(16, 21))
             lrs.append(optim.param_groups[0]["lr"])
+            if it == reload_at:                                      # what resuming from a checkpoint does to a live optimiser
+                optim.load_state_dict(optim.state_dict())
             r = trainer.train_step(img, labels, optim, sched)
             rec.append([r[k].item() for k in ("ce", "con", "lkd", "loss")])
         torch.cuda.synchronize()
@@ -645,3 +647,18 @@ def test_whole_step_graph_replays_the_eager_iteration():
     # and the update itself took the schedule: against a run whose optimiser never saw the decay the weights differ visibly
     first = eager[0]
     assert np.all(np.isfinite(graph)) and graph[-1][3] < first[3]
+
+
+def test_step_graph_is_dropped_and_rebuilt_when_the_optimiser_state_moves():
+    """``optim.load_state_dict`` (resume) replaces the momentum buffers: the captured optimiser launch would update the OLD ones.
+    The trainer notices (``SGD.plan_is_current``), drops the graph, runs eagerly and captures again after its warm-up count - the
+    run equals the eager run with the same reload."""
+    eager, pe, n_e, _, _ = _scheduled_steps("0", steps=12, reload_at=6)
+    graph, pg, n_g, _, err = _scheduled_steps("1", steps=12, reload_at=6)
+    assert err is None, err
+    # replays: steps 3, 4, 5 (captured at step 3), eager again from the reload at step 6 for the warm-up count, replays from step 9
+    assert n_e == 0 and n_g == 3 + 3, (n_e, n_g)
+    np.testing.assert_allclose(graph, eager, rtol=2e-3)
+    for n in pe:
+        d = ((pe[n] - pg[n]).norm() / pe[n].norm()).item()
+        assert d < 1e-4, (n, d)

@@ -167,6 +167,11 @@ class Trainer:
         """Replay (or capture, then replay) the iteration; None when this call has to run eagerly."""
         key = (tuple(images.shape), tuple(labels.shape), images.dtype, labels.dtype, id(optim), self.model.training)
         sg = self._sg
+        if sg is not None and sg["key"] == key and not optim.plan_is_current():
+            # parameters / gradients / momentum buffers moved (load_state_dict, add_param_group, a re-wrapped model): the captured
+            # optimiser launch holds the old addresses - drop the graph, run eagerly, capture again after the warm-up count
+            self._sg, self._sg_seen, sg = None, 0, None
+            optim.device_hyper(False)
         if sg is not None and sg["key"] == key:
             sg["images"].copy_(images, non_blocking=True)
             sg["labels"].copy_(labels, non_blocking=True)
