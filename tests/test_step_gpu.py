@@ -661,4 +661,6 @@ def test_step_graph_is_dropped_and_rebuilt_when_the_optimiser_state_moves():
     np.testing.assert_allclose(graph, eager, rtol=2e-3)
     for n in pe:
         d = ((pe[n] - pg[n]).norm() / pe[n].norm()).item()
-        assert d < 1e-4, (n, d)
+        # 12 steps: the library's weight-gradient kernel of the stem is not bit-reproducible between two runs (1.7e-4 on its weight
+        # here); a graph that kept stepping the OLD momentum buffers would be off by > 1e-2 after six more steps at momentum 0.9
+        assert d < 1e-3, (n, d)
