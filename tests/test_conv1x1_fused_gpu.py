@@ -456,12 +456,23 @@ def test_backward_link_refuses_a_second_consumer(use_node):
         with torch.autocast("cuda", dtype=torch.bfloat16):
             h1 = blocks._conv_abn_train(c.conv1, c.bn1, x * 1.0, make_link=True)
             assert getattr(h1, "_ucd_link", None) is not None
+            early = h1.to(torch.bfloat16) * 1.0                   # a reader of h1 created BEFORE the linked consumer (see below)
             h2 = blocks._conv_abn_train(c.conv2, c.bn2, h1, make_link=True)
             good = h2.float().sum()
             bad = h2.float().sum() + h1.float().mean()            # h1 gains a second consumer
+            # a second consumer created BEFORE the linked convolution runs AFTER it in the backward - the engine's input
+            # buffer then holds the consumer's dx already and may add the late gradient INTO it in place: same address (the address
+            # check alone would pass), bumped version counter - which the producer now checks as well
+            bad_early = h2.float().sum() + early.float().sum()
         with pytest.raises(RuntimeError, match="second consumer"):
             bad.backward(retain_graph=True)
         torch.cuda.synchronize()
+        x.grad = None
+        mod.finish_grad_sync(); mod.zero_grad()                  # (the aborted backward had delivered conv2's gradient already)
+        with pytest.raises(RuntimeError, match="second consumer"):
+            bad_early.backward(retain_graph=True)
+        torch.cuda.synchronize()
+        mod.finish_grad_sync(); mod.zero_grad()
         # the flag was cleared with the error: the same graph without the extra reader is fine afterwards
         x.grad = None
         good.backward()

@@ -438,7 +438,7 @@ class _ConvABNFunction(torch.autograd.Function):
         ctx.cfg = (act, slope, residual is not None)
         if make_link and bias is not None and (act & hip.ACT_MASK) != hip.ACT_ELU and (residual is None or needs_y):
             partial = torch.empty(hip.conv1x1_row_tiles(M), 2, N, dtype=torch.float32, device=x.device)
-            ctx.my_link = (partial, [0, 0])      # {served, address of the consumer's dx} (see ConvABNTrainNode::backward)
+            ctx.my_link = (partial, [0, 0, 0])   # {served, address of the consumer's dx, its version} (see ConvABNTrainNode::backward)
             if residual is None:
                 y._ucd_link = (z, buf, bias, partial, ctx.my_link[1], act, slope)
             else:                                # the block's last node: the NEXT block's conv1 + shortcut node may serve it
@@ -456,7 +456,8 @@ class _ConvABNFunction(torch.autograd.Function):
         N = w4.shape[0]
         M, HW = B * H * W, H * W
         rows = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0] * t.shape[2] * t.shape[3], t.shape[1])
-        if ctx.my_link is not None and ctx.my_link[1][0] == 1 and dy.data_ptr() != ctx.my_link[1][1]:
+        if ctx.my_link is not None and ctx.my_link[1][0] == 1 and (dy.data_ptr() != ctx.my_link[1][1]
+                                                                   or dy._version != ctx.my_link[1][2]):
             ctx.my_link[1][0] = 0
             raise RuntimeError("ucd conv+abn node: the backward link was served but the gradient that arrived is not the consumer's "
                                "input gradient - the linked map has a second consumer (hook, ret_intermediate tap, retain_graph "
@@ -488,6 +489,7 @@ class _ConvABNFunction(torch.autograd.Function):
             C = lz.shape[1]
             lflag[0] = 1
             lflag[1] = dx.data_ptr()
+            lflag[2] = dx._version
             return dict(out_mode=3, out_norm=(lbuf[3 * C:4 * C], lbuf[5 * C:], lbias, lbuf[4 * C:5 * C], lact & hip.ACT_MASK, lslope),
                         residual=rows(lz), partial=lpart)
         if dilation > 0:
@@ -517,7 +519,7 @@ class _ConvABNFunction(torch.autograd.Function):
                 extra = {}
                 if ctx.blink is not None and (fold or dskip is None):
                     bz, bbuf, bpart, bflag, bslope = ctx.blink            # block link: out_mode 4 against the block in front
-                    bflag[0], bflag[1] = 1, dx.data_ptr()
+                    bflag[0], bflag[1], bflag[2] = 1, dx.data_ptr(), dx._version
                     extra = dict(out_mode=4, out_norm=(bbuf[3 * K:4 * K], None, None, bbuf[4 * K:5 * K], hip.ACT_LEAKY_RELU, bslope),
                                  residual=rows(x), side2=rows(bz), partial=bpart)
                 elif link is not None and dskip is None:

@@ -459,6 +459,14 @@ static void block_link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& out, cons
   lk_flag.data_ptr<int64_t>()[1] = (int64_t)reinterpret_cast<intptr_t>(d.y);
 }
 
+// the version counter of the gradient tensor a served link's product wrote: the engine's input buffer may later add a
+// second consumer's gradient INTO that tensor in place - same address, so the address check alone would pass - which bumps it
+static void link_record_version(const at::Tensor& lk_flag, const at::Tensor& dx) {
+  if (lk_flag.defined() && lk_flag.numel() >= 3 && lk_flag.data_ptr<int64_t>()[0] == 1 &&
+      lk_flag.data_ptr<int64_t>()[1] == (int64_t)reinterpret_cast<intptr_t>(dx.data_ptr()))
+    lk_flag.data_ptr<int64_t>()[2] = (int64_t)dx._version();
+}
+
 class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
  public:
   static variable_list forward(AutogradContext* ctx, at::Tensor x, at::Tensor w4, at::Tensor weight, at::Tensor bias,
@@ -577,7 +585,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     make_link = make_link && bias.defined() && (act & UCD_ACT_MASK) != UCD_ACT_ELU && (!has_res || needs_y);
     if (make_link) {
       my_partial = at::empty({(int64_t)ucd_conv1x1_row_tiles((int)M), 2, N}, x.options().dtype(at::kFloat));
-      my_flag = at::zeros({2}, at::TensorOptions().dtype(at::kLong));   // {served, address of the consumer's dx}
+      my_flag = at::zeros({3}, at::TensorOptions().dtype(at::kLong));   // {served, address of the consumer's dx, its version counter}
     }
     ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf, wflip,
                             consume_link ? lk_z : at::Tensor(), consume_link ? lk_buf : at::Tensor(),
@@ -635,12 +643,13 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       // consumer's input-gradient product wrote.  Anything else (a sum made by the engine, a hook's copy, a stale flag from
       // a backward pass that stopped short of this node) carries a derivative on part of dy only - wrong gradients, silently.
       const int64_t want = my_flag.data_ptr<int64_t>()[1];
-      const bool same = dy.defined() && (int64_t)reinterpret_cast<intptr_t>(dy.data_ptr()) == want;
+      const bool same = dy.defined() && (int64_t)reinterpret_cast<intptr_t>(dy.data_ptr()) == want &&
+                        (my_flag.numel() < 3 || (int64_t)dy._version() == my_flag.data_ptr<int64_t>()[2]);
       if (!same) {
         my_flag.data_ptr<int64_t>()[0] = 0;
         TORCH_CHECK(false, "ucd conv+abn node: the backward link was served but the gradient that arrived is not the consumer's "
-                           "input gradient - the linked map has a second consumer (hook, ret_intermediate tap, retain_graph "
-                           "replay).  Run with UCD_BWD_LINK=0.");
+                           "input gradient, or was added to in place since - the linked map has a second consumer (hook, "
+                           "ret_intermediate tap, retain_graph replay).  Run with UCD_BWD_LINK=0.");
       }
     }
     if (dy.defined()) {
@@ -726,8 +735,10 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
           d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)(9 * N); d.y = dx.data_ptr(); d.ldy = (int)K;
           d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0;
           d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation;
-          if (lk_flag.defined() && ctx->saved_data["lk_kind"].toInt() != 3)
+          if (lk_flag.defined() && ctx->saved_data["lk_kind"].toInt() != 3) {
             link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
+            link_record_version(lk_flag, dx);
+          }
           check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
         } else {
           dx = at::conv2d(dz, wflip, {}, {1, 1}, {dilation, dilation}, {dilation, dilation}, 1);
@@ -762,6 +773,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         } else if (lk_flag.defined() && !fold && !dskip.defined()) {
           link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
         }
+        link_record_version(lk_flag, dx);
         check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
         if (!fold && dskip.defined()) dx = dx + dskip;
       } else if (fold) {
