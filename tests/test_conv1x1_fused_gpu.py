@@ -975,3 +975,62 @@ def test_projection_block_alias_equals_the_separate_gradient_add(cin, chans, str
     worst = max(_rel(a[i], b[i]) for i in range(1, len(a)) if b[i].abs().max() > 0)
     print("projection alias", cin, chans, stride, hw, "worst gradient difference on / off", worst)
     assert worst < 3e-2, worst
+
+
+# ---- every pipeline form of the GEMM kernel (UCD_CONV_PIPE is read once per process: one child process per form) ----------------------
+_PIPE_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from ucd_amd import hip
+dev = torch.device("cuda:0")
+g = torch.Generator(dev).manual_seed(11)
+def ints(*shape, hi):
+    return torch.randint(-hi, hi + 1, shape, device=dev, generator=g).bfloat16()
+# (M, K, N, conv3 = (H, W, d) or None): ragged row counts, both tile widths, 1x1 and 3x3, grids below and above 256 tiles
+for M, K, N, sp in ((2 * 9 * 11, 128, 64, (9, 11, 1)), (777, 256, 128, None), (2178, 128, 256, (33, 33, 2)), (26136, 256, 256, (33, 33, 1)),
+                    (26136, 1024, 256, None), (4 * 33 * 33 - 0, 64, 128, (33, 33, 6))):
+    a = ints(M, K, hi=2) * (torch.rand(M, K, device=dev, generator=g) < 0.2)
+    taps = 9 if sp else 1
+    w = ints(N, taps * K, hi=1) * (torch.rand(N, taps * K, device=dev, generator=g) < 0.2)
+    y = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    if sp:
+        H, W, d = sp
+        B = M // (H * W)
+        ref = torch.nn.functional.conv2d(a.float().view(B, H, W, K).permute(0, 3, 1, 2),
+                                         w.float().view(N, 3, 3, K).permute(0, 3, 1, 2), None, 1, d, d).permute(0, 2, 3, 1).reshape(M, N)
+    else:
+        ref = a.float() @ w.float().t()
+    assert ref.abs().max().item() <= 256
+    hip.conv1x1(a, w, y, conv3=sp)
+    assert torch.equal(y.float(), ref), ("plain", M, K, N, sp)
+    part = hip.conv1x1_stats_partial(M, N, dev)
+    y.fill_(float("nan"))
+    hip.conv1x1(a, w, y, out_mode=2, partial=part, conv3=sp)
+    assert torch.equal(y.float(), ref), ("stats", M, K, N, sp)
+    tiles = hip.load().ucd_conv1x1_row_tiles(M)
+    p = part.view(tiles, 3, N)
+    for t in (0, tiles - 1):
+        rows = ref[t * 128:(t + 1) * 128]
+        k = p[t, 0]
+        assert torch.equal(p[t, 1], (rows - k).sum(0)) and torch.equal(p[t, 2], ((rows - k) ** 2).sum(0)), ("partials", M, K, N, sp, t)
+    res = ints(M, N, hi=3)
+    one, zero = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    hip.conv1x1(a, w, y, out_mode=1, out_norm=(zero, one, zero, None, hip.ACT_LEAKY_RELU, 0.5), residual=res, conv3=sp)
+    z = ref + res.float()
+    assert torch.equal(y.float(), torch.where(z > 0, z, z * 0.5).bfloat16().float()), ("affine", M, K, N, sp)
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("pipe", ["2x64", "4x32", "4x64", "lw32", "lw64", "lw64x2", "lw256"])
+def test_every_pipeline_form_of_the_gemm_kernel_is_exact_on_integers(pipe):
+    """The GEMM / implicit-GEMM kernel has seven pipeline forms since round 4 (double buffer, two four-stage forms, loader waves on
+    128-row tiles with 2 / 3 / 4 stages and on 256-row tiles); the library picks by grid, ``UCD_CONV_PIPE`` forces one.  Each form runs
+    the plain, statistics and affine + residual + activation epilogues on sparse small integers (every output exactly representable:
+    bit-exact against fp32 products, the per-tile statistics partials included) at ragged row counts, in a process of its own."""
+    import subprocess
+    import sys
+    env = dict(os.environ, UCD_CONV_PIPE=pipe)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _PIPE_CHILD % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (pipe, r.stdout[-500:], r.stderr[-1500:])
