@@ -459,6 +459,12 @@ typedef struct ucd_conv1x1_desc {
   int stride;
 } ucd_conv1x1_desc;
 
+/* Kernel forms behind ucd_conv1x1 (chosen per launch by the grid; results do not depend on the choice - tests/
+ * test_conv1x1_fused_gpu.py::test_every_pipeline_form... holds every form bit-exact on integers): single LDS stage at four workgroups
+ * per CU (full grids), double buffer at two (<= 640 tiles, out_mode 4), and since round 4 the loader-wave forms - MFMA waves that
+ * only multiply and loader waves that only stage - on 128-row tiles for grids of <= 256 tiles and on 256-row tiles for grids of
+ * 257 .. 640 tiles that fit the chip as 256-row tiles.  The environment variable UCD_CONV_PIPE (read once per process: 2x64, 4x32,
+ * 4x64, lw32, lw64, lw64x2, lw256) forces one form for every double-buffer-eligible launch; it exists for probes and A/B runs. */
 int ucd_conv1x1_row_tiles(int M);
 size_t ucd_conv1x1_stats_partial_bytes(int M, int C);
 int ucd_conv1x1(const ucd_conv1x1_desc* desc, ucd_stream_t stream);
@@ -518,7 +524,9 @@ int ucd_stem_pool_backward(const void* z, const void* dpool, const uint8_t* idx,
  * dz [M][N] and x [M][K] bf16 row matrices (leading dimensions in elements), N and K multiples of 64.  The result is in the
  * weight's channels-last order [N][kh][kw][K]: dw (bf16, may be NULL) and / or dw32 (fp32, may be NULL; += when accumulate32,
  * e.g. straight into the fp32 gradient bucket).  workspace: ucd_conv_wgrad_workspace_bytes(M, N, K, taps) bytes of fp32 slabs
- * (one per row chunk), added in a fixed order (deterministic). */
+ * (one per row chunk), added in a fixed order (deterministic).  3x3 layers with 128-aligned channels, M >= 8192 and dilation <= 18
+ * run the three-tap form (one kernel row per workgroup, round 4); UCD_WGRAD3=0 in the environment keeps the 9-tap form for them
+ * (both are exact on integer operands and agree bit for bit there: tests/test_conv1x1_fused_gpu.py). */
 size_t ucd_conv_wgrad_workspace_bytes(int M, int N, int K, int taps);
 int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
                    void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, ucd_stream_t stream);

@@ -579,6 +579,12 @@ __global__ __launch_bounds__(kStatThreads) void tile_stats_reduce_kernel(const f
       const float k2 = p2[0], a2 = p2[C], b2 = p2[2 * C], k3 = p3[0], a3 = p3[C], b3 = p3[2 * C];
       add(t, k0, a0, b0); add(t + TL, k1, a1, b1); add(t + 2 * TL, k2, a2, b2); add(t + 3 * TL, k3, a3, b3);
     }
+    for (; t + TL < tiles; t += 2 * TL) {   // the bench's 205 row tiles = two tiles per lane: both in flight (was one round trip each)
+      const float* p0 = partial + (size_t)t * 3 * C + c;
+      const float* p1 = p0 + (size_t)TL * 3 * C;
+      const float k0 = p0[0], a0 = p0[C], b0 = p0[2 * C], k1 = p1[0], a1 = p1[C], b1 = p1[2 * C];
+      add(t, k0, a0, b0); add(t + TL, k1, a1, b1);
+    }
     for (; t < tiles; t += TL) {
       const float* pt = partial + (size_t)t * 3 * C + c;
       add(t, pt[0], pt[C], pt[2 * C]);
