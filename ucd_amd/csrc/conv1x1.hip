@@ -30,6 +30,8 @@
 //     barrier} - the fill latency of one workgroup is covered by the MFMAs of the other three;
 //   DB, two stages, two workgroups per CU: the fill of step k+1 is issued before the MFMAs of step k and waited for with
 //     a counted vmcnt - for grids that give a CU only one or two workgroups (chosen by the host per launch).
+//   loader waves (round 4, conv_lw_kernel below): the workgroup's MFMA waves never issue a fill and its loader waves never touch the
+//     matrix pipe - three stages, one barrier per K step, one workgroup per CU on 128- or 256-row tiles; chosen by the grid (pick_pipe).
 // Only the fused input transform (PRO) stages A through registers (it has to touch the values).  Rows past M are clamped,
 // never branched around and never stored.  The output tile goes through LDS (fp32, two 64-row halves) so that global
 // stores, residual loads and the per-channel reductions are row-contiguous 16-byte accesses.  blockIdx -> tile: the

@@ -19,6 +19,8 @@
 // of step s+1 in flight under the 16 MFMAs of step s behind a counted vmcnt.  The LDS image is lane-linear, so the bank-conflict swizzle of the transposed reads sits on the
 // source address too: 256-byte rows store chunk c of row r at c ^ (((r & 3) << 2) | ((r >> 2) & 3)), 128-byte rows at
 // c ^ (((r >> 1) & 1) << 2) - the four rows of a transposed read then lie in four different 64-byte bank ranges.
+// The 3x3 layers with 128-aligned channels and large maps take wgrad3_kernel (round 4, further down): one kernel ROW per workgroup -
+// three taps from one dZ tile and one X tile of 64 + 2 d rows, 6 MFMA + 2 loader waves; this 9-tap form keeps the rest.
 // Workgroup -> work: all tiles and taps of one row chunk sit on one XCD (ids congruent mod 8 share an L2), so a chunk's rows
 // of dZ and X leave HBM once and are re-read by its tiles from that L2.
 #include <type_traits>
