@@ -3,6 +3,8 @@ batch norm + activation; raw gamma for ABN, |gamma| + eps for the in-place varia
 by the reference).  Tolerance 1e-5 abs/rel in fp32; bf16 I/O is checked against the same fp32
 oracle at bf16 resolution."""
 import numpy as np
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -629,3 +631,58 @@ def test_stem_conv7x7_matches_conv2d(B, H, W, nchw):
     ref = F.conv2d(x.bfloat16().float(), w.bfloat16().float(), None, 2, 3)
     err = ((z.float() - ref).norm() / ref.norm()).item()
     assert err < 3e-3, err
+
+_PACKED_VS_GENERIC = r"""
+import sys, torch
+from ucd_amd import hip
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+outs = {}
+for (B, C, H, W, slope, act) in ((3, 64, 33, 32, 0.01, 1), (2, 64, 65, 67, 0.01, 1), (2, 256, 33, 33, 0.01, 1), (3, 1024, 17, 19, 1.0, 0), (1, 8, 5, 7, 0.2, 1), (2, 128, 9, 11, 0.01, 1 | 0x100)):
+    x = (torch.randn(B, C, H, W, device=dev) * 1.5 + 0.3).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = torch.randn_like(x); r = torch.randn_like(x)
+    M, HW = B * H * W, H * W
+    buf = torch.zeros(6 * C, device=dev); w = torch.randn(C, device=dev) * 0.3 + 1; w[1] = -0.7; b = torch.randn(C, device=dev) * 0.2
+    sums, ks, mean, invstd, scale = buf[:2*C], buf[2*C:3*C], buf[3*C:4*C], buf[4*C:5*C], buf[5*C:]
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    hip.abn_stats_finalize(x, C, M, C, None, HW, sums, ks, w, rm, rv, 0.1, 1e-5, mean, invstd, scale)
+    y = torch.empty_like(x); y2 = torch.empty_like(x); y3 = torch.empty_like(x); dx = torch.empty_like(x); dz = torch.empty_like(x); dx2 = torch.empty_like(x); dx3 = torch.empty_like(x)
+    hip.abn_apply(x, C, y, C, None, 0, M, C, None, HW, mean, scale, b, act, slope)
+    hip.abn_apply(x, C, y2, C, r, C, M, C, None, HW, mean, scale, b, act, slope)
+    hip.abn_apply(x, C, y3, C, None, 0, M, C, None, HW, mean, scale, None, act, slope)
+    s2 = torch.zeros(2 * C, device=dev); s3 = torch.zeros(2 * C, device=dev)
+    hip.abn_bwd_reduce(x, C, dy, C, None, 0, M, C, None, HW, mean, invstd, scale, b, act, slope, s2)
+    hip.abn_bwd_apply(x, C, dy, C, None, 0, dx, C, None, 0, M, C, None, HW, mean, invstd, scale, b, w, s2, M, 0, act, slope)
+    hip.abn_bwd_reduce(x, C, dy, C, y, C, M, C, None, HW, mean, invstd, scale, b, act, slope, s3)
+    hip.abn_bwd_apply(x, C, dy, C, y, C, dx2, C, dz, C, M, C, None, HW, mean, invstd, scale, b, w, s3, M, 0, act, slope)
+    hip.abn_bwd_apply(x, C, dy, C, y, C, dx3, C, None, 0, M, C, None, HW, mean, invstd, scale, b, w, s3, M, 1, act, slope)   # frozen
+    torch.cuda.synchronize()
+    outs[(B, C, H, W, act)] = [t.cpu() for t in (y, y2, y3, s2, dx, s3, dx2, dz, dx3)]
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_packed_math_kernels_equal_the_per_element_kernels_bit_for_bit(tmp_path):
+    """Round 4: the bf16 apply / backward passes of the step run on float pairs (csrc/abn.hip: abn_*_fast_kernel, packed-fp32
+    instructions, the nullable operands as template flags).  Same operations in the same order as the per-element kernels
+    (the library is built without fp contraction), so every output - activations, both backward sums, input gradients with the
+    sign from x or from the stored output, dz, the frozen form - must be BIT-identical; UCD_ABN_GENERIC=1 (read once per process,
+    hence the two child processes) selects the per-element kernels."""
+    import subprocess
+    import sys
+    script = tmp_path / "packed_vs_generic.py"
+    script.write_text(_PACKED_VS_GENERIC)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("packed", "generic"):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.pop("UCD_ABN_GENERIC", None)
+        if mode == "generic":
+            env["UCD_ABN_GENERIC"] = "1"
+        out = tmp_path / f"{mode}.pt"
+        subprocess.run([sys.executable, str(script), str(out)], env=env, check=True, timeout=600)
+        res[mode] = torch.load(out)
+    names = "y y_res y_noshift sums dx sums_y dx_y dz dx_frozen".split()
+    for shape, tensors in res["packed"].items():
+        for name, a, b in zip(names, tensors, res["generic"][shape]):
+            assert torch.equal(a, b), f"{name} at {shape}: {(a.float() != b.float()).sum().item()} values differ"

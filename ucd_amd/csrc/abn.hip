@@ -327,6 +327,61 @@ __global__ __launch_bounds__(kBlock) void abn_apply_kernel(const T* x, int ld_x,
   }
 }
 
+// bf16, no plane bias, leaky_relu / identity (slope = 1): the layers of the train step.  Same arithmetic as abn_apply_kernel
+// ((x - mean) * scale + shift, + residual, select; no contraction) on float pairs.
+template <bool RES>
+__global__ __launch_bounds__(kBlock) void abn_apply_fast_kernel(const __hip_bfloat16* x, int ld_x, __hip_bfloat16* y, int ld_y,
+                                                               const __hip_bfloat16* __restrict__ res, int ld_r, int M, int C,
+                                                               const float* __restrict__ mean, const float* __restrict__ scale,
+                                                               const float* __restrict__ beta, float slope, int TX, int TY,
+                                                               int rows_per_band) {
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  if (ty >= TY || cg * 8 >= C) return;
+  const size_t coff = (size_t)cg * 8;
+  const Pack8 mu = load_f8(mean + coff), sc = load_f8(scale + coff);
+  Pack8 sh;
+  if (beta) sh = load_f8(beta + coff);
+  else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh.p[j] = f32x2{0.f, 0.f};
+  }
+  const int r_begin = blockIdx.y * rows_per_band;
+  const int r_end = min(M, r_begin + rows_per_band);
+  auto emit = [&](const uint4& xv, const uint4& rv, int r) {
+    const Pack8 v = unpack8(xv);
+    Pack8 o;
+    if (RES) {
+      const Pack8 q = unpack8(rv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.p[j] = leaky2((v.p[j] - mu.p[j]) * sc.p[j] + sh.p[j] + q.p[j], slope);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.p[j] = leaky2((v.p[j] - mu.p[j]) * sc.p[j] + sh.p[j], slope);
+    }
+    *reinterpret_cast<uint4*>(y + (size_t)r * ld_y + coff) = pack8(o);
+  };
+  auto ld = [&](const __hip_bfloat16* p, int ldp, int r) { return *reinterpret_cast<const uint4*>(p + (size_t)r * ldp + coff); };
+  int r = r_begin + ty;
+  for (; r + 3 * TY < r_end; r += 4 * TY) {
+    uint4 v0 = ld(x, ld_x, r), v1 = ld(x, ld_x, r + TY), v2 = ld(x, ld_x, r + 2 * TY), v3 = ld(x, ld_x, r + 3 * TY);
+    uint4 q0 = v0, q1 = v0, q2 = v0, q3 = v0;
+    if (RES) {
+      q0 = ld(res, ld_r, r); q1 = ld(res, ld_r, r + TY); q2 = ld(res, ld_r, r + 2 * TY); q3 = ld(res, ld_r, r + 3 * TY);
+    }
+    emit(v0, q0, r);
+    emit(v1, q1, r + TY);
+    emit(v2, q2, r + 2 * TY);
+    emit(v3, q3, r + 3 * TY);
+  }
+  for (; r < r_end; r += TY) {
+    const uint4 v = ld(x, ld_x, r);
+    uint4 q = v;
+    if (RES) q = ld(res, ld_r, r);
+    emit(v, q, r);
+  }
+}
+
 // ---- backward reduce ----------------------------------------------------------------------------
 template <typename T, int ACT>
 __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_kernel(
@@ -489,6 +544,156 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_kernel(
     v.load(x + (size_t)r * ld_x + coff);
     g.load(dy + (size_t)r * ld_dy + coff);
     if (yout) yo.load(yout + (size_t)r * ld_y + coff);
+    emit(v, g, yo, r);
+  }
+}
+
+// ---- backward, bf16 fast path (no plane bias, leaky_relu / identity): packed-fp32 math, nullable operands as flags --------
+template <bool YOUT>
+__global__ __launch_bounds__(kBlock) void abn_bwd_reduce_fast_kernel(
+    const __hip_bfloat16* __restrict__ x, int ld_x, const __hip_bfloat16* __restrict__ dy, int ld_dy,
+    const __hip_bfloat16* __restrict__ yout, int ld_y, int M, int C, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift, float slope, int TX, int TY,
+    int rows_per_band, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  const bool live = ty < TY && cg * 8 < C;
+  f32x2 s1[4], s2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { s1[j] = f32x2{0.f, 0.f}; s2[j] = f32x2{0.f, 0.f}; }
+  if (live) {
+    const size_t coff = (size_t)cg * 8;
+    const Pack8 mu = load_f8(mean + coff), is = load_f8(invstd + coff), sc = load_f8(scale + coff);
+    Pack8 sh;
+    if (shift) sh = load_f8(shift + coff);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sh.p[j] = f32x2{0.f, 0.f};
+    }
+    const int r_begin = blockIdx.y * rows_per_band;
+    const int r_end = min(M, r_begin + rows_per_band);
+    auto accumulate = [&](const uint4& xv, const uint4& gv, const uint4& yv) {
+      const Pack8 v = unpack8(xv), g = unpack8(gv);
+      Pack8 yo;
+      if (YOUT) yo = unpack8(yv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x2 d = v.p[j] - mu.p[j];
+        const f32x2 sgn = YOUT ? yo.p[j] : d * sc.p[j] + sh.p[j];
+        const f32x2 dz = leaky_grad2(g.p[j], sgn, slope);
+        s1[j] += dz;
+        s2[j] += dz * (d * is.p[j]);
+      }
+    };
+    auto ld = [&](const __hip_bfloat16* p, int ldp, int r) { return *reinterpret_cast<const uint4*>(p + (size_t)r * ldp + coff); };
+    int r = r_begin + ty;
+    for (; r + 3 * TY < r_end; r += 4 * TY) {
+      const uint4 v0 = ld(x, ld_x, r), g0 = ld(dy, ld_dy, r), v1 = ld(x, ld_x, r + TY), g1 = ld(dy, ld_dy, r + TY);
+      const uint4 v2 = ld(x, ld_x, r + 2 * TY), g2 = ld(dy, ld_dy, r + 2 * TY), v3 = ld(x, ld_x, r + 3 * TY), g3 = ld(dy, ld_dy, r + 3 * TY);
+      uint4 y0 = v0, y1 = v0, y2 = v0, y3 = v0;
+      if (YOUT) { y0 = ld(yout, ld_y, r); y1 = ld(yout, ld_y, r + TY); y2 = ld(yout, ld_y, r + 2 * TY); y3 = ld(yout, ld_y, r + 3 * TY); }
+      accumulate(v0, g0, y0);
+      accumulate(v1, g1, y1);
+      accumulate(v2, g2, y2);
+      accumulate(v3, g3, y3);
+    }
+    for (; r < r_end; r += TY) {
+      const uint4 v = ld(x, ld_x, r), g = ld(dy, ld_dy, r);
+      uint4 yo = v;
+      if (YOUT) yo = ld(yout, ld_y, r);
+      accumulate(v, g, yo);
+    }
+  }
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { acc[2 * j] = s1[j].x; acc[2 * j + 1] = s1[j].y; acc[8 + 2 * j] = s2[j].x; acc[8 + 2 * j + 1] = s2[j].y; }
+  block_reduce_rows<16>(acc, tx, ty, TX, TY, lds);
+  if (ty == 0 && cg * 8 < C) {
+    float* p = partial + (size_t)blockIdx.y * 2 * C + cg * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      p[i] = acc[i];
+      p[C + i] = acc[8 + i];
+    }
+  }
+}
+
+// dx = (dz - mean(dz) - xhat * mean(dz xhat)) * gamma invstd with the same operation order as abn_bwd_apply_kernel:
+// ((dz - k0) - xhat k1) gw (the library is built with -ffp-contract=off: no fma anywhere).  frozen: k0 = k1 = invstd = 0, gw = scale.
+template <bool YOUT, bool DZOUT>
+__global__ __launch_bounds__(kBlock) void abn_bwd_apply_fast_kernel(
+    const __hip_bfloat16* x, int ld_x, const __hip_bfloat16* dy, int ld_dy, const __hip_bfloat16* yout, int ld_y,
+    __hip_bfloat16* dx, int ld_dx, __hip_bfloat16* dz_out, int ld_dz, int M, int C, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ weight, const float* __restrict__ sums, float inv_count, int frozen, int abs_gamma, float slope,
+    int TX, int TY, int rows_per_band) {
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int cg = blockIdx.x * TX + tx;
+  if (ty >= TY || cg * 8 >= C) return;
+  const size_t coff = (size_t)cg * 8;
+  const Pack8 mu = load_f8(mean + coff), sc = load_f8(scale + coff);
+  Pack8 sh, is, k0, k1, gw;
+  if (shift) sh = load_f8(shift + coff);
+  else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh.p[j] = f32x2{0.f, 0.f};
+  }
+  if (frozen) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { is.p[j] = f32x2{0.f, 0.f}; k0.p[j] = f32x2{0.f, 0.f}; k1.p[j] = f32x2{0.f, 0.f}; gw.p[j] = sc.p[j]; }
+  } else {
+    is = load_f8(invstd + coff);
+    const Pack8 a0 = load_f8(sums + coff), a1 = load_f8(sums + C + coff);
+    Pack8 w;
+    if (weight) w = load_f8(weight + coff);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k0.p[j] = a0.p[j] * inv_count;                    // mean(dz)
+      f32x2 kk = a1.p[j] * inv_count;                   // mean(dz * xhat)
+      if (abs_gamma) {                                  // sums[C + c] is d weight = sign(weight) * sum dz*xhat; scale = (|w| + eps) * invstd
+        if (weight) kk = f32x2{w.p[j].x < 0.f ? -kk.x : kk.x, w.p[j].y < 0.f ? -kk.y : kk.y};
+        gw.p[j] = sc.p[j];
+      } else {
+        gw.p[j] = weight ? w.p[j] * is.p[j] : is.p[j];
+      }
+      k1.p[j] = kk;
+    }
+  }
+  const int r_begin = blockIdx.y * rows_per_band;
+  const int r_end = min(M, r_begin + rows_per_band);
+  auto emit = [&](const uint4& xv, const uint4& gv, const uint4& yv, int r) {
+    const Pack8 v = unpack8(xv), g = unpack8(gv);
+    Pack8 yo, o, oz;
+    if (YOUT) yo = unpack8(yv);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x2 d = v.p[j] - mu.p[j];
+      const f32x2 sgn = YOUT ? yo.p[j] : d * sc.p[j] + sh.p[j];
+      const f32x2 dz = leaky_grad2(g.p[j], sgn, slope);
+      const f32x2 xh = d * is.p[j];
+      o.p[j] = (dz - k0.p[j] - xh * k1.p[j]) * gw.p[j];
+      oz.p[j] = dz;
+    }
+    *reinterpret_cast<uint4*>(dx + (size_t)r * ld_dx + coff) = pack8(o);
+    if (DZOUT) *reinterpret_cast<uint4*>(dz_out + (size_t)r * ld_dz + coff) = pack8(oz);
+  };
+  auto ld = [&](const __hip_bfloat16* p, int ldp, int r) { return *reinterpret_cast<const uint4*>(p + (size_t)r * ldp + coff); };
+  int r = r_begin + ty;
+  for (; r + 3 * TY < r_end; r += 4 * TY) {
+    const uint4 v0 = ld(x, ld_x, r), g0 = ld(dy, ld_dy, r), v1 = ld(x, ld_x, r + TY), g1 = ld(dy, ld_dy, r + TY);
+    const uint4 v2 = ld(x, ld_x, r + 2 * TY), g2 = ld(dy, ld_dy, r + 2 * TY), v3 = ld(x, ld_x, r + 3 * TY), g3 = ld(dy, ld_dy, r + 3 * TY);
+    uint4 y0 = v0, y1 = v0, y2 = v0, y3 = v0;
+    if (YOUT) { y0 = ld(yout, ld_y, r); y1 = ld(yout, ld_y, r + TY); y2 = ld(yout, ld_y, r + 2 * TY); y3 = ld(yout, ld_y, r + 3 * TY); }
+    emit(v0, g0, y0, r);
+    emit(v1, g1, y1, r + TY);
+    emit(v2, g2, y2, r + 2 * TY);
+    emit(v3, g3, y3, r + 3 * TY);
+  }
+  for (; r < r_end; r += TY) {
+    const uint4 v = ld(x, ld_x, r), g = ld(dy, ld_dy, r);
+    uint4 yo = v;
+    if (YOUT) yo = ld(yout, ld_y, r);
     emit(v, g, yo, r);
   }
 }
@@ -664,6 +869,13 @@ int check_common(const char* fn, int dtype, int M, int C, int act) {
   return 0;
 }
 
+// bf16 tensors without a plane bias under leaky_relu / identity take the packed-math kernels (UCD_ABN_GENERIC=1: the per-element
+// kernels everywhere - the A/B switch of tools/abn_bench.py)
+inline bool fast_path(int dtype, const float* plane_bias, int act_kind) {
+  static const bool generic = getenv("UCD_ABN_GENERIC") != nullptr;
+  return !generic && dtype == UCD_BF16 && !plane_bias && act_kind != UCD_ACT_ELU;
+}
+
 #define UCD_TRY(expr)          \
   do {                         \
     int _rc = (expr);          \
@@ -769,6 +981,18 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
                                                                  g.rows_per_band);                             \
   }
   const int a = act & UCD_ACT_MASK;
+  if (fast_path(dtype, plane_bias, a) && aligned16(mean) && aligned16(scale) && (!shift || aligned16(shift))) {
+    const Geom g = make_geom<8>(M, C, 512, 4);
+    const float sl = a == UCD_ACT_LEAKY_RELU ? slope : 1.f;
+    typedef __hip_bfloat16 B;
+    if (residual)
+      abn_apply_fast_kernel<true><<<dim3(g.gx, g.gy), kBlock, 0, s>>>((const B*)x, ld_x, (B*)y, ld_y, (const B*)residual, ld_r, M, C,
+                                                                      mean, scale, shift, sl, g.TX, g.TY, g.rows_per_band);
+    else
+      abn_apply_fast_kernel<false><<<dim3(g.gx, g.gy), kBlock, 0, s>>>((const B*)x, ld_x, (B*)y, ld_y, nullptr, 0, M, C, mean, scale,
+                                                                       shift, sl, g.TX, g.TY, g.rows_per_band);
+    return check_launch(fn);
+  }
   if (dtype == UCD_BF16) {
     if (a == UCD_ACT_LEAKY_RELU) LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
     else if (a == UCD_ACT_ELU) LAUNCH_APPLY(__hip_bfloat16, 8, UCD_ACT_ELU)
@@ -805,7 +1029,18 @@ static int bwd_reduce_impl(const char* fn, const void* x, int ld_x, const void* 
         shift, slope, g.TX, g.TY, g.rows_per_band, partial);                                                       \
   }
   const int a = act & UCD_ACT_MASK;
-  if (dtype == UCD_BF16) {
+  if (fast_path(dtype, plane_bias, a) && aligned16(mean) && aligned16(invstd) && aligned16(scale) && (!shift || aligned16(shift))) {
+    typedef __hip_bfloat16 B;
+    g = make_geom<8>(M, C, 512, 8, kMaxBands);
+    UCD_REQUIRE(workspace_bytes >= (size_t)g.gy * 2 * C * 4, UCD_EWORKSPACE, "%s: workspace too small", fn);
+    const float sl = a == UCD_ACT_LEAKY_RELU ? slope : 1.f;
+    if (y)
+      abn_bwd_reduce_fast_kernel<true><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>(
+          (const B*)x, ld_x, (const B*)dy, ld_dy, (const B*)y, ld_y, M, C, mean, invstd, scale, shift, sl, g.TX, g.TY, g.rows_per_band, partial);
+    else
+      abn_bwd_reduce_fast_kernel<false><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>(
+          (const B*)x, ld_x, (const B*)dy, ld_dy, nullptr, 0, M, C, mean, invstd, scale, shift, sl, g.TX, g.TY, g.rows_per_band, partial);
+  } else if (dtype == UCD_BF16) {
     if (a == UCD_ACT_LEAKY_RELU) LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
     else if (a == UCD_ACT_ELU) LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_ELU)
     else LAUNCH_RED(__hip_bfloat16, 8, UCD_ACT_IDENTITY)
@@ -932,6 +1167,22 @@ int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const 
         (act & UCD_NORM_ABS_GAMMA) != 0, slope, g.TX, g.TY, g.rows_per_band);                                                                                          \
   }
   const int a = act & UCD_ACT_MASK;
+  if (fast_path(dtype, plane_bias, a) && aligned16(mean) && aligned16(scale) && (!shift || aligned16(shift)) &&
+      (frozen || (aligned16(invstd) && aligned16(sums) && C % 4 == 0 && (!weight || aligned16(weight))))) {
+    typedef __hip_bfloat16 B;
+    const Geom g = make_geom<8>(M, C, 512, 4);
+    const float sl = a == UCD_ACT_LEAKY_RELU ? slope : 1.f;
+    const int ag = (act & UCD_NORM_ABS_GAMMA) != 0;
+#define UCD_BWD_FAST(YO, DZ)                                                                                                      \
+  abn_bwd_apply_fast_kernel<YO, DZ><<<dim3(g.gx, g.gy), kBlock, 0, s>>>((const B*)x, ld_x, (const B*)dy, ld_dy, (const B*)y, ld_y, \
+                                                                        (B*)dx, ld_dx, (B*)dz_out, ld_dz, M, C, mean, invstd, scale, \
+                                                                        shift, weight, sums, inv_count, frozen, ag, sl, g.TX, g.TY, \
+                                                                        g.rows_per_band)
+    if (y) { if (dz_out) UCD_BWD_FAST(true, true); else UCD_BWD_FAST(true, false); }
+    else { if (dz_out) UCD_BWD_FAST(false, true); else UCD_BWD_FAST(false, false); }
+#undef UCD_BWD_FAST
+    return check_launch(fn);
+  }
   if (dtype == UCD_BF16) {
     if (a == UCD_ACT_LEAKY_RELU) LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_LEAKY_RELU)
     else if (a == UCD_ACT_ELU) LAUNCH_BWD(__hip_bfloat16, 8, UCD_ACT_ELU)

@@ -75,6 +75,49 @@ template <> struct Vec<__hip_bfloat16> {
   }
 };
 
+// ---- eight bf16 activations as four float pairs ---------------------------------------------------
+// The element-wise passes (ABN apply / backward) are VALU-issue-bound when written per element: ~17 instructions per value
+// (the unpack / select / re-insert of Vec<bf16>::get/set, one exec-masked branch per nullable operand) against ~5 with
+// packed-fp32 math (v_pk_add_f32 / v_pk_mul_f32; the library is built without fp contraction), one v_cvt_pk_bf16_f32 per PAIR and the nullable operands
+// as template flags (round 4: abn_apply on a 13 MB layer 11.7 -> see profiles/r04_abn_fast.txt).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+struct Pack8 {
+  f32x2 p[4];          // p[j] = elements (2j, 2j + 1)
+};
+__device__ __forceinline__ Pack8 unpack8(const uint4& raw) {
+  Pack8 o;
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o.p[j] = f32x2{__uint_as_float(w[j] << 16), __uint_as_float(w[j] & 0xFFFF0000u)};
+  return o;
+}
+__device__ __forceinline__ uint4 pack8(const Pack8& f) {   // round-to-nearest-even, the same instruction as __float2bfloat16
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16x2v b = __builtin_convertvector(f.p[j], bf16x2v);
+    w[j] = __builtin_bit_cast(uint32_t, b);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ Pack8 load_f8(const float* p) {  // eight per-channel constants (32-byte aligned: channel groups of 8)
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  Pack8 o;
+  o.p[0] = f32x2{a.x, a.y}; o.p[1] = f32x2{a.z, a.w}; o.p[2] = f32x2{b.x, b.y}; o.p[3] = f32x2{b.z, b.w};
+  return o;
+}
+// leaky_relu on a pair: z > 0 ? z : z * slope (slope = 1: identity)
+__device__ __forceinline__ f32x2 leaky2(f32x2 z, float slope) {
+  const f32x2 zs = z * slope;
+  return f32x2{z.x > 0.f ? z.x : zs.x, z.y > 0.f ? z.y : zs.y};
+}
+// g * act'(s) for leaky_relu: s > 0 ? g : g * slope
+__device__ __forceinline__ f32x2 leaky_grad2(f32x2 g, f32x2 s, float slope) {
+  const f32x2 gs = g * slope;
+  return f32x2{s.x > 0.f ? g.x : gs.x, s.y > 0.f ? g.y : gs.y};
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_fwd(float z, float slope) {
   if (ACT == UCD_ACT_LEAKY_RELU) return z > 0.f ? z : z * slope;
