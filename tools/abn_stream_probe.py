@@ -36,7 +36,21 @@ for C, hw in ((256, 33), (1024, 33), (512, 33), (2048, 33), (128, 65), (512, 65)
     t_copy = bench(lambda: y.copy_(x))
     t_add = bench(lambda: torch.add(x, dy, out=dx))
     t_app = bench(lambda: hip.abn_apply(x, C, y, C, None, 0, M, C, None, HW, mean, scale, b, 1, 0.01))
+    xi = x.clone()
+    t_inpl = bench(lambda: hip.abn_apply(xi, C, xi, C, None, 0, M, C, None, HW, mean, scale, b, 1, 0.01))
+    big = [torch.empty_like(x) for _ in range(max(2, int(600e6 / (x.numel() * 2))))]      # > 256 MB of distinct outputs: no cache reuse
+    it = [0]
+    def cold():
+        it[0] = (it[0] + 1) % len(big)
+        hip.abn_apply(x, C, big[it[0]], C, None, 0, M, C, None, HW, mean, scale, b, 1, 0.01)
+    t_cold = bench(cold)
+    it[0] = 0
+    def cold_copy():
+        it[0] = (it[0] + 1) % len(big)
+        big[it[0]].copy_(x)
+    t_ccopy = bench(cold_copy)
+    del big
     t_appr = bench(lambda: hip.abn_apply(x, C, y, C, r, C, M, C, None, HW, mean, scale, b, 1, 0.01))
     t_bapp = bench(lambda: hip.abn_bwd_apply(x, C, dy, C, None, 0, dx, C, None, 0, M, C, None, HW, mean, invstd, scale, b, w, sums, M, 0, 1, 0.01))
     t_red = bench(lambda: hip.abn_bwd_reduce(x, C, dy, C, None, 0, M, C, None, HW, mean, invstd, scale, b, 1, 0.01, sums))
-    print(f"{C:5d}x{hw:3d}^2 {x.numel()*2/1e6:6.1f} MB | copy {t_copy:6.1f} add3 {t_add:6.1f} | apply {t_app:6.1f} apply+res {t_appr:6.1f} bwd_apply {t_bapp:6.1f} bwd_reduce {t_red:6.1f}", flush=True)
+    print(f"{C:5d}x{hw:3d}^2 {x.numel()*2/1e6:6.1f} MB | copy {t_copy:6.1f} add3 {t_add:6.1f} | apply {t_app:6.1f} in-place {t_inpl:6.1f} rotating-out {t_cold:6.1f} (copy {t_ccopy:6.1f}) apply+res {t_appr:6.1f} bwd_apply {t_bapp:6.1f} bwd_reduce {t_red:6.1f}", flush=True)

@@ -62,7 +62,8 @@ with open(sys.argv[2], "w") as f:
     bygrid = collections.defaultdict(lambda: [0, 0])
     for r in win:
         k = short(r["Kernel_Name"])
-        if "abn_apply_kernel" in k or "abn_bwd_apply_kernel" in k or "abn_bwd_reduce_kernel" in k:
+        if any(n in k for n in ("abn_apply_kernel", "abn_bwd_apply_kernel", "abn_bwd_reduce_kernel", "abn_apply_fast_kernel",
+                                "abn_bwd_apply_fast_kernel", "abn_bwd_reduce_fast_kernel")):
             key = (k.split()[1], "x".join(str(r[c]) for c in sorted(r) if c.startswith("Grid_Size")))
             bygrid[key][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); bygrid[key][1] += 1
     f.write("# ABN stream kernels by grid size (threads): ms/step, calls/step, avg us\n")
