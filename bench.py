@@ -61,6 +61,9 @@ def parse():
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--global_batch", type=int, default=24)
+    p.add_argument("--force_dist", nargs="?", const="1", default=None, choices=["1", "abn", "ddp"],
+                   help="one process: a one-rank RCCL group with every SyncBN / gradient collective issued (the N > 1 code path on "
+                        "one GPU); abn / ddp: only the SyncBN or only the gradient-bucket collectives")
     p.add_argument("--crop", type=int, default=513)
     p.add_argument("--opt_level", default="O1", choices=["O0", "O1"])
     p.add_argument("--task", default="15-5")
@@ -197,6 +200,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     device = torch.device("cuda", local_rank if args.device is None else args.device)
     torch.cuda.set_device(device)
+    if args.force_dist and world == 1:
+        # the multi-rank code path on ONE GPU: a one-rank RCCL process group, and every SyncBN all-gather / all-reduce and every
+        # gradient bucket's all-reduce issued anyway (UCD_FORCE_COLLECTIVES, read by ucd_amd/abn.py and ucd_amd/ddp.py when they
+        # are imported in build()) - what a box with one GPU can exercise of the N > 1 step, step graph included
+        os.environ["UCD_FORCE_COLLECTIVES"] = args.force_dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29741")
+        dist.init_process_group(backend="nccl", world_size=1, rank=0, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -238,7 +249,9 @@ def main():
                  "step_graph_error": trainer.step_graph_error,
                  "teacher_graph": bool(trainer._sg is not None or trainer._tg is not None),
                  "teacher_graph_error": getattr(trainer, "teacher_graph_error", None),
-                 "teacher_overlap": trainer._side is not None}
+                 "teacher_overlap": trainer._side is not None,
+                 # --force_dist: a one-rank RCCL group with every SyncBN / gradient collective issued (NOT a multi-GPU number)
+                 "forced_collectives": bool(args.force_dist and world == 1)}
     own_kernels = switches.snapshot()
     lockstep = None
     if args.check_lockstep and world > 1:
@@ -317,7 +330,7 @@ def main():
         if lockstep is not None:
             out["lockstep"] = bool(lockstep)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or (args.force_dist and dist.is_initialized()):
         dist.destroy_process_group()
 
 

@@ -260,3 +260,28 @@ def test_bench_four_ranks_one_gpu_stay_in_lockstep(tmp_path):
     assert d["n_gpus"] == 4 and d["config"]["parallelism"] == "dp4" and d["value"] > 0
     assert d["lockstep"] is True
     assert all(np.isfinite(v) for v in d["losses"].values())
+
+def test_bench_forced_collectives_on_one_gpu_match_the_plain_run(tmp_path):
+    """bench.py --force_dist: ONE process with a one-rank RCCL process group in which every SyncBN all-gather / all-reduce
+    (the library-owned communicator of csrc/comm.hip) and every gradient bucket's all-reduce is issued anyway - the N > 1 step
+    with its RCCL calls, which a one-GPU box cannot otherwise run (RCCL refuses two ranks on one device).  The losses must
+    match the plain single-process run on the same batch (fp32 mode: the synchronised layers combine their one rank's statistics
+    through the gather table, a different but equivalent arithmetic), and the JSON says how the step ran (captured into the step graph or
+    not, with the error if the capture was refused)."""
+    import json
+    out = {}
+    for mode, extra in (("plain", []), ("forced", ["--force_dist"])):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "3", "--global_batch", "2",
+                            "--crop", "129", "--opt_level", "O0", "--no_miopen_find", "--no_cpu_baseline", "--no_kernel_timing"] + extra,
+                           capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out[mode] = json.loads(lines[0])
+    a, b = out["plain"], out["forced"]
+    assert b["execution"]["forced_collectives"] is True and a["execution"]["forced_collectives"] is False
+    assert b["own_kernels"]["UCD_FORCE_COLLECTIVES"] == "1"
+    for k, v in a["losses"].items():
+        assert np.isfinite(b["losses"][k])
+        assert abs(b["losses"][k] - v) <= 2e-3 * max(1.0, abs(v)), (k, v, b["losses"][k])

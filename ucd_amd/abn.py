@@ -60,7 +60,8 @@ def _after_optimizer_step(optimizer, args, kwargs):
 register_optimizer_step_post_hook(_after_optimizer_step)
 
 
-_FORCE_SYNC = os.environ.get("UCD_ABN_FORCE_SYNC") == "1"   # profiling aid: take the multi-rank code path at world 1
+# take the multi-rank code path at world 1 (profiling aid; bench.py --force_dist sets UCD_FORCE_COLLECTIVES for the whole step)
+_FORCE_SYNC = os.environ.get("UCD_ABN_FORCE_SYNC") == "1" or os.environ.get("UCD_FORCE_COLLECTIVES") in ("1", "abn")
 
 
 def _group_size(group):

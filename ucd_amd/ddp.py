@@ -33,6 +33,8 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch.optim.optimizer import register_optimizer_step_post_hook
 
+from . import switches as _switches
+
 
 def _view_like(buf, p):
     """View of the flat slice ``buf`` with the shape AND strides of ``p`` (channels-last 4-D weights keep their
@@ -55,13 +57,16 @@ class GradReducer:
         # parameter's slot in the fp32 bucket is filled from the bf16 gradient when the bucket completes
         self.shadow_of = shadow_of or {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # UCD_FORCE_COLLECTIVES=1 (bench.py --force_dist): a one-rank process group still launches every bucket's all-reduce - the
+        # multi-rank code path, RCCL calls included, on a box with one GPU
+        self.collective = self.world > 1 or (dist.is_initialized() and _switches.get("UCD_FORCE_COLLECTIVES") in ("1", "ddp"))
         # gradient buckets get a communicator of their own: they are launched from autograd hooks on a side
         # stream while InPlaceABNSync issues its statistics collectives on the compute stream - two independent
         # orderings that must not share one RCCL communicator
-        if group is None and self.world > 1 and dist.get_backend() == "nccl":
+        if group is None and self.collective and dist.get_backend() == "nccl":
             group = dist.new_group(backend="nccl")
         self.group = group
-        self.use_avg = self.world > 1 and dist.get_backend(group) == "nccl"   # RCCL reduces with AVG; gloo sums
+        self.use_avg = self.collective and dist.get_backend(group) == "nccl"   # RCCL reduces with AVG; gloo sums
         self.wire_dtype = wire_dtype
         params = [p for p in params if p.requires_grad]
         # ABN layers whose backward kernels write [d bias | d weight] straight into gradient storage (ucd_amd/abn.py,
@@ -86,7 +91,16 @@ class GradReducer:
         self.params = params
         self.device = params[0].device if params else torch.device("cpu")
         self.on_gpu = self.device.type == "cuda"
-        self.overlap = overlap and self.on_gpu and self.world > 1
+        self.overlap = overlap and self.on_gpu and self.collective
+        # fp32 buckets on an RCCL process group go through a library-owned communicator of their own (ucd_amd/comm.py:
+        # ucd_comm_all_reduce_sum on the reducer's stream, then 1 / world) instead of c10d's ProcessGroupNCCL: the same call
+        # path as the SyncBN exchanges, and one that a hipGraph capture of the whole step takes (c10d's asynchronous work
+        # objects on a side stream crash hipStreamEndCapture on this stack - measured with bench.py --force_dist ddp)
+        self.direct = None
+        if (self.collective and self.on_gpu and wire_dtype in (None, torch.float32) and dist.get_backend(group) == "nccl"
+                and _switches.get("UCD_DIRECT_RCCL", "1") != "0" and _switches.get("UCD_DDP_DIRECT", "1") != "0"):
+            from .comm import direct_comm
+            self.direct = direct_comm(self.group)
         self.stream = torch.cuda.Stream(self.device) if self.overlap else None
         self.buckets = []
         self._bucket_of = {}
@@ -225,7 +239,7 @@ class GradReducer:
                 torch._foreach_copy_(dst, src)
             for _, holder in b.fed:
                 holder.grad = None
-        if self.world > 1:
+        if self.collective:
             self._launch(b)
 
     def _event(self, key):
@@ -245,8 +259,20 @@ class GradReducer:
             self._reduce(b)
         self._inflight.append(b)
 
+    def _direct_sum(self, buf):
+        """In-place average of an fp32 buffer over the ranks on the CURRENT stream (library-owned communicator)."""
+        from . import hip
+        hip._check(hip.load().ucd_comm_all_reduce_sum(self.direct.handle, hip.ptr(buf), buf.numel(), hip.stream()),
+                   "ucd_comm_all_reduce_sum")
+        if self.world > 1:
+            buf.mul_(1.0 / self.world)
+
     def _reduce(self, b):
         buf = b.flat
+        if self.direct is not None and buf.dtype == torch.float32:
+            self._direct_sum(buf)
+            b.work = None
+            return
         if self.wire_dtype is not None and self.wire_dtype != buf.dtype:
             b.wire = buf.to(self.wire_dtype)
             buf = b.wire
@@ -280,7 +306,7 @@ class GradReducer:
                         self.direct_flat[o:o + C].copy_(g)
                         p.grad = self.direct_flat[o:o + C]
                 off += 2 * C
-        if self.world == 1:
+        if not self.collective:
             self._reset_step()
             return
         if self.direct_flat is not None:                        # kernel-written ABN parameter gradients: one small reduce
@@ -293,6 +319,8 @@ class GradReducer:
             else:
                 self._reduce_flat(self.direct_flat)
         for b in self._inflight:
+            if b.work is None:                                  # direct path: stream-ordered, nothing to wait for on the host
+                continue
             if self.overlap:
                 with torch.cuda.stream(self.stream):
                     b.work.wait()
@@ -320,6 +348,9 @@ class GradReducer:
             b.done = False
 
     def _reduce_flat(self, flat):
+        if self.direct is not None and flat.dtype == torch.float32:
+            self._direct_sum(flat)
+            return
         if self.use_avg:
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
         else:

@@ -31,6 +31,8 @@ DEFAULTS = {
     "UCD_STEP_GRAPH": "auto",      # whole-step hipGraph: auto = world 1 only, 1 = always try, 0 = never
     "UCD_TEACHER_OVERLAP": "1",    # frozen teacher on a side stream beside the student's forward (0: in front of it, same stream)
     "UCD_DIRECT_RCCL": "1",        # library-owned RCCL communicator for SyncBN
+    "UCD_DDP_DIRECT": "1",         # gradient buckets over a library-owned RCCL communicator (0: torch.distributed all_reduce)
+    "UCD_FORCE_COLLECTIVES": "0",  # 1 | abn | ddp: a one-rank process group still issues every SyncBN / gradient collective (bench.py --force_dist)
 }
 
 _cache: dict = {}
