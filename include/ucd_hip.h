@@ -103,7 +103,10 @@ int ucd_abn_eval_params(const float* weight, const float* running_var, float eps
 
 /* y = act((x + plane_bias - mean) * scale + shift + residual); shift is the affine bias (NULL = 0);
  * y may alias x (in place) or be a channel slice of a wider buffer (ld_y > C); residual / plane_bias
- * may be NULL.  Subtracting the mean first keeps the result exact when x is close to it. */
+ * may be NULL.  Subtracting the mean first keeps the result exact when x is close to it.
+ * bf16 tensors without a plane bias under leaky_relu / identity (this call, ucd_abn_bwd_reduce and ucd_abn_bwd_apply) run on
+ * packed fp32 pairs (round 4: same operations in the same order, bit-identical, 2 - 3x faster on the 13 - 27 MB layers);
+ * UCD_ABN_GENERIC=1 in the environment (read once per process) keeps the per-element kernels everywhere. */
 int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r,
                   int dtype, int M, int C, const float* plane_bias, int HW,
                   const float* mean, const float* scale, const float* shift, int act, float slope,

@@ -20,6 +20,8 @@ def per_kernel(path, counter):
                 k = "wgrad3x3_kernel"
             if k == "sgd_step_dev_kernel":
                 k = "sgd_step_kernel"
+            if k in ("abn_apply_fast_kernel", "abn_bwd_apply_fast_kernel", "abn_bwd_reduce_fast_kernel"):   # round 4: the packed-math forms
+                k = k.replace("_fast", "")
             if k == "wgrad_kernel":
                 k = "wgrad3x3_kernel" if re.search(r"wgrad_kernel<\d+, \d+, true", r["Kernel_Name"]) else "wgrad1x1_kernel"
             agg[k].append(float(r["Counter_Value"]))

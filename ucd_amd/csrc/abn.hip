@@ -884,7 +884,7 @@ int check_common(const char* fn, int dtype, int M, int C, int act) {
 // bf16 tensors without a plane bias under leaky_relu / identity take the packed-math kernels (UCD_ABN_GENERIC=1: the per-element
 // kernels everywhere - the A/B switch of tools/abn_bench.py)
 inline bool fast_path(int dtype, const float* plane_bias, int act_kind) {
-  static const bool generic = getenv("UCD_ABN_GENERIC") != nullptr;
+  static const bool generic = getenv("UCD_ABN_GENERIC") != nullptr && getenv("UCD_ABN_GENERIC")[0] == '1';
   return !generic && dtype == UCD_BF16 && !plane_bias && act_kind != UCD_ACT_ELU;
 }
 

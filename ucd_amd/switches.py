@@ -27,6 +27,7 @@ DEFAULTS = {
     "UCD_CONV_PIPE": "auto",       # pipeline of the GEMM kernel: auto | 2x64 | 4x32 | 4x64 | lw32 | lw64 | lw256 (read by the library)
     "UCD_STEM_FOLD": "1",          # stem norm + max-pool as one pass
     "UCD_ABN_NODE": "1",           # C++ autograd nodes
+    "UCD_ABN_GENERIC": "0",        # 1: per-element ABN apply / backward kernels instead of the packed-pair forms (read by the library)
     "UCD_SGD": "hip",              # one-launch optimiser step (torch: torch's fused SGD)
     "UCD_STEP_GRAPH": "auto",      # whole-step hipGraph: auto = world 1 only, 1 = always try, 0 = never
     "UCD_TEACHER_OVERLAP": "1",    # frozen teacher on a side stream beside the student's forward (0: in front of it, same stream)
