@@ -1034,3 +1034,76 @@ def test_every_pipeline_form_of_the_gemm_kernel_is_exact_on_integers(pipe):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _PIPE_CHILD % {"root": root}], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (pipe, r.stdout[-500:], r.stderr[-1500:])
+
+_BN64_VS_BN128 = r"""
+import sys, torch
+from ucd_amd import hip
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+outs = {}
+cases = [(2178, 256, 256, None), (2178, 1024, 256, None), (2178, 256, 256, (33, 33, 2)), (2178, 512, 512, None), (8450, 512, 128, None),
+         (8450, 128, 128, (65, 65, 1)), (2178, 2048, 256, (33, 33, 12)), (2, 2048, 256, None)]
+for (M, K, N, conv3) in cases:
+    a = (torch.randn(M, K, device=dev) * 0.3 + 1.0).abs().bfloat16()          # post-activation-like: positive, mean >> spread
+    KK = 9 * K if conv3 else K
+    w = (torch.randn(N, KK, device=dev) * (1.0 / KK) ** 0.5 + 0.5 / KK).bfloat16()
+    mean = torch.randn(N, device=dev) * 0.1; scale = torch.rand(N, device=dev) + 0.5; shift = torch.randn(N, device=dev) * 0.1
+    invstd = torch.rand(N, device=dev) + 0.5
+    res = torch.randn(M, N, device=dev).bfloat16(); z3 = torch.randn(M, N, device=dev).bfloat16()
+    tiles = hip.conv1x1_row_tiles(M)
+    kw = dict(conv3=conv3) if conv3 else {}
+    r = {}
+    wide = torch.zeros(M, 640, device=dev, dtype=torch.bfloat16)              # the product lands in a channel slice of a wider buffer
+    hip.conv1x1(a, w, wide[:, 128:128 + N], **kw); r["plain_slice"] = wide.clone()
+    y0 = res.clone(); hip.conv1x1(a, w, y0, accumulate=True, **kw); r["accumulate"] = y0
+    y1 = torch.empty_like(res); hip.conv1x1(a, w, y1, out_mode=1, out_norm=(mean, scale, shift, None, 1, 0.01), residual=res, **kw); r["affine_res"] = y1
+    p2 = hip.conv1x1_stats_partial(M, N, dev); y2 = torch.empty_like(res)
+    hip.conv1x1(a, w, y2, out_mode=2, partial=p2, **kw); r["stats_y"] = y2; r["stats_partial"] = p2.clone()
+    buf = torch.zeros(6 * N, device=dev)
+    hip.conv1x1_stats_finalize(p2, M, N, torch.ones(N, device=dev), torch.zeros(N, device=dev), torch.ones(N, device=dev), 0.1, 1e-5, buf)
+    r["mean_invstd"] = buf[3 * N:5 * N].clone()
+    r["true_mean_invstd"] = torch.cat([y2.float().mean(0), 1.0 / torch.sqrt(y2.float().var(0, unbiased=False) + 1e-5)])
+    p3 = torch.zeros(tiles, 2, N, device=dev); y3 = torch.empty_like(res)
+    hip.conv1x1(a, w, y3, out_mode=3, out_norm=(mean, scale, shift, invstd, 1, 0.01), residual=res, partial=p3, **kw); r["link_y"] = y3; r["link_partial"] = p3.clone()
+    if not conv3:
+        p4 = torch.zeros(tiles, 2, N, device=dev); y4 = res.clone()
+        hip.conv1x1(a, w, y4, out_mode=4, out_norm=(mean, None, None, invstd, 1, 0.01), residual=z3, side2=res, partial=p4, accumulate=True)
+        r["block_y"] = y4; r["block_partial"] = p4.clone()
+    torch.cuda.synchronize()
+    outs[(M, K, N, conv3)] = {k: v.float().cpu() for k, v in r.items()}
+torch.save(outs, sys.argv[1])
+"""
+
+
+def test_small_grids_on_64_column_tiles_equal_the_128_column_tiles(tmp_path):
+    """Round 4: launches of at most 128 (128 x 128) tiles - the 3 - 6 images per GPU of the multi-GPU split - run on 128 x 64 tiles
+    (``UCD_CONV_BN64_TILES``, csrc/conv1x1.hip).  Every output mode (plain into a channel slice, accumulate, affine + residual,
+    statistics, backward link, block link; 1x1, 3x3, a dilated ASPP branch, a two-row product) must give the SAME bf16 outputs bit for
+    bit as the 128-column tiles; the per-tile partial sums are taken in a different order (agreement to fp32 rounding), and the
+    finalised mean / invstd of both agree with torch's to 1e-5.  Two child processes: the switch is read once per process."""
+    import subprocess
+    import sys
+    script = tmp_path / "bn64_vs_bn128.py"
+    script.write_text(_BN64_VS_BN128)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode, v in (("bn64", "128"), ("bn128", "0")):
+        env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), UCD_CONV_BN64_TILES=v)
+        env.pop("UCD_CONV_PIPE", None)
+        out = tmp_path / f"{mode}.pt"
+        subprocess.run([sys.executable, str(script), str(out)], env=env, check=True, timeout=600)
+        res[mode] = torch.load(out)
+    for case, a in res["bn64"].items():
+        b = res["bn128"][case]
+        for name in a:
+            if name.endswith("partial"):
+                rel = ((a[name] - b[name]).norm() / (b[name].norm() + 1e-30)).item()
+                assert rel < 1e-6, (case, name, rel)
+            elif name == "mean_invstd":
+                N = a[name].numel() // 2
+                t = a["true_mean_invstd"]
+                for got in (a[name], b[name]):
+                    assert ((got[N:] - t[N:]).abs() / t[N:]).max().item() < 1e-5, (case, "invstd")
+                    assert ((got[:N] - t[:N]).abs() * t[N:]).max().item() < 1e-5, (case, "mean")
+            elif name != "true_mean_invstd":
+                assert torch.equal(a[name], b[name]), (case, name, int((a[name] != b[name]).sum()))

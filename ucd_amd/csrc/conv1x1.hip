@@ -954,7 +954,13 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   a.iH = d->H; a.iW = d->W; a.dil = d->dilation;
   a.tiles128 = ceil_div(d->M, 128);
   a.stride = stride; a.oW = oW > 0 ? oW : 1; a.ohw = oH * oW > 0 ? oH * oW : 1; a.a_rows = (int)a_rows;
-  const int BN = d->N % 128 == 0 ? 128 : 64;
+  // few row tiles (3 - 6 images per GPU, the multi-GPU split): 64-column tiles double the workgroups of a launch that would leave
+  // more than half of the CUs without one - a 52-workgroup 3x3 launch is bound by the 36 x 16 MFMAs of ONE workgroup per CU, not by
+  // its fills (a fourth LDS stage changed nothing: 18.4 vs 18.4 us).  3 images: 3x3 256 -> 256 18.6 -> 14.0 us, ASPP 102.8 -> 81.4,
+  // 1x1 2048 -> 256 15.5 -> 11.1; grids of 129 .. 256 tiles measured level or slower (256 -> 1024: 6.4 -> 7.2).  Same products bit
+  // for bit, per-tile statistics equal to fp32 rounding (tests/test_conv1x1_fused_gpu.py).  UCD_CONV_BN64_TILES overrides (0: off).
+  static const int bn64_below = getenv("UCD_CONV_BN64_TILES") ? atoi(getenv("UCD_CONV_BN64_TILES")) : 128;
+  const int BN = (d->N % 128 == 0 && (long long)ceil_div(d->M, kBM) * (d->N / 128) > bn64_below) ? 128 : 64;
   a.tiles_m = ceil_div(d->M, kBM); a.tiles_n = d->N / BN;
   const int grid = ceil_div(a.tiles_m, 8) * 8 * a.tiles_n;
   // 3x3 with a grid that leaves a CU one or two workgroups (N = 256 at 33^2: 410; tools/conv3x3_probe.py): the

@@ -25,6 +25,8 @@ DEFAULTS = {
     "UCD_OWN_STEM": "1",           # 7x7/2 stem forward on csrc/stem.hip
     "UCD_WGRAD3": "1",             # 3x3 weight gradients: one kernel row per workgroup (0: the 9-tap form; read by the library)
     "UCD_CONV_PIPE": "auto",       # pipeline of the GEMM kernel: auto | 2x64 | 4x32 | 4x64 | lw32 | lw64 | lw256 (read by the library)
+    "UCD_CONV_BN64_TILES": "128",  # launches of at most this many 128 x 128 tiles run on 128 x 64 tiles (0: never; read by the library)
+    "UCD_CONV3_MIN_ROWS": "8192",  # stand-alone 3x3 layers (ASPP) below this many rows stay on the library path
     "UCD_STEM_FOLD": "1",          # stem norm + max-pool as one pass
     "UCD_ABN_NODE": "1",           # C++ autograd nodes
     "UCD_ABN_GENERIC": "0",        # 1: per-element ABN apply / backward kernels instead of the packed-pair forms (read by the library)
