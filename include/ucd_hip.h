@@ -467,7 +467,9 @@ typedef struct ucd_conv1x1_desc {
  * per CU (full grids), double buffer at two (<= 640 tiles, out_mode 4), and since round 4 the loader-wave forms - MFMA waves that
  * only multiply and loader waves that only stage - on 128-row tiles for grids of <= 256 tiles and on 256-row tiles for grids of
  * 257 .. 640 tiles that fit the chip as 256-row tiles.  The environment variable UCD_CONV_PIPE (read once per process: 2x64, 4x32,
- * 4x64, lw32, lw64, lw64x2, lw256) forces one form for every double-buffer-eligible launch; it exists for probes and A/B runs. */
+ * 4x64, lw32, lw64, lw64x2, lw256) forces one form for every double-buffer-eligible launch; it exists for probes and A/B runs.
+ * Launches of at most 128 (128 x 128) tiles (3 - 6 images per GPU) run on 128 x 64 tiles - same outputs bit for bit, twice the
+ * workgroups; UCD_CONV_BN64_TILES (read once per process) sets that bound, 0 = never. */
 int ucd_conv1x1_row_tiles(int M);
 size_t ucd_conv1x1_stats_partial_bytes(int M, int C);
 int ucd_conv1x1(const ucd_conv1x1_desc* desc, ucd_stream_t stream);
