@@ -1107,3 +1107,32 @@ def test_small_grids_on_64_column_tiles_equal_the_128_column_tiles(tmp_path):
                     assert ((got[:N] - t[:N]).abs() * t[N:]).max().item() < 1e-5, (case, "mean")
             elif name != "true_mean_invstd":
                 assert torch.equal(a[name], b[name]), (case, name, int((a[name] != b[name]).sum()))
+
+@pytest.mark.parametrize("B,C,h,w,Ct", [(2, 256, 33, 33, 21), (3, 256, 17, 19, 16), (2, 256, 9, 9, 64), (1, 128, 5, 7, 6)])
+def test_classifier_heads_on_the_own_kernels_match_the_convolution(B, C, h, w, Ct):
+    """The classifier heads (segmentation_module.py:72-74, 102-105: Ct = 16 + 5 ... classes, off the kernels' 64-channel grid) as
+    one product on a zero-padded 64-row weight (``_HeadProduct``): logits, input gradient, weight gradient (fp32) and bias gradient
+    against the fp32 convolution on the same bf16 inputs, at bf16 resolution."""
+    from ucd_amd.segmentation_module import _HeadProduct, _own_heads_ok
+    dev = torch.device("cuda:0")
+    x = (synth.t_normal(70 + Ct, (B, C, h, w), stream=1) * 0.8 + 0.2).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wt = (synth.t_normal(71 + Ct, (Ct, C, 1, 1), stream=2) * C ** -0.5).to(dev)
+    bias = (synth.t_normal(72 + Ct, (Ct,), stream=3) * 0.3).to(dev)
+    g = synth.t_normal(73 + Ct, (B, Ct, h, w), stream=4).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    assert _own_heads_ok(x, wt)
+    xa = x.clone().requires_grad_(True); wa = wt.clone().requires_grad_(True); ba = bias.clone().requires_grad_(True)
+    y = _HeadProduct.apply(xa, wa, ba)
+    assert y.shape == (B, Ct, h, w) and y.dtype == torch.bfloat16 and y.is_contiguous(memory_format=torch.channels_last)
+    y.backward(g)
+    xr = x.float().requires_grad_(True); wr = wt.bfloat16().float().requires_grad_(True); br = bias.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    yr.backward(g.float())
+    rel = lambda a, b: ((a.float() - b.float()).norm() / (b.float().norm() + 1e-30)).item()
+    assert rel(y, yr) < 4e-3, rel(y, yr)                       # one bf16 rounding of the output
+    assert rel(xa.grad, xr.grad) < 4e-3, rel(xa.grad, xr.grad)
+    assert wa.grad.dtype == torch.float32 and rel(wa.grad, wr.grad) < 2e-3, rel(wa.grad, wr.grad)
+    assert rel(ba.grad, br.grad) < 1e-4, rel(ba.grad, br.grad)
+    # a frozen head: no weight / bias gradient asked for
+    xa2 = x.clone().requires_grad_(True)
+    _HeadProduct.apply(xa2, wt, bias).backward(g)
+    assert torch.equal(xa2.grad, xa.grad)

@@ -23,10 +23,72 @@ import torch.nn.functional as F
 
 from . import backbone as models
 from . import hip
+from . import switches as _switches
 from .abn import ABN, InPlaceABN, InPlaceABNSync
 from .blocks import DeeplabV3
 
 _NORMS = {"iabn_sync": InPlaceABNSync, "iabn": InPlaceABN, "abn": ABN}
+
+
+class _HeadProduct(torch.autograd.Function):
+    """All classifier heads as ONE product on the own GEMM kernels: ``logits[M, Ct] = x[M, C] . w[Ct, C]^T + b``.
+
+    The heads are off the 64-channel grid of the kernels (16 + 5 classes at VOC 15-5, 101 + 50 at ADE), so the library served
+    them (a CK convolution forward, ``convolution_backward`` + a strided ``sum`` for the bias gradient: 0.3 ms per step).  Here the
+    weight is zero-padded to 64 rows: forward = ``ucd_conv1x1`` out_mode 1 with mean 0, scale 1, shift = bias (``(v - 0) * 1 + b``:
+    exactly the bias add in fp32 before the one rounding to bf16) into an [M, 64] buffer whose first Ct columns are the logits;
+    backward = the input gradient as a K = 64 product on the transposed padded weight, the weight gradient through
+    ``ucd_conv_wgrad`` straight into fp32, the bias gradient as per-image column sums (``ucd_plane_sum``).  bf16 GPU tensors with
+    C a multiple of 64 and Ct <= 64 only (``UCD_OWN_HEADS=0`` keeps the library); everything else goes to ``F.conv2d``."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        B, C, h, wd = x.shape
+        Ct = w.shape[0]
+        M = B * h * wd
+        dev = x.device
+        rows = x.permute(0, 2, 3, 1).reshape(M, C)                    # a view of the channels-last map
+        wp = torch.zeros(64, C, dtype=torch.bfloat16, device=dev)
+        wp[:Ct] = w.detach().reshape(Ct, C)
+        shift = torch.zeros(64, dtype=torch.float32, device=dev)
+        if b is not None:
+            shift[:Ct] = b.detach()
+        zero, one = torch.zeros(64, dtype=torch.float32, device=dev), torch.ones(64, dtype=torch.float32, device=dev)
+        y = torch.empty(M, 64, dtype=torch.bfloat16, device=dev)
+        hip.conv1x1(rows, wp, y, out_mode=1, out_norm=(zero, one, shift, None, hip.ACT_IDENTITY, 1.0))
+        ctx.save_for_backward(rows, wp)
+        ctx.meta = (B, C, h, wd, Ct, w.dtype, None if b is None else b.dtype)
+        # dense channels-last [B, Ct, h, w] like the convolution's own output
+        return y[:, :Ct].contiguous().view(B, h, wd, Ct).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, wp = ctx.saved_tensors
+        B, C, h, wd, Ct, wdt, bdt = ctx.meta
+        M = B * h * wd
+        dev = g.device
+        gp = torch.zeros(M, 64, dtype=torch.bfloat16, device=dev)
+        gp[:, :Ct] = g.permute(0, 2, 3, 1).reshape(M, Ct)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxr = torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+            hip.conv1x1(gp, wp.t().contiguous(), dxr)                  # [M, 64] . [C, 64]^T
+            dx = dxr.view(B, h, wd, C).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[1]:
+            dw32 = torch.empty(64, C, dtype=torch.float32, device=dev)
+            hip.conv_wgrad(gp, rows, dw32=dw32)
+            dw = dw32[:Ct].reshape(Ct, C, 1, 1).to(wdt)
+        if bdt is not None and ctx.needs_input_grad[2]:
+            per_image = torch.empty(B, 64, dtype=torch.float32, device=dev)
+            hip.plane_sum(gp, 64, B, h * wd, 64, 1.0, per_image)
+            db = per_image.sum(0)[:Ct].to(bdt)
+        return dx, dw, db
+
+
+def _own_heads_ok(x, w):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 64 == 0 and w.shape[0] <= 64
+            and x.is_contiguous(memory_format=torch.channels_last) and _switches.get("UCD_OWN_HEADS", "1") != "0"
+            and _switches.get("UCD_FUSED_CONV1X1", "1") != "0")
 
 
 def make_model(opts, classes=None):
@@ -109,11 +171,12 @@ class IncrementalSegmentationModule(nn.Module):
         x_b = self.body(x)
         x_pl = self.head(x_b)
         if len(self.cls) == 1:
-            x_o = self.cls[0](x_pl)
+            c0 = self.cls[0]
+            x_o = _HeadProduct.apply(x_pl, c0.weight, c0.bias) if _own_heads_ok(x_pl, c0.weight) else c0(x_pl)
         else:  # all heads in one 1x1 convolution
             w = torch.cat([m.weight for m in self.cls], dim=0)
             b = torch.cat([m.bias for m in self.cls], dim=0)
-            x_o = F.conv2d(x_pl, w, b)
+            x_o = _HeadProduct.apply(x_pl, w, b) if _own_heads_ok(x_pl, w) else F.conv2d(x_pl, w, b)
         return x_o, x_b, x_pl
 
     def init_new_classifier(self, device):

@@ -22,6 +22,7 @@ DEFAULTS = {
     "UCD_OWN3X3_WIDE": "1",        # 0: the 512 -> 512 3x3 layers on MIOpen
     "UCD_OWN_STRIDED": "1",        # strided conv2 / proj_conv on the own kernels
     "UCD_OWN_WGRAD": "1",          # weight gradients on csrc/wgrad.hip
+    "UCD_OWN_HEADS": "1",          # classifier heads (Ct <= 64) on the own GEMM kernels through a zero-padded 64-row weight (0: library)
     "UCD_OWN_STEM": "1",           # 7x7/2 stem forward on csrc/stem.hip
     "UCD_WGRAD3": "1",             # 3x3 weight gradients: one kernel row per workgroup (0: the 9-tap form; read by the library)
     "UCD_CONV_PIPE": "auto",       # pipeline of the GEMM kernel: auto | 2x64 | 4x32 | 4x64 | lw32 | lw64 | lw256 (read by the library)
