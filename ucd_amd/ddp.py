@@ -96,6 +96,7 @@ class GradReducer:
         # ucd_comm_all_reduce_sum on the reducer's stream, then 1 / world) instead of c10d's ProcessGroupNCCL: the same call
         # path as the SyncBN exchanges, and one that a hipGraph capture of the whole step takes (c10d's asynchronous work
         # objects on a side stream crash hipStreamEndCapture on this stack - measured with bench.py --force_dist ddp)
+        self._late_dst, self._late_src = [], []                 # world 1: bf16 -> fp32 gradient copies deferred to finish()
         self.direct = None
         if (self.collective and self.on_gpu and wire_dtype in (None, torch.float32) and dist.get_backend(group) == "nccl"
                 and _switches.get("UCD_DIRECT_RCCL", "1") != "0" and _switches.get("UCD_DDP_DIRECT", "1") != "0"):
@@ -235,8 +236,13 @@ class GradReducer:
                 if holder.grad is not None:
                     dst.append(view32)
                     src.append(holder.grad)
-            if src:
-                torch._foreach_copy_(dst, src)
+            if src and (self.collective or _switches.get("UCD_DDP_LATE_COPY", "1") == "0"):
+                torch._foreach_copy_(dst, src)                   # before the bucket's reduction starts
+            elif src:
+                # a single process reduces nothing: the widening copies of ALL buckets go out as one multi-tensor launch at the end of
+                # the backward (finish) instead of one per bucket (nine launches of ~25 us, mostly fixed cost, at the bench size)
+                self._late_dst += dst
+                self._late_src += src
             for _, holder in b.fed:
                 holder.grad = None
         if self.collective:
@@ -307,6 +313,9 @@ class GradReducer:
                         p.grad = self.direct_flat[o:o + C]
                 off += 2 * C
         if not self.collective:
+            if self._late_src:
+                torch._foreach_copy_(self._late_dst, self._late_src)
+                self._late_dst, self._late_src = [], []
             self._reset_step()
             return
         if self.direct_flat is not None:                        # kernel-written ABN parameter gradients: one small reduce

@@ -35,6 +35,7 @@ DEFAULTS = {
     "UCD_STEP_GRAPH": "auto",      # whole-step hipGraph: auto = world 1 only, 1 = always try, 0 = never
     "UCD_TEACHER_OVERLAP": "1",    # frozen teacher on a side stream beside the student's forward (0: in front of it, same stream)
     "UCD_DIRECT_RCCL": "1",        # library-owned RCCL communicator for SyncBN
+    "UCD_DDP_LATE_COPY": "1",      # world 1: the bf16 -> fp32 gradient copies of all buckets as ONE launch at the end of the backward
     "UCD_DDP_DIRECT": "1",         # gradient buckets over a library-owned RCCL communicator (0: torch.distributed all_reduce)
     "UCD_FORCE_COLLECTIVES": "0",  # 1 | abn | ddp: a one-rank process group still issues every SyncBN / gradient collective (bench.py --force_dist)
 }
