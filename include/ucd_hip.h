@@ -135,6 +135,26 @@ int ucd_abn_bwd_apply(const void* x, int ld_x, const void* dy, int ld_dy, const 
                       const float* weight, const float* sums, float count, int frozen,
                       int act, float slope, ucd_stream_t stream);
 
+/* Apply pass that FINALISES the statistics itself (round 5, bf16 activations, leaky_relu / identity): acc[0..C) = sum (x - k),
+ * acc[C..2C) = sum (x - k)^2 over `count` rows (the atomic accumulator of ucd_conv1x1's statistics epilogue, all-reduced over the
+ * ranks under SyncBN; `reps` replicas of [2 C], summed here), kshift[c] = k.  Every workgroup derives mean / invstd / scale of its channels in its prologue (2C loads);
+ * the first row band also stores them to mean / invstd / scale (saved for the backward) and updates the running statistics
+ * (momentum, unbiased variance) - what ucd_conv1x1_stats_finalize did in a launch of its own.  flags: UCD_NORM_ABS_GAMMA. */
+int ucd_abn_apply_stats(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r, int M, int C,
+                        const float* acc, int reps, const float* kshift, float count, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                        float* scale, int act, float slope, ucd_stream_t stream);
+
+/* Backward apply on RAW sums (round 5, bf16): sums[0..C) = sum dz, sums[C..2C) = sum dz * xhat as accumulated by ucd_conv1x1's
+ * out_mode 3 / 4 epilogues with stat_acc (no sign applied, all-reduced over the ranks under SyncBN; count = rows over all ranks).
+ * grad_out (optional): [d bias | d weight] of the layer is written by the first row band from grad_sums (this rank's sums; NULL:
+ * sums; both `reps` replicas of [2 C], summed in the prologue), d weight with the sign of weight under UCD_NORM_ABS_GAMMA - what ucd_abn_reduce_partials did in a launch of its own.
+ * Arguments otherwise as ucd_abn_bwd_apply (training statistics; identity / leaky_relu). */
+int ucd_abn_bwd_apply_raw(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, void* dx, int ld_dx,
+                          void* dz_out, int ld_dz, int M, int C, const float* mean, const float* invstd, const float* scale,
+                          const float* shift, const float* weight, const float* sums, const float* grad_sums, int reps,
+                          float* grad_out, float count, int act, float slope, ucd_stream_t stream);
+
 /* Whole-layer forward in one call (single process): training != 0 -> ucd_abn_stats_finalize + ucd_abn_apply with
  * buf = [sums(2C) | kshift(C) | mean(C) | invstd(C) | scale(C)] (kept for the backward); training == 0 ->
  * running statistics, with [invstd | scale] taken from eval_consts when given (frozen teacher) or computed into buf. */
@@ -460,6 +480,20 @@ typedef struct ucd_conv1x1_desc {
    * stride 2, :79 proj_conv 1x1 stride 2).  a is the [B, H, W, K] map, y the [B, OH, OW, N] one with OH = (H - 1) / stride + 1
    * (padding 0 for taps <= 1, padding = dilation for taps = 9), M = B*OH*OW; out_mode 0, 1 or 2, no input transform. */
   int stride;
+  /* Atomic statistics (round 5; NULL: the per-tile partial rows above).  stat_acc != NULL: out_mode 2 / 3 / 4 add their
+   * per-channel column sums with fp32 atomics into stat_acc[0..N) / stat_acc[N..2N) (zeroed by the caller before the launch; one
+   * accumulator per layer and direction, see ucd_abn_apply_stats / ucd_abn_bwd_apply_raw, which finalise it in their prologue - no
+   * second-stage reduction launch).  out_mode 2 then sums about the caller's shift stat_shift[n] (any value near the channel mean:
+   * the layer's running mean; NOT the tile's first row) and row tile 0 stores a snapshot of that shift to partial[0..N) (the consumer
+   * reads the snapshot, so the running mean may be updated meanwhile).  stat_acc2 (optional): a second accumulator receiving the same
+   * adds (SyncBN: one is all-reduced, the other stays this rank's parameter gradient).  Sums are order dependent: results differ
+   * in the last bits from run to run. */
+  float* stat_acc;  const float* stat_shift;  float* stat_acc2;
+  /* stat_rep (0 / 1: one): REPLICAS of the accumulator, a power of two - row tile t adds into replica t % stat_rep (stat_acc holds
+   * stat_rep x [2 N] floats); adds to one address are serialised at the memory side (~25 ns each), so a launch of hundreds of row
+   * tiles spreads them (ucd_conv1x1_stat_replicas(M) is the library's choice: <= 64 adds per address) and the finalising apply pass
+   * sums the replicas in its prologue. */
+  int stat_rep;
 } ucd_conv1x1_desc;
 
 /* Kernel forms behind ucd_conv1x1 (chosen per launch by the grid; results do not depend on the choice - tests/
@@ -471,6 +505,7 @@ typedef struct ucd_conv1x1_desc {
  * Launches of at most 128 (128 x 128) tiles (3 - 6 images per GPU) run on 128 x 64 tiles - same outputs bit for bit, twice the
  * workgroups; UCD_CONV_BN64_TILES (read once per process) sets that bound, 0 = never. */
 int ucd_conv1x1_row_tiles(int M);
+int ucd_conv1x1_stat_replicas(int M);   /* replicas of an atomic statistics accumulator for a product of M rows (1 .. 64) */
 size_t ucd_conv1x1_stats_partial_bytes(int M, int C);
 int ucd_conv1x1(const ucd_conv1x1_desc* desc, ucd_stream_t stream);
 

@@ -1022,6 +1022,209 @@ print("ok")
 """
 
 
+@pytest.mark.parametrize("M,K,N,sp", [(26136, 1024, 256, None), (26136, 256, 1024, None), (26136, 256, 256, (33, 33, 1)),
+                                      (101400, 128, 512, None), (3267, 512, 128, None), (300, 64, 64, None)])
+def test_atomic_statistics_epilogues_and_the_finalising_apply_passes(M, K, N, sp):
+    """Round 5: the statistics epilogue (out_mode 2) and the link epilogues (out_mode 3 / 4) add their column sums with fp32 atomics
+    into ONE zeroed [2 N] accumulator per layer (``stat_acc``) instead of per-tile rows, and the apply passes finalise it in their
+    prologue (``ucd_abn_apply_stats`` / ``ucd_abn_bwd_apply_raw``: no tile_stats_reduce / reduce_bands launch; SURVEY K1,
+    modules/residual.py:51-73).  Held against (a) float64 statistics of the stored map, (b) the deterministic per-tile path of the
+    same library: same stored products bit for bit, mean / invstd / running statistics / sums to fp32 rounding (1e-6 relative - the
+    atomic sums are order dependent in the last bits), dx of the backward apply equal when fed the same sums."""
+    from ucd_amd import hip
+    g = torch.Generator(DEV).manual_seed(M + 3 * K + N)
+    taps = 9 if sp else 1
+    a = (torch.randn(M, K, device=DEV, generator=g) * 1.3 + 0.2).bfloat16()
+    w = (torch.randn(N, taps * K, device=DEV, generator=g) * (2.0 / (K * taps)) ** 0.5).bfloat16()
+    gamma = (torch.rand(N, device=DEV, generator=g) - 0.3)                      # negative entries: the |gamma| + eps convention
+    beta = torch.randn(N, device=DEV, generator=g) * 0.1
+    shift = torch.randn(N, device=DEV, generator=g) * 0.3                       # the common shift (the layer's running mean)
+    res = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    # ---- deterministic path
+    z0 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    part = hip.conv1x1_stats_partial(M, N, DEV)
+    hip.conv1x1(a, w, z0, out_mode=2, partial=part, conv3=sp)
+    buf0 = torch.zeros(6 * N, device=DEV)
+    rm0, rv0 = shift.clone(), torch.ones(N, device=DEV)
+    hip.conv1x1_stats_finalize(part, M, N, gamma, rm0, rv0, 0.1, 1e-5, buf0, None, hip.NORM_ABS_GAMMA)
+    y0 = torch.empty_like(z0)
+    hip.abn_apply(z0, N, y0, N, res, N, M, N, None, 1, buf0[3 * N:4 * N], buf0[5 * N:], beta, hip.ACT_LEAKY_RELU | hip.NORM_ABS_GAMMA, 0.01)
+    # ---- atomic path
+    z1 = torch.empty_like(z0)
+    R = hip.load().ucd_conv1x1_stat_replicas(M)               # row tile t adds into replica t % R: <= 64 adds per address
+    assert R >= 1 and (R & (R - 1)) == 0 and (hip.conv1x1_row_tiles(M) <= 64 * R or R == 64)
+    acc = torch.zeros(R, 2 * N, device=DEV)
+    buf1 = torch.zeros(6 * N, device=DEV)
+    rm1, rv1 = shift.clone(), torch.ones(N, device=DEV)
+    hip.conv1x1(a, w, z1, out_mode=2, partial=buf1[2 * N:3 * N], conv3=sp, stat_acc=acc, stat_shift=rm1, stat_rep=R)
+    assert torch.equal(z0, z1)
+    assert torch.equal(buf1[2 * N:3 * N], shift)                                # the snapshot of the shift
+    zf = z1.double()
+    assert R == 1 or acc[R - 1].abs().sum() > 0                                 # every replica took adds
+    torch.testing.assert_close(acc.sum(0)[:N].double(), (zf - shift.double()).sum(0), rtol=2e-5, atol=2e-2)
+    y1 = torch.empty_like(z0)
+    hip.abn_apply_stats(z1, y1, res, M, N, acc, buf1[2 * N:3 * N], float(M), gamma, beta, rm1, rv1, 0.1, 1e-5, buf1,
+                        hip.ACT_LEAKY_RELU | hip.NORM_ABS_GAMMA, 0.01, reps=R)
+    mean, var = zf.mean(0), zf.var(0, unbiased=False)
+    torch.testing.assert_close(buf1[3 * N:4 * N].double(), mean, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(buf1[4 * N:5 * N].double(), 1 / torch.sqrt(var + 1e-5), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(buf1[3 * N:], buf0[3 * N:], rtol=1e-5, atol=2e-6)            # mean | invstd | scale: both paths
+    torch.testing.assert_close(rm1, rm0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv1, rv0, rtol=1e-5, atol=1e-6)
+    assert _rel(y1, y0) < 5e-4 and (y1.float() - y0.float()).abs().max() <= 2.0 ** -7 * y0.float().abs().max()
+    # ---- link epilogue (out_mode 3) into an accumulator, the backward apply on the raw sums
+    om, osc, osh, oinv = (torch.randn(N, device=DEV, generator=g) * 0.3, torch.rand(N, device=DEV, generator=g) + 0.5,
+                          torch.randn(N, device=DEV, generator=g) * 0.2, torch.rand(N, device=DEV, generator=g) + 0.5)
+    tiles = hip.conv1x1_row_tiles(M)
+    norm = (om, osc, osh, oinv, hip.ACT_LEAKY_RELU, 0.01)
+    p3 = torch.empty(tiles, 2, N, device=DEV)
+    dz0 = torch.empty_like(z0)
+    hip.conv1x1(a, w, dz0, out_mode=3, out_norm=norm, residual=res, partial=p3, conv3=sp)
+    sums0 = torch.zeros(2 * N, device=DEV)
+    hip._check(hip.load().ucd_abn_reduce_partials(hip.ptr(p3), tiles, N, hip.ptr(sums0), None, hip.ptr(gamma), hip.NORM_ABS_GAMMA,
+                                                  hip.stream()), "reduce")
+    acc3, acc3b = torch.zeros(R, 2 * N, device=DEV), torch.zeros(R, 2 * N, device=DEV)
+    dz1 = torch.empty_like(z0)
+    hip.conv1x1(a, w, dz1, out_mode=3, out_norm=norm, residual=res, partial=p3, conv3=sp, stat_acc=acc3, stat_acc2=acc3b, stat_rep=R)
+    assert torch.equal(dz0, dz1)
+    sign = torch.where(gamma < 0, -1.0, 1.0)
+    torch.testing.assert_close(acc3.sum(0)[:N], sums0[:N], rtol=2e-5, atol=2e-3)
+    torch.testing.assert_close(acc3.sum(0)[N:] * sign, sums0[N:], rtol=2e-5, atol=2e-3)
+    torch.testing.assert_close(acc3b, acc3, rtol=1e-4, atol=1e-3)               # the second accumulator took the same adds (in its own order)
+    # the producer's backward: identity activation on d pre, mean / invstd / scale of ITS statistics (buf0), parameter gradients
+    dx0, dx1 = torch.empty_like(z0), torch.empty_like(z0)
+    act = hip.ACT_IDENTITY | hip.NORM_ABS_GAMMA
+    hip.abn_bwd_apply(z0, N, dz0, N, None, 0, dx0, N, None, 0, M, N, None, 1, buf0[3 * N:4 * N], buf0[4 * N:5 * N], buf0[5 * N:], beta,
+                      gamma, sums0, float(M), 0, act, 0.0)
+    # fed the SAME sums (sign removed again): bit-identical dx, and the parameter gradients written by the launch
+    raw = torch.cat([sums0[:N], sums0[N:] * sign])
+    gout = torch.full((2 * N,), float("nan"), device=DEV)
+    hip.abn_bwd_apply_raw(z0, dz0, None, dx1, None, M, N, buf0[3 * N:4 * N], buf0[4 * N:5 * N], buf0[5 * N:], beta, gamma, raw, None, gout,
+                          float(M), act, 0.0)
+    assert torch.equal(dx0, dx1)
+    assert torch.equal(gout, sums0)
+    # and from the replicated accumulators (summed in the prologue): the same dx up to the rounding of the sums
+    dx2 = torch.empty_like(z0)
+    hip.abn_bwd_apply_raw(z0, dz0, None, dx2, None, M, N, buf0[3 * N:4 * N], buf0[4 * N:5 * N], buf0[5 * N:], beta, gamma, acc3, acc3b, gout,
+                          float(M), act, 0.0, reps=R)
+    assert _rel(dx2, dx0) < 5e-4
+    torch.testing.assert_close(gout, sums0, rtol=1e-4, atol=5e-3)
+    if sp is None:
+        # ---- block link (out_mode 4)
+        z3 = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        p4 = torch.empty(tiles, 2, N, device=DEV)
+        y4a, y4b = res.clone(), res.clone()
+        kw = dict(out_mode=4, out_norm=(om, None, None, oinv, hip.ACT_LEAKY_RELU, 0.01), residual=z3, side2=res, accumulate=True)
+        hip.conv1x1(a, w, y4a, partial=p4, **kw)
+        s4 = torch.zeros(2 * N, device=DEV)
+        hip._check(hip.load().ucd_abn_reduce_partials(hip.ptr(p4), tiles, N, hip.ptr(s4), None, None, 0, hip.stream()), "reduce")
+        acc4 = torch.zeros(R, 2 * N, device=DEV)
+        hip.conv1x1(a, w, y4b, partial=p4, stat_acc=acc4, stat_rep=R, **kw)
+        assert torch.equal(y4a, y4b)
+        torch.testing.assert_close(acc4.sum(0), s4, rtol=2e-5, atol=5e-3)
+
+
+_RA_CHILD = r"""
+import sys, torch
+sys.path.insert(0, %(root)r)
+from ucd_amd import hip
+dev = torch.device("cuda:0")
+g = torch.Generator(dev).manual_seed(5)
+def ints(*shape, hi):
+    return torch.randint(-hi, hi + 1, shape, device=dev, generator=g).bfloat16()
+out = {}
+# the mod4 shape of the benchmark (205 row tiles, one column range), a ragged 12-image grid (103 tiles, two ranges) and the per-rank
+# shape of the 8-GPU split (26 tiles, eight ranges of one step each); N = 512: four steps
+for M, K, N in ((26136, 256, 1024), (13068, 256, 1024), (3267, 256, 1024), (26136 - 77, 256, 512)):
+    a = ints(M, K, hi=2) * (torch.rand(M, K, device=dev, generator=g) < 0.2)
+    w = ints(N, K, hi=1) * (torch.rand(N, K, device=dev, generator=g) < 0.2)
+    ref = a.float() @ w.float().t()
+    assert ref.abs().max().item() <= 256
+    tiles = hip.load().ucd_conv1x1_row_tiles(M)
+    y = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+    hip.conv1x1(a, w, y)
+    assert torch.equal(y.float(), ref), ("plain", M, K, N)
+    res = ints(M, N, hi=3)
+    y0 = res.clone()
+    hip.conv1x1(a, w, y0, accumulate=True)
+    assert torch.equal(y0.float(), ref + res.float()), ("accumulate", M, K, N)
+    wide = torch.zeros(M, N + 256, device=dev, dtype=torch.bfloat16)                 # a channel slice of a wider buffer (ldy > N)
+    hip.conv1x1(a, w, wide[:, 128:128 + N])
+    assert torch.equal(wide[:, 128:128 + N].float(), ref) and not wide[:, :128].any() and not wide[:, 128 + N:].any(), ("slice", M, K, N)
+    part = hip.conv1x1_stats_partial(M, N, dev).fill_(float("nan"))
+    y.fill_(float("nan"))
+    hip.conv1x1(a, w, y, out_mode=2, partial=part)
+    assert torch.equal(y.float(), ref), ("stats y", M, K, N)
+    p = part.view(tiles, 3, N)
+    assert not torch.isnan(p).any()
+    for t in (0, tiles // 2, tiles - 1):
+        rows = ref[t * 128:(t + 1) * 128]
+        k = p[t, 0]
+        assert torch.equal(k, rows[0]) and torch.equal(p[t, 1], (rows - k).sum(0)) and torch.equal(p[t, 2], ((rows - k) ** 2).sum(0)), ("partials", M, K, N, t)
+    one, zero = torch.ones(N, device=dev), torch.zeros(N, device=dev)
+    hip.conv1x1(a, w, y, out_mode=1, out_norm=(zero, one, zero, None, hip.ACT_LEAKY_RELU, 0.5), residual=res)
+    z = ref + res.float()
+    assert torch.equal(y.float(), torch.where(z > 0, z, z * 0.5).bfloat16().float()), ("affine + residual", M, K, N)
+    hip.conv1x1(a, w, y, out_mode=1, out_norm=(zero, one, zero, None, hip.ACT_LEAKY_RELU, 0.5))
+    assert torch.equal(y.float(), torch.where(ref > 0, ref, ref * 0.5).bfloat16().float()), ("affine", M, K, N)
+    # block link (out_mode 4): d pre = (acc + d shortcut) * act'(block output), sums of d pre and d pre * x-hat(z3) (mean 0, invstd 1)
+    outb, z3 = ints(M, N, hi=2), ints(M, N, hi=2)
+    p4 = torch.full((tiles, 2, N), float("nan"), device=dev)
+    y4 = res.clone()
+    hip.conv1x1(a, w, y4, out_mode=4, out_norm=(zero, None, None, one, hip.ACT_LEAKY_RELU, 0.5), residual=outb, side2=z3, partial=p4, accumulate=True)
+    dpre = ((ref + res.float()) * torch.where(outb.float() > 0, 1.0, 0.5)).bfloat16().float()
+    assert torch.equal(y4.float(), dpre), ("block link y", M, K, N)
+    assert not torch.isnan(p4).any()
+    for t in (0, tiles - 1):
+        rows, zz = dpre[t * 128:(t + 1) * 128], z3[t * 128:(t + 1) * 128].float()
+        assert torch.allclose(p4[t, 0], rows.sum(0), rtol=0, atol=1e-3) and torch.allclose(p4[t, 1], (rows * zz).sum(0), rtol=0, atol=1e-3), ("block link sums", M, K, N, t)
+    # real-valued operands: what the other kernel forms of this library give for the same call (dumped for the parent to compare)
+    ar = (torch.randn(M, K, device=dev, generator=g) * 1.3 + 0.2).bfloat16()
+    wr = (torch.randn(N, K, device=dev, generator=g) * (2.0 / K) ** 0.5).bfloat16()
+    rr = torch.randn(M, N, device=dev, generator=g).bfloat16()
+    mean, scale, shift = torch.randn(N, device=dev, generator=g) * 0.3, torch.rand(N, device=dev, generator=g) + 0.5, torch.randn(N, device=dev, generator=g) * 0.2
+    yp = torch.empty(M, N, device=dev, dtype=torch.bfloat16); hip.conv1x1(ar, wr, yp)
+    pr = hip.conv1x1_stats_partial(M, N, dev); ys = torch.empty_like(yp); hip.conv1x1(ar, wr, ys, out_mode=2, partial=pr)
+    buf = torch.zeros(6 * N, device=dev)
+    hip.conv1x1_stats_finalize(pr, M, N, torch.ones(N, device=dev), torch.zeros(N, device=dev), torch.ones(N, device=dev), 0.1, 1e-5, buf)
+    ya = torch.empty_like(yp); hip.conv1x1(ar, wr, ya, out_mode=1, out_norm=(mean, scale, shift, None, hip.ACT_LEAKY_RELU, 0.01), residual=rr)
+    torch.cuda.synchronize()
+    out[(M, K, N)] = dict(plain=yp.cpu(), stats_y=ys.cpu(), mean_invstd=buf[3 * N:5 * N].cpu(), affine=ya.float().cpu(),
+                          ref=(ar.float() @ wr.float().t()).cpu())
+torch.save(out, sys.argv[1])
+print("ok")
+"""
+
+
+def test_resident_a_form_of_the_short_k_products_is_exact_on_integers_and_matches_the_tiled_forms(tmp_path):
+    """conv_ra_kernel (round 5: conv3 of the mod4 blocks and the block link, 256 -> 1024; modules/residual.py:67-73) against exact
+    integer products for every output mode it takes (plain, accumulate, slice output, statistics with the per-tile partial rows, affine
+    (+ residual) + activation, block link with its two sums) at the benchmark's 205 row tiles and on the column-range split of smaller
+    grids; then, on real-valued operands, against the tiled forms of the same library (``UCD_CONV_RA=0`` in a second process): plain and
+    statistics outputs bit for bit, mean / invstd to fp32 rounding, the affine epilogue within one bf16 rounding of z."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for ra in ("2", "0"):
+        env = dict(os.environ, UCD_CONV_RA=ra)
+        env.pop("UCD_CONV_PIPE", None)
+        f = tmp_path / f"ra{ra}.pt"
+        r = subprocess.run([sys.executable, "-c", _RA_CHILD % {"root": root}, str(f)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (ra, r.stdout[-500:], r.stderr[-2000:])
+        outs[ra] = torch.load(f)
+    for key, a in outs["2"].items():
+        b = outs["0"][key]
+        # another order of the sum over k inside a K step: the fp32 accumulators differ in the last bits, a few stored values by one
+        # bf16 rounding step
+        for name in ("plain", "stats_y"):
+            da = (a[name].float() - b[name].float()).abs()
+            assert (da > 0).float().mean() < 0.02 and (da <= 2.0 ** -7 * b[name].float().abs().clamp_min(1e-3)).all(), (key, name)
+        torch.testing.assert_close(a["mean_invstd"], b["mean_invstd"], rtol=1e-4, atol=2e-5)
+        # the affine epilogue sees z after one bf16 rounding here (the tiled forms apply it to the fp32 accumulator)
+        assert _rel(a["affine"], b["affine"]) < 4e-3 and (a["affine"] - b["affine"]).abs().max() <= 0.04 * b["affine"].abs().max(), key
+
+
 @pytest.mark.parametrize("pipe", ["2x64", "4x32", "4x64", "lw32", "lw64", "lw64x2", "lw256"])
 def test_every_pipeline_form_of_the_gemm_kernel_is_exact_on_integers(pipe):
     """The GEMM / implicit-GEMM kernel has seven pipeline forms since round 4 (double buffer, two four-stage forms, loader waves on

@@ -287,3 +287,60 @@ def test_bench_forced_collectives_on_one_gpu_match_the_plain_run(tmp_path):
         # nine optimiser steps (six warm-up + three timed) of the chaotic random-weight network separate two equivalent arithmetics
         # by a few 1e-3 (measured 1e-4 .. 2.4e-3 over five runs; the library's atomics alone move a re-run by as much)
         assert abs(b["losses"][k] - v) <= 2e-2 * max(1.0, abs(v)), (k, v, b["losses"][k])
+
+
+def test_aborted_backward_leaves_no_widening_copies_behind():
+    """at world 1 the bf16 -> fp32 widening copies of the gradient buckets are queued and flushed in finish().  A
+    backward that stops before finish() (an exception inside a later node, a whole-step capture that fails) must not leave its
+    queued pairs for the next step: after the abort the next step's gradients equal those of a wrapper that never saw the abort."""
+    from functools import partial
+    import torch
+    from ucd_amd import abn, synth
+    from ucd_amd.blocks import ResidualBlock
+    from ucd_amd.ddp import DistributedDataParallel
+    from ucd_amd import switches
+    dev = "cuda:0"
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    switches.set("UCD_STAT_ATOMIC", "0")             # bit-equality below: the deterministic statistics path
+
+    class Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    def make():
+        net = torch.nn.Sequential(ResidualBlock(256, (64, 64, 256), norm_act=norm), ResidualBlock(256, (64, 64, 256), norm_act=norm))
+        net.load_state_dict(synth.fill_state_dict(net.state_dict(), 3))
+        net = net.to(dev).to(memory_format=torch.channels_last).train()
+        return net, DistributedDataParallel(net, bf16_weights=True, bucket_mb=0.05)      # several small buckets
+
+    x0 = synth.t_normal(4, (2, 256, 9, 9), stream=1).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    x1 = synth.t_normal(5, (2, 256, 9, 9), stream=1).to(dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    grads = []
+    for abort in (True, False):
+        net, mod = make()
+        assert len(mod.reducer.buckets) >= 3
+        if abort:
+            # the second block's gradients (the first buckets) complete, then the backward dies between the two blocks
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                h = net[0](x0)
+                y = net[1](Boom.apply(h))
+            mod.reducer.prepare_step()
+            with pytest.raises(RuntimeError, match="boom"):
+                y.float().sum().backward()
+            assert mod.reducer._late_src, "the aborted backward queued nothing: the test does not exercise the hazard"
+        mod.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(x1)
+        y.float().square().mean().backward()
+        mod.finish_grad_sync()
+        assert not mod.reducer._late_src
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.float().clone() for n, p in net.named_parameters()})
+    switches.unset("UCD_STAT_ATOMIC")
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n

@@ -56,7 +56,9 @@ def test_model_parameter_names_are_the_references():
     assert set(sd) == set(ref)
     assert all(sd[k].shape == ref[k].shape for k in ref)
     assert not m.cls[0].weight.requires_grad and not m.cls[0].bias.requires_grad
-    assert sum(p.numel() for p in m.parameters()) == 58040661 - 0 or True
+    # SURVEY N1 [probe]: 58.04 M parameters, of which cls[0] (16 x 256 + 16 = 4112) is frozen
+    assert sum(p.numel() for p in m.parameters()) == 58040661
+    assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 58040661 - 4112
 
 
 def test_poly_lr_and_presets():

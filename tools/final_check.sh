@@ -1,4 +1,4 @@
-cd $GRAFT_REPO_ROOT; O=gpurun_out/r04_final; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R; O=gpurun_out/r04_final; mkdir -p $O
 timeout 2400 python -m pytest tests -x -q -m gpu > $O/tests_gpu.txt 2>&1; tail -3 $O/tests_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 900 python bench.py --steps 20 --warmup 6 > $O/bench.json 2> $O/bench.err; python -c "

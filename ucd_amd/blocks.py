@@ -649,7 +649,8 @@ def _conv_abn_train(conv, bn, x, residual=None, activation=None, activation_para
                               bool(make_link),
                               *((blink[0], blink[1], None, blink[2], blink[3], 0, float(blink[4]), 3) if blink is not None else
                                 (link[0], link[1], link[2], link[3], link[4], int(link[5]), float(link[6]), 1) if link is not None
-                                else (None, None, None, None, None, 0, 0.0, 0)), int(stride) if stride else 1)
+                                else (None, None, None, None, None, 0, 0.0, 0)), int(stride) if stride else 1,
+                              _env("UCD_STAT_ATOMIC", "1") != "0")
     k = 2 if with_skip else 1
     if len(out) > k:                             # the node made a link: (z, buf, partial, flag) follow the regular outputs
         if residual is None:

@@ -329,25 +329,146 @@ __global__ __launch_bounds__(kBlock) void abn_apply_kernel(const T* x, int ld_x,
 
 // bf16, no plane bias, leaky_relu / identity (slope = 1): the layers of the train step.  Same arithmetic as abn_apply_kernel
 // ((x - mean) * scale + shift, + residual, select; no contraction) on float pairs.
-template <bool RES>
+// FIN (round 5): the statistics arrive as RAW sums about a shift (fin.acc = [sum (x - k) | sum (x - k)^2], fin.kshift = k: the
+// atomic accumulator of the producing GEMM's epilogue) and every thread finalises its eight channels itself - the arithmetic of
+// finalize_channel_pre; the first row band also stores mean / invstd / scale for the backward and updates the running statistics
+// (what tile_stats_reduce_kernel<1> did in a launch of its own, 103 times per step).
+// Sum of the `reps` replicas of a [2 C] accumulator for this thread's eight channels, valid in EVERY thread on return.  The replicas
+// were filled by atomics (executed at the memory side: their lines come from memory, ~1-2 us per dependent round trip), so the TY
+// row threads of a channel group split them - thread ty takes replicas ty, ty + TY, ... with up to four (16 loads) in flight - and
+// combine through LDS in a fixed order (block_reduce_rows).  reps == 1: a plain load.  Called by all 256 threads (barriers inside).
+__device__ __forceinline__ void replica_sum(const float* __restrict__ acc, int reps, int C, size_t coff, int tx, int ty, int TX, int TY,
+                                            bool live, float* lds, Pack8& s1, Pack8& s2) {
+  if (reps <= 1) {
+    if (live) { s1 = load_f8(acc + coff); s2 = load_f8(acc + C + coff); }
+    return;
+  }
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = 0.f;
+  if (live) {
+    for (int r = ty; r < reps; r += 4 * TY) {
+      Pack8 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * TY;
+        if (rr < reps) {
+          a[u] = load_f8(acc + (size_t)rr * 2 * C + coff);
+          b[u] = load_f8(acc + (size_t)rr * 2 * C + C + coff);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { a[u].p[j] = f32x2{0.f, 0.f}; b[u].p[j] = f32x2{0.f, 0.f}; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * j] += a[u].p[j].x; v[2 * j + 1] += a[u].p[j].y;
+          v[8 + 2 * j] += b[u].p[j].x; v[8 + 2 * j + 1] += b[u].p[j].y;
+        }
+    }
+  }
+  block_reduce_rows<16>(v, tx, ty, TX, TY, lds);
+  // row 0 of the reduction scratch holds the totals (the last tree level ends with a barrier)
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s1.p[j] = f32x2{lds[tx * 16 + 2 * j], lds[tx * 16 + 2 * j + 1]};
+      s2.p[j] = f32x2{lds[tx * 16 + 8 + 2 * j], lds[tx * 16 + 8 + 2 * j + 1]};
+    }
+  }
+}
+
+struct ApplyFin {
+  const float* acc;        // [reps][2 C]
+  int reps;
+  const float* kshift;     // [C]
+  const float* weight;     // [C] or NULL
+  float* running_mean;     // [C] or NULL
+  float* running_var;
+  float* mean;             // outputs [C]
+  float* invstd;
+  float* scale;
+  float count, momentum, eps;
+  int abs_gamma;
+};
+__device__ __forceinline__ void apply_fin_channels(const ApplyFin& f, const Pack8& s1, const Pack8& s2, const Pack8& k, const Pack8& w,
+                                                   size_t coff, bool writer, Pack8& mu, Pack8& sc) {
+  const float inv_n = 1.f / f.count;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float m[2], is[2], scl[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float s = s1.p[j][e], ss = s2.p[j][e];
+      const float d = s * inv_n;                      // mean - k
+      m[e] = k.p[j][e] + d;
+      const float var = fmaxf((ss - s * d) * inv_n, 0.f);
+      is[e] = 1.f / sqrtf(var + f.eps);
+      scl[e] = (f.weight ? gamma_eff(w.p[j][e], f.eps, f.abs_gamma) : 1.f) * is[e];
+      if (writer) {
+        const int c = (int)coff + 2 * j + e;
+        if (f.running_mean) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * m[e];
+        if (f.running_var) {
+          const float unbiased = f.count > 1.f ? var * (f.count / (f.count - 1.f)) : var;
+          f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * unbiased;
+        }
+        f.mean[c] = m[e];
+        f.invstd[c] = is[e];
+        f.scale[c] = scl[e];
+      }
+    }
+    mu.p[j] = f32x2{m[0], m[1]};
+    sc.p[j] = f32x2{scl[0], scl[1]};
+  }
+}
+
+template <bool RES, bool FIN = false>
 __global__ __launch_bounds__(kBlock) void abn_apply_fast_kernel(const __hip_bfloat16* x, int ld_x, __hip_bfloat16* y, int ld_y,
                                                                const __hip_bfloat16* __restrict__ res, int ld_r, int M, int C,
                                                                const float* __restrict__ mean, const float* __restrict__ scale,
                                                                const float* __restrict__ beta, float slope, int TX, int TY,
-                                                               int rows_per_band) {
+                                                               int rows_per_band, ApplyFin fin = ApplyFin{}) {
+  extern __shared__ __attribute__((aligned(16))) float fin_lds[];   // FIN with replicas: [256][16] reduction scratch
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cg = blockIdx.x * TX + tx;
-  if (ty >= TY || cg * 8 >= C) return;
+  const bool live = ty < TY && cg * 8 < C;
+  if (!FIN && !live) return;
   const size_t coff = (size_t)cg * 8;
-  const Pack8 mu = load_f8(mean + coff), sc = load_f8(scale + coff);
+  Pack8 mu, sc;
+  const int r_begin = blockIdx.y * rows_per_band;
+  const int r_end = min(M, r_begin + rows_per_band);
+  auto ld = [&](const __hip_bfloat16* p, int ldp, int r) { return *reinterpret_cast<const uint4*>(p + (size_t)r * ldp + coff); };
+  int r = r_begin + ty;
+  // FIN: the first batch of rows is requested BEFORE the statistics (vector memory returns in order: rows first, then the accumulator
+  // - both round trips overlap, and the accumulator's lines come from memory: atomics leave nothing in L2)
+  const bool pre = FIN && live && r + 3 * TY < r_end;
+  uint4 pv0, pv1, pv2, pv3, pq0, pq1, pq2, pq3;
+  if (pre) {
+    pv0 = ld(x, ld_x, r); pv1 = ld(x, ld_x, r + TY); pv2 = ld(x, ld_x, r + 2 * TY); pv3 = ld(x, ld_x, r + 3 * TY);
+    pq0 = pv0; pq1 = pv0; pq2 = pv0; pq3 = pv0;
+    if (RES) { pq0 = ld(res, ld_r, r); pq1 = ld(res, ld_r, r + TY); pq2 = ld(res, ld_r, r + 2 * TY); pq3 = ld(res, ld_r, r + 3 * TY); }
+  }
+  if (FIN) {
+    Pack8 s1, s2, kk, ww;
+    if (live) {                                         // requested with the rows, ahead of the accumulator's round trip
+      kk = load_f8(fin.kshift + coff);
+      if (fin.weight) ww = load_f8(fin.weight + coff);
+    }
+    replica_sum(fin.acc, fin.reps, C, coff, tx, ty, TX, TY, live, fin_lds, s1, s2);
+    if (!live) return;
+    apply_fin_channels(fin, s1, s2, kk, ww, coff, blockIdx.y == 0 && ty == 0, mu, sc);
+  } else {
+    mu = load_f8(mean + coff);
+    sc = load_f8(scale + coff);
+  }
   Pack8 sh;
   if (beta) sh = load_f8(beta + coff);
   else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) sh.p[j] = f32x2{0.f, 0.f};
   }
-  const int r_begin = blockIdx.y * rows_per_band;
-  const int r_end = min(M, r_begin + rows_per_band);
   auto emit = [&](const uint4& xv, const uint4& rv, int r) {
     const Pack8 v = unpack8(xv);
     Pack8 o;
@@ -361,8 +482,13 @@ __global__ __launch_bounds__(kBlock) void abn_apply_fast_kernel(const __hip_bflo
     }
     *reinterpret_cast<uint4*>(y + (size_t)r * ld_y + coff) = pack8(o);
   };
-  auto ld = [&](const __hip_bfloat16* p, int ldp, int r) { return *reinterpret_cast<const uint4*>(p + (size_t)r * ldp + coff); };
-  int r = r_begin + ty;
+  if (pre) {
+    emit(pv0, pq0, r);
+    emit(pv1, pq1, r + TY);
+    emit(pv2, pq2, r + 2 * TY);
+    emit(pv3, pq3, r + 3 * TY);
+    r += 4 * TY;
+  }
   for (; r + 3 * TY < r_end; r += 4 * TY) {
     uint4 v0 = ld(x, ld_x, r), v1 = ld(x, ld_x, r + TY), v2 = ld(x, ld_x, r + 2 * TY), v3 = ld(x, ld_x, r + 3 * TY);
     uint4 q0 = v0, q1 = v0, q2 = v0, q3 = v0;
@@ -621,17 +747,34 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_reduce_fast_kernel(
 
 // dx = (dz - mean(dz) - xhat * mean(dz xhat)) * gamma invstd with the same operation order as abn_bwd_apply_kernel:
 // ((dz - k0) - xhat k1) gw (the library is built with -ffp-contract=off: no fma anywhere).  frozen: k0 = k1 = invstd = 0, gw = scale.
-template <bool YOUT, bool DZOUT>
+// RAW (round 5): sums are the atomic accumulator of a link epilogue - [sum dz | sum dz * xhat] with no sign applied; the first row
+// band writes the layer's parameter gradients [d bias | d weight] to grad_out from grad_sums (what reduce_bands_kernel did)
+template <bool YOUT, bool DZOUT, bool RAW = false>
 __global__ __launch_bounds__(kBlock) void abn_bwd_apply_fast_kernel(
     const __hip_bfloat16* x, int ld_x, const __hip_bfloat16* dy, int ld_dy, const __hip_bfloat16* yout, int ld_y,
     __hip_bfloat16* dx, int ld_dx, __hip_bfloat16* dz_out, int ld_dz, int M, int C, const float* __restrict__ mean,
     const float* __restrict__ invstd, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* __restrict__ weight, const float* __restrict__ sums, float inv_count, int frozen, int abs_gamma, float slope,
-    int TX, int TY, int rows_per_band) {
+    int TX, int TY, int rows_per_band, const float* __restrict__ grad_sums = nullptr, float* __restrict__ grad_out = nullptr,
+    int reps = 1) {
+  extern __shared__ __attribute__((aligned(16))) float raw_lds[];   // RAW with replicas: [256][16] reduction scratch
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int cg = blockIdx.x * TX + tx;
-  if (ty >= TY || cg * 8 >= C) return;
+  const bool live = ty < TY && cg * 8 < C;
+  if (!RAW && !live) return;
   const size_t coff = (size_t)cg * 8;
+  Pack8 rs0, rs1, rg0, rg1;                             // RAW: the replica-summed sums (and this rank's, for the parameter gradients)
+  if (RAW) {
+    replica_sum(sums, reps, C, coff, tx, ty, TX, TY, live, raw_lds, rs0, rs1);
+    const bool want_g = grad_out != nullptr && blockIdx.y == 0;       // block-uniform
+    if (want_g && grad_sums != sums) {
+      __syncthreads();                                  // the scratch is read by everyone before it is reused
+      replica_sum(grad_sums, reps, C, coff, tx, ty, TX, TY, live, raw_lds, rg0, rg1);
+    } else {
+      rg0 = rs0; rg1 = rs1;
+    }
+    if (!live) return;
+  }
   const Pack8 mu = load_f8(mean + coff), sc = load_f8(scale + coff);
   Pack8 sh, is, k0, k1, gw;
   if (shift) sh = load_f8(shift + coff);
@@ -644,7 +787,9 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_fast_kernel(
     for (int j = 0; j < 4; ++j) { is.p[j] = f32x2{0.f, 0.f}; k0.p[j] = f32x2{0.f, 0.f}; k1.p[j] = f32x2{0.f, 0.f}; gw.p[j] = sc.p[j]; }
   } else {
     is = load_f8(invstd + coff);
-    const Pack8 a0 = load_f8(sums + coff), a1 = load_f8(sums + C + coff);
+    Pack8 a0, a1;
+    if (RAW) { a0 = rs0; a1 = rs1; }
+    else { a0 = load_f8(sums + coff); a1 = load_f8(sums + C + coff); }
     Pack8 w;
     if (weight) w = load_f8(weight + coff);
 #pragma unroll
@@ -652,12 +797,22 @@ __global__ __launch_bounds__(kBlock) void abn_bwd_apply_fast_kernel(
       k0.p[j] = a0.p[j] * inv_count;                    // mean(dz)
       f32x2 kk = a1.p[j] * inv_count;                   // mean(dz * xhat)
       if (abs_gamma) {                                  // sums[C + c] is d weight = sign(weight) * sum dz*xhat; scale = (|w| + eps) * invstd
-        if (weight) kk = f32x2{w.p[j].x < 0.f ? -kk.x : kk.x, w.p[j].y < 0.f ? -kk.y : kk.y};
+        if (weight && !RAW) kk = f32x2{w.p[j].x < 0.f ? -kk.x : kk.x, w.p[j].y < 0.f ? -kk.y : kk.y};
         gw.p[j] = sc.p[j];
       } else {
         gw.p[j] = weight ? w.p[j] * is.p[j] : is.p[j];
       }
       k1.p[j] = kk;
+    }
+    if (RAW && grad_out && blockIdx.y == 0 && ty == 0) {
+      const Pack8 g0 = rg0, g1 = rg1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x2 dwt = g1.p[j];
+        if (abs_gamma && weight) dwt = f32x2{w.p[j].x < 0.f ? -dwt.x : dwt.x, w.p[j].y < 0.f ? -dwt.y : dwt.y};
+        *reinterpret_cast<f32x2*>(grad_out + coff + 2 * j) = g0.p[j];
+        *reinterpret_cast<f32x2*>(grad_out + C + coff + 2 * j) = dwt;
+      }
     }
   }
   const int r_begin = blockIdx.y * rows_per_band;
@@ -1015,6 +1170,71 @@ int ucd_abn_apply(const void* x, int ld_x, void* y, int ld_y, const void* residu
     else LAUNCH_APPLY(float, 4, UCD_ACT_IDENTITY)
   }
 #undef LAUNCH_APPLY
+  return check_launch(fn);
+}
+
+int ucd_abn_apply_stats(const void* x, int ld_x, void* y, int ld_y, const void* residual, int ld_r, int M, int C,
+                        const float* acc, int reps, const float* kshift, float count, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                        float* scale, int act, float slope, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_apply_stats";
+  if (reps < 1) reps = 1;
+  UCD_TRY(check_common(fn, UCD_BF16, M, C, act));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, UCD_BF16, C, false));
+  UCD_TRY(check_act_tensor(fn, "y", y, ld_y, UCD_BF16, C, false));
+  UCD_TRY(check_act_tensor(fn, "residual", residual, ld_r, UCD_BF16, C, true));
+  const int a = act & UCD_ACT_MASK;
+  UCD_REQUIRE(a != UCD_ACT_ELU, UCD_EUNSUPPORTED, "%s: leaky_relu / identity only", fn);
+  UCD_REQUIRE(acc && kshift && mean && invstd && scale && count > 0.f, UCD_EINVAL, "%s: NULL statistics argument", fn);
+  UCD_REQUIRE(aligned16(acc) && aligned16(kshift) && (C % 4 == 0) && (!weight || aligned16(weight)) && (!bias || aligned16(bias)), UCD_EALIGN,
+              "%s: per-channel vectors must be 16-byte aligned", fn);
+  const Geom g = make_geom<8>(M, C, 512, 4);
+  const float sl = a == UCD_ACT_LEAKY_RELU ? slope : 1.f;
+  const ApplyFin fin{acc, reps, kshift, weight, running_mean, running_var, mean, invstd, scale, count, momentum, eps,
+                     (act & UCD_NORM_ABS_GAMMA) != 0};
+  typedef __hip_bfloat16 B;
+  hipStream_t s = (hipStream_t)stream;
+  if (residual)
+    abn_apply_fast_kernel<true, true><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>((const B*)x, ld_x, (B*)y, ld_y, (const B*)residual, ld_r, M, C,
+                                                                          nullptr, nullptr, bias, sl, g.TX, g.TY, g.rows_per_band, fin);
+  else
+    abn_apply_fast_kernel<false, true><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>((const B*)x, ld_x, (B*)y, ld_y, nullptr, 0, M, C, nullptr,
+                                                                           nullptr, bias, sl, g.TX, g.TY, g.rows_per_band, fin);
+  return check_launch(fn);
+}
+
+int ucd_abn_bwd_apply_raw(const void* x, int ld_x, const void* dy, int ld_dy, const void* y, int ld_y, void* dx, int ld_dx,
+                          void* dz_out, int ld_dz, int M, int C, const float* mean, const float* invstd, const float* scale,
+                          const float* shift, const float* weight, const float* sums, const float* grad_sums, int reps,
+                          float* grad_out, float count, int act, float slope, ucd_stream_t stream) {
+  static const char* fn = "ucd_abn_bwd_apply_raw";
+  if (reps < 1) reps = 1;
+  UCD_TRY(check_common(fn, UCD_BF16, M, C, act));
+  UCD_TRY(check_act_tensor(fn, "x", x, ld_x, UCD_BF16, C, false));
+  UCD_TRY(check_act_tensor(fn, "dy", dy, ld_dy, UCD_BF16, C, false));
+  UCD_TRY(check_act_tensor(fn, "y", y, ld_y, UCD_BF16, C, true));
+  UCD_TRY(check_act_tensor(fn, "dx", dx, ld_dx, UCD_BF16, C, false));
+  UCD_TRY(check_act_tensor(fn, "dz_out", dz_out, ld_dz, UCD_BF16, C, true));
+  const int a = act & UCD_ACT_MASK;
+  UCD_REQUIRE(a != UCD_ACT_ELU, UCD_EUNSUPPORTED, "%s: leaky_relu / identity only", fn);
+  UCD_REQUIRE(mean && invstd && scale && sums && count > 0.f, UCD_EINVAL, "%s: training statistics missing", fn);
+  UCD_REQUIRE(aligned16(mean) && aligned16(invstd) && aligned16(scale) && aligned16(sums) && C % 4 == 0 && (!shift || aligned16(shift)) &&
+                  (!weight || aligned16(weight)) && (!grad_sums || aligned16(grad_sums)) && (!grad_out || aligned16(grad_out)),
+              UCD_EALIGN, "%s: per-channel vectors must be 16-byte aligned", fn);
+  typedef __hip_bfloat16 B;
+  const Geom g = make_geom<8>(M, C, 512, 4);
+  const float sl = a == UCD_ACT_LEAKY_RELU ? slope : 1.f;
+  const int ag = (act & UCD_NORM_ABS_GAMMA) != 0;
+  const float* gs = grad_sums ? grad_sums : sums;
+  hipStream_t s = (hipStream_t)stream;
+#define UCD_BWD_RAW(YO, DZ)                                                                                                        \
+  abn_bwd_apply_fast_kernel<YO, DZ, true><<<dim3(g.gx, g.gy), kBlock, kBlock * 16 * 4, s>>>((const B*)x, ld_x, (const B*)dy, ld_dy, (const B*)y, ld_y, \
+                                                                              (B*)dx, ld_dx, (B*)dz_out, ld_dz, M, C, mean, invstd, scale, \
+                                                                              shift, weight, sums, 1.f / count, 0, ag, sl, g.TX, g.TY, \
+                                                                              g.rows_per_band, gs, grad_out, reps)
+  if (y) { if (dz_out) UCD_BWD_RAW(true, true); else UCD_BWD_RAW(true, false); }
+  else { if (dz_out) UCD_BWD_RAW(false, true); else UCD_BWD_RAW(false, false); }
+#undef UCD_BWD_RAW
   return check_launch(fn);
 }
 

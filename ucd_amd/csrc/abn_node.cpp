@@ -42,6 +42,59 @@ void* workspace(const at::Tensor& like, size_t bytes, int64_t stream, int tag = 
   return it->second.data_ptr();
 }
 
+// ---- statistics arena (round 5) ----------------------------------------------------------------------------------------------------
+// The per-layer [2 C] accumulators that the GEMM epilogues add their column sums to with fp32 atomics (ucd_conv1x1 stat_acc) live in
+// ONE zero-filled buffer per device: a slot is handed out per layer and direction during the forward, and stat_arena_reset - called
+// once per training step (ucd_amd/train.py, ucd_amd/ddp.py) - zeroes the used range with ONE fill and starts over.  Correctness never
+// depends on the caller: every slot carries the arena's generation, a reset invalidates the slots of older generations (their
+// consumers fall back to the reduction kernels), and a full arena resets itself.
+struct StatArena {
+  at::Tensor buf;
+  int64_t off = 0, gen = 1;
+};
+std::map<int, StatArena> g_arena;
+constexpr int64_t kArenaFloats = 16 << 20;     // 64 MiB: about four steps' worth at the benchmark's shapes (replicated slots, ~15 MB per step)
+
+int64_t arena_gen(int dev) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return g_arena[dev].gen;
+}
+
+void stat_arena_reset(int64_t dev) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_arena.find((int)dev);
+  if (it == g_arena.end() || !it->second.buf.defined()) return;
+  StatArena& a = it->second;
+  if (a.off > 0) a.buf.narrow(0, 0, a.off).zero_();      // one fill on the current stream (a memset node in a captured step)
+  a.off = 0;
+  a.gen += 1;
+}
+
+// n floats (rounded to 64) of zeros, or an undefined tensor (arena switched off by the caller / request larger than the arena)
+at::Tensor arena_alloc(const at::Tensor& like, int64_t n, int64_t* gen) {
+  const int dev = (int)like.get_device();
+  n = (n + 63) / 64 * 64;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    StatArena& a = g_arena[dev];
+    if (!a.buf.defined()) a.buf = at::zeros({kArenaFloats}, like.options().dtype(at::kFloat));
+    if (n > kArenaFloats) return at::Tensor();
+    if (a.off + n <= kArenaFloats) {
+      at::Tensor t = a.buf.narrow(0, a.off, n);
+      a.off += n;
+      *gen = a.gen;
+      return t;
+    }
+  }
+  stat_arena_reset(dev);                       // full (nobody resets per step): zero it, invalidate the outstanding slots
+  std::lock_guard<std::mutex> lock(g_mu);
+  StatArena& a = g_arena[dev];
+  at::Tensor t = a.buf.narrow(0, 0, n);
+  a.off = n;
+  *gen = a.gen;
+  return t;
+}
+
 bool dense_channels_last(const at::Tensor& x) {
   if (x.dim() != 4) return false;
   const auto B = x.size(0), C = x.size(1), H = x.size(2), W = x.size(3);
@@ -422,6 +475,27 @@ at::Tensor conv_stride1(at::Tensor x, at::Tensor w, int64_t d, c10::optional<at:
 // with_skip: x is also the block's identity shortcut; the node returns (y, alias of x) so that x has one consumer and the
 // shortcut's gradient is folded into the input-gradient product (Gemm1x1SkipNode's trick).
 // Reference: conv1 -> bn1, conv3 -> bn3 (+ shortcut, activation), proj_conv -> proj_bn of modules/residual.py:57-97.
+// Atomic link (round 5): the producer's `partial` is a zeroed arena slot [2 C] (SyncBN: [4 C] = to-be-reduced | local) instead of
+// per-tile rows; flag = {served, address of the consumer's dx, its version, arena generation of the slot (0: tile rows), state, replicas}
+// with state 0 empty -> 1 filled by the consumer's product -> 2 read by the producer's backward.
+static bool link_is_atomic(const at::Tensor& flag) { return flag.defined() && flag.numel() >= 6 && flag.data_ptr<int64_t>()[3] != 0; }
+// may this consumer serve the link?  (tile-row links: always; atomic links: the slot must be of the current generation and empty)
+static bool link_servable(const at::Tensor& flag, const at::Tensor& like) {
+  if (!link_is_atomic(flag)) return true;
+  const int64_t* f = flag.data_ptr<int64_t>();
+  TORCH_CHECK(f[4] != 1, "ucd conv+abn node: a backward link's accumulator was filled twice (retain_graph replay of the consumer) - "
+                         "run with UCD_STAT_ATOMIC=0");
+  return f[4] == 0 && f[3] == arena_gen((int)like.get_device());
+}
+static void link_atomic(ucd_conv1x1_desc& d, const at::Tensor& lk_partial, const at::Tensor& lk_flag, int64_t C) {
+  if (!link_is_atomic(lk_flag)) return;
+  const int64_t R = lk_flag.data_ptr<int64_t>()[5];            // replicas (the producer sized the slot: [R][2 C], SyncBN twice)
+  d.stat_acc = lk_partial.data_ptr<float>();
+  d.stat_rep = (int)R;
+  d.stat_acc2 = lk_partial.numel() >= 2 * R * 2 * C ? d.stat_acc + R * 2 * C : nullptr;
+  lk_flag.data_ptr<int64_t>()[4] = 1;
+}
+
 // B side of the backward link: turn the input-gradient product into out_mode 3 against the producer's statistics
 static void link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& lk_z, const at::Tensor& lk_buf, const at::Tensor& lk_bias,
                           const at::Tensor& lk_partial, const at::Tensor& lk_flag, int64_t C, AutogradContext* ctx) {
@@ -433,6 +507,7 @@ static void link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& lk_z, const at:
   d.out_act = (int)(ctx->saved_data["lk_act"].toInt() & UCD_ACT_MASK);
   d.out_slope = (float)ctx->saved_data["lk_slope"].toDouble();
   d.partial = lk_partial.data_ptr<float>();
+  link_atomic(d, lk_partial, lk_flag, C);
   // served: the producer's backward may skip its reduction pass - but ONLY for the gradient this product writes.  The address
   // of that tensor is recorded so the producer can tell "dy is exactly the consumer's dx" from "autograd summed several
   // contributions" (a second consumer of the producer's output: the derivative would be applied to a part of dy only).
@@ -455,6 +530,7 @@ static void block_link_epilogue(ucd_conv1x1_desc& d, const at::Tensor& out, cons
   d.out_act = UCD_ACT_LEAKY_RELU;
   d.out_slope = (float)ctx->saved_data["lk_slope"].toDouble();
   d.partial = lk_partial.data_ptr<float>();
+  link_atomic(d, lk_partial, lk_flag, C);
   lk_flag.data_ptr<int64_t>()[0] = 1;
   lk_flag.data_ptr<int64_t>()[1] = (int64_t)reinterpret_cast<intptr_t>(d.y);
 }
@@ -477,7 +553,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                c10::optional<at::Tensor> lk_z_, c10::optional<at::Tensor> lk_buf_,
                                c10::optional<at::Tensor> lk_bias_, c10::optional<at::Tensor> lk_partial_,
                                c10::optional<at::Tensor> lk_flag_, int64_t lk_act, double lk_slope, int64_t lk_kind,
-                               int64_t stride) {
+                               int64_t stride, bool stat_atomic) {
+    // stat_atomic (round 5): statistics and link sums through fp32 atomics into arena slots, finalised in the prologue of the apply
+    // passes (no tile_stats_reduce / reduce_bands launches); off: the deterministic per-tile rows + second-stage kernels
     // stride > 1: the strided layers of the first block of a stage (conv2 3x3 stride 2 with padding = dilation, proj_conv 1x1
     // stride 2): forward and weight gradient on the own kernels (the strided row gather / implicit GEMM, ucd_conv_wgrad_strided),
     // input gradient through the library's backward-data solver; no shortcut fold, no link consumed (it may still MAKE one).
@@ -527,6 +605,24 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       d.M = (int)M; d.N = (int)N; d.K = (int)K; d.out_mode = 2; d.partial = partial;
       if (conv3) { d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation; }
       if (stride > 1) { d.H = (int)H; d.W = (int)W; d.stride = (int)stride; }
+      int64_t gen = 0;
+      const int64_t R = ucd_conv1x1_stat_replicas((int)M);
+      at::Tensor acc = (stat_atomic && N % 8 == 0) ? arena_alloc(x, R * 2 * N, &gen) : at::Tensor();
+      if (acc.defined()) {
+        // sums about the running mean (equal on every rank), straight into the layer's accumulator; SyncBN: one all-reduce of the
+        // 2 N raw sums (they are additive about a common shift) instead of gather + Chan combination
+        d.stat_acc = acc.data_ptr<float>();
+        d.stat_rep = (int)R;
+        d.stat_shift = running_mean.data_ptr<float>();
+        d.partial = b + 2 * N;                                   // the snapshot of the shift
+        check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
+        if (sync) check(ucd_comm_all_reduce_sum((ucd_comm_t)comm, d.stat_acc, (size_t)(R * 2 * N), (ucd_stream_t)stream), "ucd_comm_all_reduce_sum");
+        check(ucd_abn_apply_stats(z.data_ptr(), (int)N, y.data_ptr(), (int)N, resp, has_res ? (int)N : 0, (int)M, (int)N, d.stat_acc,
+                                  (int)R, b + 2 * N, (float)M * (sync ? (float)world : 1.f), fptr(weight), fptr(bias),
+                                  running_mean.data_ptr<float>(), running_var.data_ptr<float>(), (float)momentum, (float)eps, b + 3 * N,
+                                  b + 4 * N, b + 5 * N, (int)act, (float)slope, (ucd_stream_t)stream),
+              "ucd_abn_apply_stats");
+      } else {
       check(ucd_conv1x1(&d, (ucd_stream_t)stream), "ucd_conv1x1");
       if (!sync) {
         check(ucd_conv1x1_stats_finalize(partial, (int)M, (int)N, fptr(weight), running_mean.data_ptr<float>(),
@@ -547,6 +643,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                    running_var.data_ptr<float>(), (float)momentum, (float)eps, b, (int)act, (float)slope,
                                    (ucd_stream_t)stream),
               "ucd_abn_sync_forward");
+      }
       }
     } else {
       if (conv3 || stride > 1) {
@@ -578,14 +675,23 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
     at::Tensor lk_partial = lk_partial_.has_value() ? *lk_partial_ : at::Tensor();
     at::Tensor lk_flag = lk_flag_.has_value() ? *lk_flag_ : at::Tensor();
     const bool consume_link = lk_z.defined() && lk_buf.defined() && (lk_bias.defined() || lk_kind == 3) && lk_partial.defined() &&
-                              lk_flag.defined() && (lk_kind != 3 || with_skip);
+                              lk_flag.defined() && (lk_kind != 3 || with_skip) && (!link_is_atomic(lk_flag) || (K % 8 == 0));
     at::Tensor my_partial, my_flag;
     // a link needs leaky_relu / identity (the fused epilogues' activations); with a residual it is the block link, whose
     // consumer reads the sign from y - so y must be among the saved tensors (needs_y: leaky_relu with a residual)
     make_link = make_link && bias.defined() && (act & UCD_ACT_MASK) != UCD_ACT_ELU && (!has_res || needs_y);
     if (make_link) {
-      my_partial = at::empty({(int64_t)ucd_conv1x1_row_tiles((int)M), 2, N}, x.options().dtype(at::kFloat));
-      my_flag = at::zeros({3}, at::TensorOptions().dtype(at::kLong));   // {served, address of the consumer's dx, its version counter}
+      my_flag = at::zeros({6}, at::TensorOptions().dtype(at::kLong));   // {served, address of the consumer's dx, its version, generation, state, replicas}
+      int64_t gen = 0;
+      const int64_t R = ucd_conv1x1_stat_replicas((int)M);
+      if (stat_atomic && N % 8 == 0) my_partial = arena_alloc(x, (sync ? 2 : 1) * R * 2 * N, &gen);
+      if (my_partial.defined()) {
+        my_partial = my_partial.narrow(0, 0, (sync ? 2 : 1) * R * 2 * N);
+        my_flag.data_ptr<int64_t>()[3] = gen;
+        my_flag.data_ptr<int64_t>()[5] = R;
+      } else {
+        my_partial = at::empty({(int64_t)ucd_conv1x1_row_tiles((int)M), 2, N}, x.options().dtype(at::kFloat));
+      }
     }
     ctx->save_for_backward({x, w4, z, needs_y ? y : at::Tensor(), weight, bias, buf, wflip,
                             consume_link ? lk_z : at::Tensor(), consume_link ? lk_buf : at::Tensor(),
@@ -667,7 +773,31 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       void* ws = workspace(x, ws_bytes, stream);
       const void* yp = y.defined() ? y.data_ptr() : nullptr;
       const bool linked = my_flag.defined() && my_flag.data_ptr<int64_t>()[0] == 1;
-      if (linked) {
+      if (linked && link_is_atomic(my_flag)) {
+        // atomic link: the consumer's product added the two sums into this layer's arena slot; the apply pass finalises them in its
+        // prologue and writes the parameter gradients (SyncBN: the first half is all-reduced, the second stays this rank's)
+        int64_t* fl = my_flag.data_ptr<int64_t>();
+        fl[0] = 0;
+        TORCH_CHECK(fl[4] == 1 && fl[3] == arena_gen((int)x.get_device()),
+                    "ucd conv+abn node: the statistics arena was reset between a link's consumer and its producer (a training forward "
+                    "inside a backward pass?) - run with UCD_STAT_ATOMIC=0");
+        fl[4] = 2;
+        const int64_t R = fl[5];
+        float* global = my_partial.data_ptr<float>();
+        float* local = sync ? global + R * 2 * N : global;
+        if (sync) check(ucd_comm_all_reduce_sum((ucd_comm_t)comm, global, (size_t)(R * 2 * N), (ucd_stream_t)stream), "ucd_comm_all_reduce_sum");
+        if (!param_grad) sums = at::empty({2 * N}, x.options().dtype(at::kFloat));
+        check(ucd_abn_bwd_apply_raw(z.data_ptr(), (int)N, dy.data_ptr(), (int)N, nullptr, 0, dz.data_ptr(), (int)N, nullptr, 0, (int)M,
+                                    (int)N, mean, invstd, scale, fptr(bias), fptr(weight), global, local, (int)R,
+                                    param_grad ? param_grad : sums.data_ptr<float>(), (float)M * (sync ? (float)world : 1.f),
+                                    (int)(UCD_ACT_IDENTITY | (act & UCD_NORM_ABS_GAMMA)), 0.f, (ucd_stream_t)stream),
+              "ucd_abn_bwd_apply_raw");
+        if (has_res) dres = dy;
+        if (!param_grad) {
+          dbias = sums.narrow(0, 0, N);
+          dweight = sums.narrow(0, N, N);
+        }
+      } else if (linked) {
         // the consumer's input-gradient product already applied this layer's activation derivative and left the two sums
         // as per-tile partials: combine them (fixed order) and go straight to the apply pass
         my_flag.data_ptr<int64_t>()[0] = 0;
@@ -721,7 +851,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                                     {false, true, false}));
       }
       return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-              none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+              none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
     if (conv3) {
       // 3x3: input gradient = the same convolution on the flipped + transposed weight (own implicit GEMM, or MIOpen's
@@ -735,7 +865,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
           d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)(9 * N); d.y = dx.data_ptr(); d.ldy = (int)K;
           d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0;
           d.taps = 9; d.H = (int)H; d.W = (int)W; d.dilation = (int)dilation;
-          if (lk_flag.defined() && ctx->saved_data["lk_kind"].toInt() != 3) {
+          if (lk_flag.defined() && ctx->saved_data["lk_kind"].toInt() != 3 && link_servable(lk_flag, x)) {
             link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
             link_record_version(lk_flag, dx);
           }
@@ -752,7 +882,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
                                                     {0, 0}, 1, {false, true, false}));
       }
       return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-              none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+              none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
     const size_t wsb = ucd_gemm_workspace_bytes();
     void* gws = workspace(x, wsb, stream, 1);
@@ -768,7 +898,9 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
         d.a = dz.data_ptr(); d.lda = (int)N; d.w = wflip.data_ptr(); d.ldw = (int)N; d.y = dx.data_ptr(); d.ldy = (int)K;
         d.M = (int)M; d.N = (int)K; d.K = (int)N; d.out_mode = 0; d.accumulate = fold ? 1 : 0;
         const bool block_link = lk_flag.defined() && ctx->saved_data["lk_kind"].toInt() == 3;
-        if (block_link) {
+        if (lk_flag.defined() && !link_servable(lk_flag, x)) {
+          // an atomic link whose arena slot is stale: not served - the producer runs its own reduction pass
+        } else if (block_link) {
           if (with_skip && (fold || !dskip.defined())) block_link_epilogue(d, x, lk_z, lk_buf, lk_partial, lk_flag, K, ctx);
         } else if (lk_flag.defined() && !fold && !dskip.defined()) {
           link_epilogue(d, lk_z, lk_buf, lk_bias, lk_partial, lk_flag, K, ctx);
@@ -818,7 +950,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       dw = dw.as_strided(w4.sizes(), w4.strides());
     }
     return {dx, dw, dweight, dbias, has_res ? dres : none, none, none, none, none, none, none, none, none, none, none, none, none,
-            none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+            none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
   }
 };
 
@@ -830,10 +962,10 @@ std::vector<at::Tensor> conv_abn_train(at::Tensor x, at::Tensor w4, at::Tensor w
                                        c10::optional<at::Tensor> lk_z, c10::optional<at::Tensor> lk_buf,
                                        c10::optional<at::Tensor> lk_bias, c10::optional<at::Tensor> lk_partial,
                                        c10::optional<at::Tensor> lk_flag, int64_t lk_act, double lk_slope, int64_t lk_kind,
-                                       int64_t stride) {
+                                       int64_t stride, bool stat_atomic) {
   return ConvABNTrainNode::apply(x, w4, weight, bias, residual, running_mean, running_var, momentum, eps, act, slope, comm, world,
                                  stream, param_grad, with_skip, fused, dilation, wflip, own_dgrad, wgrad_conv, make_link, lk_z,
-                                 lk_buf, lk_bias, lk_partial, lk_flag, lk_act, lk_slope, lk_kind, stride);
+                                 lk_buf, lk_bias, lk_partial, lk_flag, lk_act, lk_slope, lk_kind, stride, stat_atomic);
 }
 
 at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::optional<at::Tensor> residual,
@@ -847,6 +979,7 @@ at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::opti
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node of the training-mode ABN layer over libucd_hip.so";
+  m.def("stat_arena_reset", &stat_arena_reset, "zero the used part of the statistics arena of a device and start a new generation");
   m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
   m.def("dense_channels_last", &dense_channels_last);
   m.def("conv_stride1", &conv_stride1, "stride-1 conv (3x3 pad=dilation, or 1x1) with the input gradient on the forward solver");

@@ -98,8 +98,14 @@ class GradReducer:
         # objects on a side stream crash hipStreamEndCapture on this stack - measured with bench.py --force_dist ddp)
         self._late_dst, self._late_src = [], []                 # world 1: bf16 -> fp32 gradient copies deferred to finish()
         self.direct = None
+        # UCD_DDP_DIRECT: "auto" (default) takes the library-owned communicator where it has run - the one-rank forced-collectives
+        # mode and a multi-rank run that captures its step (UCD_STEP_GRAPH=1: c10d's work objects cannot be captured) - and leaves a
+        # plain multi-rank eager run on c10d's AVG all-reduce until a 2+ rank lockstep run of the direct path has passed;
+        # "1" / "0" force it
+        dd = _switches.get("UCD_DDP_DIRECT", "auto")
+        want_direct = dd == "1" or (dd == "auto" and (self.world == 1 or _switches.get("UCD_STEP_GRAPH", "auto") == "1"))
         if (self.collective and self.on_gpu and wire_dtype in (None, torch.float32) and dist.get_backend(group) == "nccl"
-                and _switches.get("UCD_DIRECT_RCCL", "1") != "0" and _switches.get("UCD_DDP_DIRECT", "1") != "0"):
+                and _switches.get("UCD_DIRECT_RCCL", "1") != "0" and want_direct):
             from .comm import direct_comm
             self.direct = direct_comm(self.group)
         self.stream = torch.cuda.Stream(self.device) if self.overlap else None
@@ -159,6 +165,7 @@ class GradReducer:
         """One memset per bucket instead of one per tensor; keeps the grad views alive."""
         self._finished = False
         self._dirty = False
+        self.drop_pending_copies()
         if self.direct_flat is not None:
             self.direct_flat.zero_()
             off = 0
@@ -181,6 +188,12 @@ class GradReducer:
                     p.grad = _view_like(b.flat[off:off + p.numel()], p)
                 off += p.numel()
 
+    def drop_pending_copies(self):
+        """Forget widening copies queued by a backward that never reached finish() (an exception, a whole-step capture that failed
+        mid-backward): their sources are tensors of a pass that did not complete - flushed together with the next step's copies they
+        would land in the same bucket views in one multi-tensor launch, in undefined order."""
+        self._late_dst, self._late_src = [], []
+
     def prepare_step(self):
         """Called by the wrapper's forward: if the caller cleared the gradients with ``optim.zero_grad()`` (set_to_none:
         the bucket views are gone) re-attach zeroed views, so that autograd accumulates into the buckets again and the ABN
@@ -189,6 +202,8 @@ class GradReducer:
         dropped = probe is not None and probe.grad is None and self.shadow_of.get(probe) is None
         if not dropped and self.direct_flat is not None:
             dropped = self._direct_modules[0].bias.grad is None
+        if not self._cb_queued:
+            self.drop_pending_copies()                          # a new step begins: nothing queued by an aborted backward survives
         if dropped:
             self.zero_grad()
 

@@ -48,7 +48,8 @@ class Conv1x1Desc(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int), ("out_act", C.c_int), ("out_slope", C.c_float),
                 ("partial", C.c_void_p), ("accumulate", C.c_int),
                 ("taps", C.c_int), ("H", C.c_int), ("W", C.c_int), ("dilation", C.c_int),
-                ("side2", C.c_void_p), ("ld2", C.c_int), ("stride", C.c_int)]
+                ("side2", C.c_void_p), ("ld2", C.c_int), ("stride", C.c_int),
+                ("stat_acc", C.c_void_p), ("stat_shift", C.c_void_p), ("stat_acc2", C.c_void_p), ("stat_rep", C.c_int)]
 
 
 _p, _i, _f, _z = C.c_void_p, C.c_int, C.c_float, C.c_size_t
@@ -62,6 +63,9 @@ SIGNATURES = {
     "ucd_abn_finalize": (_i, [_p, _p, _f, _i, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p]),
     "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _i, _p]),
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
+    "ucd_conv1x1_stat_replicas": (_i, [_i]),
+    "ucd_abn_apply_stats": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _p, _f, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _f, _p]),
+    "ucd_abn_bwd_apply_raw": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _f, _i, _f, _p]),
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),
     "ucd_label_path": (_i, [_p, _p, _i, _i, _p, _p, _p, _p]),
     "ucd_image_path": (_i, [_p, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
@@ -514,7 +518,7 @@ def attmap(x, ld_x, y, ld_y, B, HW, Cc):
 # 1x1 convolutions as fused GEMMs (csrc/conv1x1.hip)
 # ---------------------------------------------------------------------------------------------
 def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, partial=None, accumulate=False, conv3=None,
-            side2=None, strided=None):
+            side2=None, strided=None, stat_acc=None, stat_shift=None, stat_acc2=None, stat_rep=1):
     """y[M, N] = out(in(a)[M, K] . w[N, K]^T).  ``in_norm`` = (mean, scale, shift, act, slope) of the producer's ABN or None;
     ``out_norm`` = (mean, scale, shift, invstd, act, slope) for out_mode 1 / 3.  All 2-D bf16 row matrices.
     ``conv3 = (H, W, dilation)``: 3x3 convolution (stride 1, padding = dilation) of the [B, H, W, K] map behind ``a`` with the
@@ -546,6 +550,8 @@ def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, par
         d.side2, d.ld2 = side2.data_ptr(), side2.stride(0)
     d.partial = ptr(partial)
     d.accumulate = 1 if accumulate else 0
+    # atomic statistics (round 5): column sums into a zeroed [2 N] accumulator instead of per-tile partial rows
+    d.stat_acc, d.stat_shift, d.stat_acc2, d.stat_rep = ptr(stat_acc), ptr(stat_shift), ptr(stat_acc2), int(stat_rep)
     # roofline work of the instrumented bench pass: algorithmic bytes for the 1x1 products (HBM-bound at the network's
     # shapes), flop for the 3x3 implicit GEMM (9 K deep: MFMA-bound)
     work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)
@@ -553,6 +559,29 @@ def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, par
     with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work):
         _check(lib.ucd_conv1x1(C.byref(d), stream()), "ucd_conv1x1")
     return y
+
+
+def abn_apply_stats(x, y, residual, M, Cc, acc, kshift, count, weight, bias, running_mean, running_var, momentum, eps, buf, act,
+                    slope, reps=1):
+    """y = act(norm(x) [+ residual]) with the statistics finalised in the kernel's prologue from the raw sums ``acc`` about
+    ``kshift`` (ucd_abn_apply_stats); mean / invstd / scale land in ``buf[3C:6C]`` like ucd_conv1x1_stats_finalize's."""
+    with _timed("ucd_abn_apply", M * Cc * x.element_size() * (2 + (residual is not None))):
+        _check(load().ucd_abn_apply_stats(ptr(x), Cc, ptr(y), Cc, ptr(residual), Cc if residual is not None else 0, M, Cc, ptr(acc),
+                                          int(reps), ptr(kshift), float(count), ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+                                          float(momentum), float(eps), ptr(buf[3 * Cc:]), ptr(buf[4 * Cc:]), ptr(buf[5 * Cc:]), act,
+                                          float(slope), stream()), "ucd_abn_apply_stats")
+    return y
+
+
+def abn_bwd_apply_raw(x, dy, y, dx, dz, M, Cc, mean, invstd, scale, shift, weight, sums, grad_sums, grad_out, count, act, slope,
+                      reps=1):
+    """dx (and dz) from RAW link sums, the parameter gradients written by the same launch (ucd_abn_bwd_apply_raw)."""
+    with _timed("ucd_abn_bwd_apply", M * Cc * x.element_size() * (3 + (y is not None) + (dz is not None))):
+        _check(load().ucd_abn_bwd_apply_raw(ptr(x), Cc, ptr(dy), Cc, ptr(y), Cc if y is not None else 0, ptr(dx), Cc, ptr(dz),
+                                            Cc if dz is not None else 0, M, Cc, ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                            ptr(weight), ptr(sums), ptr(grad_sums), int(reps), ptr(grad_out), float(count), act, float(slope),
+                                            stream()), "ucd_abn_bwd_apply_raw")
+    return dx
 
 
 def conv1x1_wgrad(dy, a, dw, in_norm=None):

@@ -196,6 +196,13 @@ class IncrementalSegmentationModule(nn.Module):
         out_size = x.shape[-2:]
         if x.is_cuda and x.dim() == 4:
             x = x.contiguous(memory_format=torch.channels_last)
+        if x.is_cuda and self.training and torch.is_grad_enabled():
+            # a training forward begins a step: the statistics accumulators of the conv + ABN nodes (csrc/abn_node.cpp: one zeroed
+            # arena per device, a slot per layer and direction) are cleared with ONE fill and handed out again
+            from . import abn as _abn
+            node = _abn._abn_node()
+            if node is not None and hasattr(node, "stat_arena_reset"):
+                node.stat_arena_reset(x.device.index if x.device.index is not None else torch.cuda.current_device())
         sem, x_b, x_pl = self._network(x, x_b_old, x_pl_old, ret_intermediate)
         logits = F.interpolate(sem, size=out_size, mode="bilinear", align_corners=False) if upsample else None
         return logits, Features(x_b, x_pl, sem)

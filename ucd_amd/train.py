@@ -177,6 +177,11 @@ class Trainer:
             sg["labels"].copy_(labels, non_blocking=True)
             optim.push_hyper()
             sg["graph"].replay()
+            bw = getattr(self.model, "bf16_weights", None)
+            if bw is not None:
+                # the replayed optimiser step staled the flipped / transposed weights for any EAGER iteration that follows (another
+                # batch shape, a dropped graph): the optimiser's post-hook, which sets this flag, does not run in a replay
+                bw._flips_dirty = True
             if scheduler is not None:
                 scheduler.step()
             self.graph_steps += 1
