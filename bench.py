@@ -77,6 +77,7 @@ def parse():
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help=argparse.SUPPRESS)
     p.add_argument("--device", type=int, default=None, help=argparse.SUPPRESS)
     p.add_argument("--check_lockstep", action="store_true", help=argparse.SUPPRESS)   # test hook: ranks compare weights / statistics
+    p.add_argument("--first_step_losses", action="store_true", help=argparse.SUPPRESS)   # test hook: losses of the very first iteration
     return p.parse_args()
 
 
@@ -225,28 +226,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_warm):
+        """n_warm untimed iterations, then EXACTLY args.steps timed ones between barrier + synchronize pairs; max over the ranks"""
+        for _ in range(n_warm):
+            trainer.train_step(images, labels, optimizer, scheduler)
+        sync()
+        before = trainer.graph_steps
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_step(images, labels, optimizer, scheduler)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt, trainer.graph_steps - before == args.steps
+
+    from ucd_amd import switches
     # one-time work never belongs in the timed region, whatever W is: MIOpen's solver search and the GEMM tuning run in
     # the first step, the whole-step hipGraph is captured at the fourth call (the teacher's own graph at the third / fifth
     # when the step is not captured), the library-owned communicator is created at the first SyncBN layer - so at least six
     # untimed steps run before the clock starts
-    for _ in range(max(args.warmup, 6)):
+    multi = world > 1 or bool(args.force_dist)
+    eager_ms = graph_ms = None
+    first_losses = None
+    if args.first_step_losses:
+        # the losses of iteration 1 depend on the initial weights alone: two equivalent arithmetics (plain / forced collectives,
+        # eager / captured) are compared THERE, before nine optimiser steps of a chaotic network separate them
         trainer.train_step(images, labels, optimizer, scheduler)
-    sync()
-    graph_steps_before = trainer.graph_steps
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        trainer.train_step(images, labels, optimizer, scheduler)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        torch.cuda.synchronize()
+        first_losses = {k: float(v) for k, v in trainer.last.items()}
+    if not multi:
+        dt, graphed = timed(max(args.warmup, 6))
+    else:
+        # More than one rank (or the forced-collectives mode): a captured multi-rank iteration has the 212 SyncBN exchanges and the
+        # gradient buckets inside the graph - measured 11.2 against 14.9 ms eager at 3 images with one-rank collectives, never yet
+        # on several GPUs, and the one failure mode seen on the way was a crash, not an exception.  So the EAGER iterations are
+        # timed first and their result leaves the process (stderr + a file) before any capture is attempted; then the step is
+        # captured (UCD_STEP_GRAPH != 0, both collective kinds on library-owned communicators, all ranks agreeing) and timed again.
+        # `value` is the better of the two; execution.eager_ms / graph_ms carry both.
+        want_graph = switches.get("UCD_STEP_GRAPH", "auto") != "0"
+        trainer.step_graph = False
+        dt, graphed = timed(max(args.warmup, 6))
+        eager_ms = 1e3 * dt / args.steps
+        if rank == 0:
+            note = {"phase": "eager (before any capture)", "n_gpus": world, "ms_per_step": eager_ms,
+                    "value": args.global_batch * args.steps / dt, "unit": "images/sec", "global_batch": args.global_batch,
+                    "forced_collectives": bool(args.force_dist and world == 1)}
+            print("UCD_BENCH_EAGER " + json.dumps(note), file=sys.stderr, flush=True)
+            try:
+                with open(os.environ.get("UCD_BENCH_EAGER_FILE", os.path.join(ROOT, f"bench_eager_n{world}.json")), "w") as f:
+                    json.dump(note, f)
+            except OSError:
+                pass
+        if want_graph and trainer.enable_multi_rank_step_graph():
+            dt2, graphed2 = timed(trainer.step_graph_warmup + 3)
+            if graphed2:
+                graph_ms = 1e3 * dt2 / args.steps
+                if dt2 < dt:
+                    dt, graphed = dt2, True
     last = {k: float(v) for k, v in trainer.last.items()}
-    from ucd_amd import switches
     # how the timed iterations actually ran: a silent fallback (capture failed, a kernel family switched off) is visible here
-    execution = {"step_graph": trainer.graph_steps - graph_steps_before == args.steps,
+    execution = {"step_graph": bool(graphed),
                  "step_graph_error": trainer.step_graph_error,
+                 "eager_ms": eager_ms, "graph_ms": graph_ms,      # multi-rank runs: both phases (None: not run / not captured)
                  "teacher_graph": bool(trainer._sg is not None or trainer._tg is not None),
                  "teacher_graph_error": getattr(trainer, "teacher_graph_error", None),
                  "teacher_overlap": trainer._side is not None,
@@ -329,6 +373,8 @@ def main():
         }
         if lockstep is not None:
             out["lockstep"] = bool(lockstep)
+        if first_losses is not None:
+            out["first_step_losses"] = first_losses
         print(json.dumps(out), flush=True)
     if world > 1 or (args.force_dist and dist.is_initialized()):
         dist.destroy_process_group()

@@ -41,20 +41,21 @@ def abn(x, P, name, training, activation="leaky_relu", slope=SLOPE):
     raise ValueError(activation)
 
 
-def residual_block(x, P, name, stride, dilation, training):
+def residual_block(x, P, name, stride, dilation, training, slope=SLOPE):
     """Bottleneck: 1x1 -> ABN -> 3x3(stride, dilation) -> ABN -> 1x1 -> ABN(identity); projection
-    shortcut (1x1 stride + identity ABN) when present; sum; leaky_relu  (residual.py:84-97)."""
+    shortcut (1x1 stride + identity ABN) when present; sum; leaky_relu  (residual.py:84-97).
+    ``slope``: the activation parameter of the block's norm_act layers (residual.py:92-93 reads it from bn1)."""
     if name + ".proj_conv.weight" in P:
         r = F.conv2d(x, P[name + ".proj_conv.weight"], stride=stride)
         r = abn(r, P, name + ".proj_bn", training, "identity")
     else:
         r = x
     c = name + ".convs."
-    y = abn(F.conv2d(x, P[c + "conv1.weight"]), P, c + "bn1", training)
+    y = abn(F.conv2d(x, P[c + "conv1.weight"]), P, c + "bn1", training, slope=slope)
     y = F.conv2d(y, P[c + "conv2.weight"], stride=stride, padding=dilation, dilation=dilation)
-    y = abn(y, P, c + "bn2", training)
+    y = abn(y, P, c + "bn2", training, slope=slope)
     y = abn(F.conv2d(y, P[c + "conv3.weight"]), P, c + "bn3", training, "identity")
-    return F.leaky_relu(y + r, SLOPE)
+    return F.leaky_relu(y + r, slope)
 
 
 def resnet_body(x, P, training, prefix="body.", structure=STRUCTURE_101, output_stride=16):
@@ -69,12 +70,12 @@ def resnet_body(x, P, training, prefix="body.", structure=STRUCTURE_101, output_
     return x
 
 
-def deeplab_head(x, P, training, prefix="head.", pooling_size=32, output_stride=16):
+def deeplab_head(x, P, training, prefix="head.", pooling_size=32, output_stride=16, slope=SLOPE):
     dils = {16: (6, 12, 18), 8: (12, 24, 32)}[output_stride]
     branches = [F.conv2d(x, P[prefix + "map_convs.0.weight"])]
     for i, d in enumerate(dils, 1):
         branches.append(F.conv2d(x, P[prefix + f"map_convs.{i}.weight"], padding=d, dilation=d))
-    out = abn(torch.cat(branches, dim=1), P, prefix + "map_bn", training)           # deeplab.py:56-57
+    out = abn(torch.cat(branches, dim=1), P, prefix + "map_bn", training, slope=slope)           # deeplab.py:56-57
     out = F.conv2d(out, P[prefix + "red_conv.weight"])                             # :58
     if training or pooling_size is None:                                           # :72-76
         pool = x.reshape(x.shape[0], x.shape[1], -1).mean(dim=-1)[:, :, None, None]
@@ -84,12 +85,12 @@ def deeplab_head(x, P, training, prefix="head.", pooling_size=32, output_stride=
                (ph - 1) // 2, (ph - 1) // 2 if ph % 2 == 1 else (ph - 1) // 2 + 1)
         pool = F.pad(F.avg_pool2d(x, (ph, pw), stride=1), pad=pad, mode="replicate")
     pool = F.conv2d(pool, P[prefix + "global_pooling_conv.weight"])                # :61
-    pool = abn(pool, P, prefix + "global_pooling_bn", training)                    # :62
+    pool = abn(pool, P, prefix + "global_pooling_bn", training, slope=slope)                    # :62
     pool = F.conv2d(pool, P[prefix + "pool_red_conv.weight"])                      # :63
     if training or pooling_size is None:
         pool = pool.repeat(1, 1, x.shape[2], x.shape[3])                           # :65-66
     out = out + pool                                                               # :68
-    return abn(out, P, prefix + "red_bn", training)                                # :69
+    return abn(out, P, prefix + "red_bn", training, slope=slope)                                # :69
 
 
 def att_map(x):

@@ -58,3 +58,15 @@ def assert_matches_compact(gold, prefix, arr, rtol=1e-5, atol=1e-6, k=512):
     if rs.size:
         mine = arr.reshape(-1, arr.shape[-1]).astype(np.float64).sum(axis=1)
         np.testing.assert_allclose(mine, rs, rtol=rtol * 10, atol=atol * arr.shape[-1])
+
+
+@pytest.fixture
+def deterministic_stats():
+    """Tests whose claim is BIT equality of two code paths (C++ node vs Python twin, a link switched on / off, a replayed graph vs
+    the eager iteration) run the conv + ABN nodes on the deterministic statistics path: per-tile partial rows combined in a fixed
+    order (``UCD_STAT_ATOMIC=0``).  The default since round 5 accumulates the column sums with fp32 atomics, whose order - and with
+    it the last bits of every batch statistic - changes from run to run."""
+    from ucd_amd import switches
+    switches.set("UCD_STAT_ATOMIC", "0")
+    yield
+    switches.unset("UCD_STAT_ATOMIC")

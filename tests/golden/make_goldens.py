@@ -449,7 +449,18 @@ def gold_aspp_eval():
     save("aspp_eval.npz", **out)
 
 
-def gold_traj513(steps=20):
+TRAJ_UPDATE_NAMES = ("body.mod1.conv1.weight", "body.mod2.block1.convs.conv1.weight", "body.mod3.block2.convs.conv2.weight",
+                     "body.mod4.block10.convs.conv3.weight", "body.mod5.block3.convs.conv3.weight", "head.map_convs.2.weight",
+                     "head.red_conv.weight", "cls.1.weight")
+TRAJ_SAMPLES = 512
+
+
+def traj_sample_index(numel):
+    """the TRAJ_SAMPLES evenly spaced flat indices at which a parameter's accumulated update is stored"""
+    return np.linspace(0, numel - 1, TRAJ_SAMPLES).astype(np.int64)
+
+
+def gold_traj513(steps=20, name="ucd_traj_513_cal.npz"):
     """``steps`` consecutive iterations of train.py:95-151 (as intended) on ONE fixed batch - configs[1] at its real crop, 2 x 513^2,
     calibrated checkpoint, SGD-Nesterov lr 1e-3 / wd 1e-4 in the reference's three groups, no scheduler - through the reference's
     own classes in fp32: the per-step losses are the golden the product's multi-step tests are held to (fp32 mode tightly over
@@ -464,6 +475,16 @@ def gold_traj513(steps=20):
     with torch.no_grad():
         out_old, feat_old = teacher(img)
     rec = {k: [] for k in ("ce", "con", "lkd", "A", "C")}
+    # the reference's accumulated UPDATE of eight parameters across the network: sampled elements + the full length,
+    # after 2 steps (what the regeneration test re-runs) and after all of them - the product's update DIRECTION is held to these
+    params = dict(student.named_parameters())
+    before = {n: params[n].detach().double().clone() for n in TRAJ_UPDATE_NAMES}
+
+    def updates():
+        d = [(params[n].detach().double() - before[n]).flatten() for n in TRAJ_UPDATE_NAMES]
+        return (np.stack([v[torch.from_numpy(traj_sample_index(v.numel()))].numpy() for v in d]),
+                np.array([float(v.norm()) for v in d]))
+    upd2 = None
     for it in range(steps):
         opt.zero_grad()
         outp, feat = student(img)
@@ -477,10 +498,14 @@ def gold_traj513(steps=20):
         for k, v in (("ce", ce.item()), ("con", con.item()), ("lkd", lkd.item()), ("A", a.shape[0]), ("C", c.shape[0])):
             rec[k].append(v)
         print(f"traj step {it}: ce {ce.item():.6f} con {con.item():.6f} lkd {lkd.item():.6f} A {a.shape[0]} C {c.shape[0]}", flush=True)
-    save("ucd_traj_513_cal.npz", cfg=np.array([502, 2, 513, steps]), ce=np.array(rec["ce"]), con=np.array(rec["con"]),
+        if it == 1:
+            upd2 = updates()
+    upd = updates()
+    save(name, cfg=np.array([502, 2, 513, steps]), ce=np.array(rec["ce"]), con=np.array(rec["con"]),
          lkd=np.array(rec["lkd"]), A=np.array(rec["A"]), C=np.array(rec["C"]),
          running_mean_after=student.body.mod1.bn1.running_mean.numpy().copy(),
-         cls1_bias_after=dict(student.named_parameters())["cls.1.bias"].detach().numpy().copy())
+         cls1_bias_after=dict(student.named_parameters())["cls.1.bias"].detach().numpy().copy(),
+         upd2=upd2[0], upd2_norm=upd2[1], upd=upd[0], upd_norm=upd[1])
 
 
 if __name__ == "__main__":
@@ -488,6 +513,8 @@ if __name__ == "__main__":
                              "cfg4_city", "traj513"]
     if "traj513" in which:
         gold_traj513()
+    if "traj513_head" in which:          # the first two iterations only (the regeneration test: equal to the committed file's prefix)
+        gold_traj513(2, "ucd_traj_513_cal_head.npz")
     if "cfg0" in which:
         gold_cfg0()
     if "pixcon" in which:

@@ -249,6 +249,7 @@ def test_cached_flipped_weights_equal_flip_transpose():
     check()
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 def test_conv_abn_python_twin_equals_cpp_node():
     """blocks._ConvABNFunction (the complete Python implementation, what bench.py's instrumented pass runs) and
     csrc/abn_node.cpp::ConvABNTrainNode issue the same library calls: bit-identical outputs, gradients and statistics."""
@@ -374,6 +375,7 @@ def test_residual_block_training_with_own_3x3(cin, chans, dil, hw):
         assert _rel(gf[n], g32[n]) < 1.5 * _rel(gp[n], g32[n]) + 1e-2, (n, _rel(gf[n], g32[n]), _rel(gp[n], g32[n]))
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 @pytest.mark.parametrize("cin,chans,hw", [(1024, (256, 256, 1024), 33), (256, (64, 64, 256), 65)])
 def test_backward_link_moves_the_abn_reduction_into_the_input_gradient_product(cin, chans, hw):
     """conv1 + bn1 -> conv2 + bn2 -> conv3 + bn3 of a bottleneck: with the backward link the input-gradient products of conv2
@@ -431,6 +433,7 @@ def test_backward_link_moves_the_abn_reduction_into_the_input_gradient_product(c
         assert _rel(a, b) < 1e-2, i                                       # node and twin agree with the link on
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 @pytest.mark.parametrize("use_node", [True, False])
 def test_backward_link_refuses_a_second_consumer(use_node):
     """The link's promise - the linked map feeds exactly ONE consumer - is checked at backward time: when the producer's output
@@ -483,6 +486,7 @@ def test_backward_link_refuses_a_second_consumer(use_node):
         mod.finish_grad_sync()
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 def test_backward_link_parity_through_the_model_with_intermediate_features_read():
     """UCD_BWD_LINK=0/1 through the whole student with --loss_de on (ret_intermediate: features["body"] and ["pre_logits"] are
     read by a second loss, train.py:118-121): the link only ever spans maps that stay inside a bottleneck, so the extra readers
@@ -606,13 +610,18 @@ def test_bench_shape_products_are_exact_on_integers_and_statistics_hold(M, K, N,
     torch.testing.assert_close(sums[N:].double(), (dz * ((r.double() - om) * oinv)).sum(0), rtol=2e-4, atol=5e-2)
 
 
-def _worst_param_grad(gf, g32):
+def _worst_param_grad(gf, g32, zero_in_exact_arithmetic=()):
     """Largest relative L2 over the parameter gradients that ARE gradients: behind a batch-statistics norm the gradient of a
-    per-channel shift is zero in exact arithmetic (bn1 / bn2 biases in an identity-activation chain), and a relative error on
-    rounding noise says nothing - parameters whose fp32 gradient is below 1e-3 of the largest (rms) are left out."""
+    per-channel shift is zero in exact arithmetic (a bias whose layer feeds a 1x1 convolution and then a training-mode norm, in an
+    identity-activation chain: ``zero_in_exact_arithmetic`` names them - both sides hold rounding noise there, the independent
+    fp32 reference's is simply another noise), and a relative error on rounding noise says nothing - those and parameters whose
+    fp32 gradient is below 1e-3 of the largest (rms) are left out."""
     rms = {n: g32[n].pow(2).mean().sqrt().item() for n in g32}
     top = max(rms.values())
-    return max(_rel(gf[n], g32[n]) for n in gf if rms[n] > 1e-3 * top)
+    rel = {n: _rel(gf[n], g32[n]) for n in gf if rms[n] > 1e-3 * top and n not in zero_in_exact_arithmetic}
+    worst = max(rel, key=rel.get)
+    print("parameter gradients (relative L2):", {n: round(v, 5) for n, v in sorted(rel.items(), key=lambda kv: -kv[1])[:4]}, "worst:", worst)
+    return rel[worst]
 
 
 @pytest.mark.parametrize("slope", [1.0, 0.01])
@@ -621,7 +630,9 @@ def _worst_param_grad(gf, g32):
 def test_bench_shape_block_chain_fused_against_fp32_layer_by_layer(cin, chans, dil, hw, slope):
     """One identity-shortcut bottleneck of mod2 / mod3 / mod4 / mod5 at the benchmark's batch (B = 24: M = 399 384 / 101 400 /
     26 136) as the chain of conv+ABN nodes the benchmark step runs (statistics epilogues, backward links, shortcut fold, weight
-    gradients) against the SAME block run layer by layer in fp32 - held directly, not relative to another bf16 path.
+    gradients) against an INDEPENDENT fp32 reference: the oracle's functional block (oracle/model.py::residual_block - stock
+    F.conv2d / F.batch_norm / F.leaky_relu on cuda tensors, no product code), so the 205- / 793- / 3121-tile grids
+    and the bench-size kernel forms meet something that is not the product.
     slope = 1 (leaky_relu(1.0) = identity through the same kernels): the arithmetic of the chain alone - output, input gradient
     and every parameter gradient within 1e-2 / 2.5e-2 in relative L2 (each stored map carries one bf16 rounding, 2^-9).
     slope = 0.01 (the network's): a stored map's rounding flips the leaky-ReLU branch of the elements nearest zero - a fraction
@@ -635,36 +646,59 @@ def test_bench_shape_block_chain_fused_against_fp32_layer_by_layer(cin, chans, d
     B = 24
     x0 = synth.t_normal(9, (B, cin, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
     dy = synth.t_normal(10, (B, chans[2], hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    from oracle import model as OM
     outs = []
-    for mode in ("fused", "fp32"):
-        blk = blocks.ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=dil)
-        blk.load_state_dict(synth.fill_state_dict(blk.state_dict(), 5))
-        blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
-        if mode == "fp32":
-            x = x0.float().clone().requires_grad_(True)
-            y = blk(x * 1.0)
-            y.backward(dy.float())
-        else:
-            mod = DistributedDataParallel(blk, bf16_weights=True)
-            x = x0.clone().requires_grad_(True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = mod(x * 1.0)
-            y.backward(dy)
-            mod.finish_grad_sync()
-        outs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in blk.named_parameters()},
-                     blk.convs.bn2.running_var.clone(), blk.convs.bn3.running_mean.clone()))
-        del blk, x, y
-        torch.cuda.empty_cache()
+    blk = blocks.ResidualBlock(cin, chans, norm_act=norm, stride=1, dilation=dil)
+    state = synth.fill_state_dict(blk.state_dict(), 5)
+    blk.load_state_dict(state)
+    blk = blk.to(DEV).to(memory_format=torch.channels_last).train()
+    mod = DistributedDataParallel(blk, bf16_weights=True)
+    x = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mod(x * 1.0)
+    y.backward(dy)
+    mod.finish_grad_sync()
+    outs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in blk.named_parameters()},
+                 blk.convs.bn2.running_var.clone(), blk.convs.bn3.running_mean.clone()))
+    del blk, mod, x, y
+    torch.cuda.empty_cache()
+    # the independent leg: the oracle's functional block on the device, parameters by the reference's state_dict names - in float64
+    # on torch's native kernels (MIOpen off): MIOpen's fp32 batch-norm backward is NOT a usable reference here - its d bias of bn3,
+    # which is nothing but the column sums of dy, is off by 1.5 % (M = 399 384) to 5.4 % (M = 26 136) from those sums taken directly,
+    # the product's by 9e-8 (tests/diag/bn3_bias_diag.py, profiles/r05_bn3_bias_diag.txt)
+    P = {"blk." + k: (v.to(DEV).double() if v.is_floating_point() else v.to(DEV)) for k, v in state.items()}
+    for k, v in P.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        x = x0.double().contiguous().clone().requires_grad_(True)
+        y = OM.residual_block(x * 1.0, P, "blk", 1, dil, True, slope=slope)
+        y.backward(dy.double().contiguous())
+    outs.append((y.detach().float(), x.grad.float(), {k[4:]: v.grad.float() for k, v in P.items() if v.requires_grad},
+                 P["blk.convs.bn2.running_var"].float(), P["blk.convs.bn3.running_mean"].float()))
+    del P, x, y
+    torch.cuda.empty_cache()
     (yf, gxf, gf, rvf, rmf), (y32, gx32, g32, rv32, rm32) = outs
-    worst = _worst_param_grad(gf, g32)
+    assert set(gf) == set(g32)
+    # slope 1 (no activation): a shift of bn2's output passes conv3 (1x1: the same constant on every pixel) and is removed by bn3's
+    # batch mean - d bn2.bias is zero in exact arithmetic; a shift of bn1's output meets conv2's zero padding, so d bn1.bias is the
+    # (small) border term only: it is held on its own, against the scale of the norm's other gradient
+    zero = ("convs.bn2.bias",) if slope == 1.0 else ()
+    border = ("convs.bn1.bias",) if slope == 1.0 else ()
+    worst = _worst_param_grad({n: v for n, v in gf.items() if n not in border}, {n: v for n, v in g32.items() if n not in border}, zero)
+    for n in border:
+        err = (gf[n] - g32[n]).pow(2).mean().sqrt().item()
+        assert err < 2e-2 * g32["convs.bn1.weight"].pow(2).mean().sqrt().item(), (n, err)
     l2 = _rel(gxf, gx32)
     print("bench-shape chain", cin, chans, hw, "slope", slope, "y", _rel(yf, y32), "dx", l2, "worst param grad", worst)
     assert _rel(yf, y32) < 1e-2
     torch.testing.assert_close(rvf, rv32, rtol=5e-3, atol=1e-5)
     torch.testing.assert_close(rmf, rm32, rtol=5e-3, atol=2e-3)
     if slope == 1.0:
-        assert l2 < 1e-2
-        assert worst < 2.5e-2, worst          # measured 1.0-2.0e-2 (the largest on a norm scale's gradient: a sum of M = 4e5 products)
+        # measured against the float64 reference: dx 3.7e-3 on all four shapes, every parameter gradient <= 5.3e-3 (one bf16 rounding
+        # per stored map); pinned at about twice that - NOT to be loosened to follow a kernel change
+        assert l2 < 6e-3, l2
+        assert worst < 1e-2, worst
     else:
         assert l2 < 0.1, l2
         assert worst < 0.13, worst
@@ -674,7 +708,8 @@ def test_bench_shape_block_chain_fused_against_fp32_layer_by_layer(cin, chans, d
 def test_bench_shape_aspp_head_fused_against_fp32(slope):
     """DeeplabV3 in training mode at the benchmark's shape (B = 24, 2048 x 33 x 33): four branches on the own kernels (1x1 and
     three dilated 3x3 implicit GEMMs), map_bn over channel slices, red_conv + statistics, the pooled branch as a plane bias -
-    against the fp32 run of the same module; slopes as in the block test (two activations here: sqrt(2 p) ~ 6 %)."""
+    against the oracle's functional head in fp32 on the device (oracle/model.py::deeplab_head: stock torch operators, no product
+    code); slopes as in the block test (two activations here: sqrt(2 p) ~ 6 %)."""
     from functools import partial
     from ucd_amd import abn, blocks
     from ucd_amd.ddp import DistributedDataParallel
@@ -682,34 +717,47 @@ def test_bench_shape_aspp_head_fused_against_fp32(slope):
     B, C, hw = 24, 2048, 33
     x0 = synth.t_normal(19, (B, C, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
     dy = synth.t_normal(20, (B, 256, hw, hw), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    from oracle import model as OM
     outs = []
-    for mode in ("fused", "fp32"):
-        head = blocks.DeeplabV3(C, 256, 256, norm_act=norm, out_stride=16, pooling_size=32)
-        head.load_state_dict(synth.fill_state_dict(head.state_dict(), 21))
-        head = head.to(DEV).to(memory_format=torch.channels_last).train()
-        if mode == "fp32":
-            x = x0.float().clone().requires_grad_(True)
-            y = head(x * 1.0)
-            y.backward(dy.float())
-        else:
-            mod = DistributedDataParallel(head, bf16_weights=True)
-            x = x0.clone().requires_grad_(True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                y = mod(x * 1.0)
-            y.backward(dy)
-            mod.finish_grad_sync()
-        outs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in head.named_parameters()}))
+    head = blocks.DeeplabV3(C, 256, 256, norm_act=norm, out_stride=16, pooling_size=32)
+    state = synth.fill_state_dict(head.state_dict(), 21)
+    head.load_state_dict(state)
+    head = head.to(DEV).to(memory_format=torch.channels_last).train()
+    mod = DistributedDataParallel(head, bf16_weights=True)
+    x = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mod(x * 1.0)
+    y.backward(dy)
+    mod.finish_grad_sync()
+    outs.append((y.detach().float(), x.grad.float(), {n: p.grad.float().clone() for n, p in head.named_parameters()}))
+    del head, mod, x, y
+    torch.cuda.empty_cache()
+    # float64 on torch's native kernels (see the block test: MIOpen's fp32 batch-norm backward is no reference)
+    P = {"head." + k: (v.to(DEV).double() if v.is_floating_point() else v.to(DEV)) for k, v in state.items()}
+    for k, v in P.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    with torch.backends.cudnn.flags(enabled=False):
+        x = x0.double().contiguous().clone().requires_grad_(True)
+        y = OM.deeplab_head(x * 1.0, P, True, prefix="head.", pooling_size=32, slope=slope)
+        y.backward(dy.double().contiguous())
+    outs.append((y.detach().float(), x.grad.float(), {k[5:]: v.grad.float() for k, v in P.items() if v.requires_grad}))
+    del P, x, y
+    torch.cuda.empty_cache()
     (yf, gxf, gf), (y32, gx32, g32) = outs
-    worst = _worst_param_grad(gf, g32)
+    assert set(gf) == set(g32)
+    # slope 1: map_bn's and the pooled branch's shifts pass a 1x1 convolution and are removed by red_bn's batch mean (zero gradients)
+    worst = _worst_param_grad(gf, g32, ("map_bn.bias", "global_pooling_bn.bias") if slope == 1.0 else ())
     l2 = _rel(gxf, gx32)
     print("bench-shape ASPP slope", slope, "y", _rel(yf, y32), "dx", l2, "worst param grad", worst)
     assert _rel(yf, y32) < 1e-2
     if slope == 1.0:
-        assert l2 < 1e-2 and worst < 1.5e-2, (l2, worst)
+        assert l2 < 1e-2 and worst < 1e-2, (l2, worst)       # measured 5.5e-3 / 4.7e-3 against the float64 reference
     else:
         assert l2 < 0.1 and worst < 0.1, (l2, worst)
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 @pytest.mark.parametrize("cin,chans,hw,dil", [(512, (256, 256, 1024), 33, 1), (256, (64, 64, 256), 65, 1), (1024, (512, 512, 2048), 33, 2)])
 def test_block_link_moves_bn3_backward_into_the_next_blocks_first_product(cin, chans, hw, dil):
     """Three bottlenecks in a row (projection block, identity, identity): with the block link the input-gradient product of an
@@ -937,6 +985,7 @@ def test_strided_forward_statistics_and_weight_gradient(B, H, W, K, N, taps, d):
             assert _rel(dw, gw) < 3e-3 and _rel(dw32, gw) < 1e-4
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 @pytest.mark.parametrize("cin,chans,stride,hw", [(256, (128, 128, 512), 2, 65), (1024, (512, 512, 2048), 1, 33), (64, (64, 64, 256), 1, 65)])
 def test_projection_block_alias_equals_the_separate_gradient_add(cin, chans, stride, hw):
     """Projection blocks (stride and / or channel change; modules/residual.py:79-87): with UCD_PROJ_ALIAS (default) proj_conv reads an
@@ -1122,6 +1171,55 @@ def test_atomic_statistics_epilogues_and_the_finalising_apply_passes(M, K, N, sp
         hip.conv1x1(a, w, y4b, partial=p4, stat_acc=acc4, stat_rep=R, **kw)
         assert torch.equal(y4a, y4b)
         torch.testing.assert_close(acc4.sum(0), s4, rtol=2e-5, atol=5e-3)
+
+
+def test_atomic_links_survive_an_arena_reset_and_refuse_a_second_fill():
+    """The arena slots behind the atomic links (csrc/abn_node.cpp) carry the arena's generation and a fill state: (1) a statistics
+    arena reset between a graph's forward and its backward (another training forward of the model - here an explicit reset)
+    invalidates the slots, the consumers do not serve the links and the producers run their own reduction passes - same gradients
+    as an undisturbed run up to the order of the sums; (2) a retain_graph replay of the consumer would add into a filled slot a
+    second time and raises instead."""
+    from functools import partial
+    from ucd_amd import abn, blocks
+    from ucd_amd.ddp import DistributedDataParallel
+    node = blocks._gemm_node()
+    if node is None or not hasattr(node, "stat_arena_reset"):
+        pytest.skip("C++ node not built")
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    x0 = synth.t_normal(9, (24, 1024, 33, 33), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+    dy = synth.t_normal(10, (24, 1024, 33, 33), stream=1).to(DEV).bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def make():
+        net = torch.nn.Sequential(blocks.ResidualBlock(1024, (256, 256, 1024), norm_act=norm), blocks.ResidualBlock(1024, (256, 256, 1024), norm_act=norm))
+        net.load_state_dict(synth.fill_state_dict(net.state_dict(), 5))
+        net = net.to(DEV).to(memory_format=torch.channels_last).train()
+        return net, DistributedDataParallel(net, bf16_weights=True)
+
+    grads = []
+    for reset_between in (False, True):
+        net, mod = make()
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mod(x * 1.0)
+        if reset_between:
+            node.stat_arena_reset(torch.cuda.current_device())
+        y.backward(dy)
+        mod.finish_grad_sync()
+        torch.cuda.synchronize()
+        grads.append([x.grad.float().clone()] + [p.grad.float().clone() for p in net.parameters()])
+    for a, b in zip(*grads):
+        assert torch.isfinite(a).all() and _rel(a, b) < 2e-2
+    # (2) the consumer of a served link run twice
+    net, mod = make()
+    x = x0.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mod(x * 1.0)
+    y.backward(dy, retain_graph=True)
+    mod.finish_grad_sync(); mod.zero_grad()
+    with pytest.raises(RuntimeError, match="filled twice|second consumer|UCD_STAT_ATOMIC"):
+        y.backward(dy)
+    torch.cuda.synchronize()
+    mod.finish_grad_sync()
 
 
 _RA_CHILD = r"""

@@ -272,21 +272,37 @@ def test_bench_forced_collectives_on_one_gpu_match_the_plain_run(tmp_path):
     out = {}
     for mode, extra in (("plain", []), ("forced", ["--force_dist"])):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env["UCD_BENCH_EAGER_FILE"] = str(tmp_path / f"eager_{mode}.json")
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "3", "--global_batch", "2",
-                            "--crop", "129", "--opt_level", "O0", "--no_miopen_find", "--no_cpu_baseline", "--no_kernel_timing"] + extra,
+                            "--crop", "129", "--opt_level", "O0", "--no_miopen_find", "--no_cpu_baseline", "--no_kernel_timing",
+                            "--first_step_losses"] + extra,
                            capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         assert len(lines) == 1, r.stdout[-2000:]
         out[mode] = json.loads(lines[0])
+        out[mode]["_stderr"] = r.stderr
     a, b = out["plain"], out["forced"]
     assert b["execution"]["forced_collectives"] is True and a["execution"]["forced_collectives"] is False
     assert b["own_kernels"]["UCD_FORCE_COLLECTIVES"] == "1"
-    for k, v in a["losses"].items():
-        assert np.isfinite(b["losses"][k])
-        # nine optimiser steps (six warm-up + three timed) of the chaotic random-weight network separate two equivalent arithmetics
-        # by a few 1e-3 (measured 1e-4 .. 2.4e-3 over five runs; the library's atomics alone move a re-run by as much)
-        assert abs(b["losses"][k] - v) <= 2e-2 * max(1.0, abs(v)), (k, v, b["losses"][k])
+    # the two arithmetics are compared where chaos has not yet acted - the losses of the FIRST iteration, which depend
+    # on the initial weights alone - at 1e-4; the losses after the nine optimiser steps of the run are a finiteness check only.
+    # (This bound may not be loosened to follow the code: a difference beyond it at step 1 is a defect of the collective path.)
+    for k, v in a["first_step_losses"].items():
+        assert abs(b["first_step_losses"][k] - v) <= 1e-4 * max(1.0, abs(v)), (k, v, b["first_step_losses"][k])
+    for k in a["losses"]:
+        assert np.isfinite(b["losses"][k]) and np.isfinite(a["losses"][k])
+    # a run that issues the multi-rank collectives times its EAGER iterations first and gets that number out of the
+    # process (stderr + a file) before any capture is attempted; then it captures the step and reports both
+    ex = b["execution"]
+    assert ex["eager_ms"] is not None and ex["eager_ms"] > 0
+    assert "UCD_BENCH_EAGER {" in b["_stderr"]
+    note = json.loads((tmp_path / "eager_forced.json").read_text())
+    assert abs(note["ms_per_step"] - ex["eager_ms"]) < 1e-6 and note["forced_collectives"] is True
+    assert ex["graph_ms"] is not None or ex["step_graph_error"] is not None, ex
+    if ex["graph_ms"] is not None:
+        assert b["ms_per_step"] <= min(ex["eager_ms"], ex["graph_ms"]) + 1e-9
+    assert a["execution"]["eager_ms"] is None and a["execution"]["graph_ms"] is None      # a plain run has one phase
 
 
 def test_aborted_backward_leaves_no_widening_copies_behind():

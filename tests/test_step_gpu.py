@@ -133,6 +133,7 @@ def test_checkpoint_roundtrip_reference_layout(tmp_path):
     ddp.load_state_dict(ck["model_state"], strict=True)
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 def test_bf16_working_weights_equal_per_call_casts(tmp_path):
     """--opt_level O1 with the flat bf16 working copies (ucd_amd/master.py) is the same arithmetic as autocast's
     per-call weight casts: two steps from the same state give the same losses and the same updated fp32 weights,
@@ -500,6 +501,11 @@ TRAJ_UPDATE_NAMES = ("body.mod1.conv1.weight", "body.mod2.block1.convs.conv1.wei
                      "head.red_conv.weight", "cls.1.weight")
 
 
+# bf16 mode against the REFERENCE's updates: cosine floors per part of the network (body: the chaotic random-weight stack, see the
+# comment at the bf16-vs-fp32 assertion below; head / classifier: tight)
+TRAJ_BF16_REF_COS = {"body": 0.75, "head": 0.97, "cls": 0.97}
+
+
 def _trajectory(opt_level, steps, step_graph="0"):
     """``steps`` iterations of the product on the fixed 2 x 513^2 batch of tests/golden/make_goldens.py::gold_traj513 (calibrated
     checkpoint, lr 1e-3, no scheduler); returns the per-step losses and the accumulated update of a few parameters."""
@@ -572,6 +578,18 @@ def test_twenty_step_trajectory_fp32_and_bf16_against_the_reference():
     np.testing.assert_allclose(ex32["cls1_bias"], g["cls1_bias_after"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(ex16["cls1_bias"], g["cls1_bias_after"], rtol=2e-2, atol=1e-5)
     np.testing.assert_allclose(ex32["running_mean"], g["running_mean_after"], rtol=1e-3, atol=1e-6)
+    # the REFERENCE's accumulated updates (512 evenly spaced elements of each of the eight tensors + the full length,
+    # tests/golden/make_goldens.py::gold_traj513) hold the fp32 product's update DIRECTION and LENGTH - not only its losses - and the
+    # bf16 mode is compared with the reference, not with the product's own fp32 path
+    for i, n in enumerate(TRAJ_UPDATE_NAMES):
+        ref = torch.from_numpy(g["upd"][i])
+        idx = torch.from_numpy(np.linspace(0, up32[n].numel() - 1, ref.numel()).astype(np.int64))
+        for tag, up, cos_floor, len_tol in (("fp32", up32, 0.99, 0.03), ("bf16", up16, TRAJ_BF16_REF_COS[n.split(".")[0]], 0.25)):
+            mine = up[n].flatten()[idx]
+            cos = float(mine @ ref / (mine.norm() * ref.norm() + 1e-300))
+            ratio = float(up[n].norm() / float(g["upd_norm"][i]))
+            print(f"update over {steps} steps, {tag} vs the reference: {n}: cosine {cos:.4f} length ratio {ratio:.3f}")
+            assert cos > cos_floor and abs(ratio - 1.0) < len_tol, (tag, n, cos, ratio)
     for n in TRAJ_UPDATE_NAMES:
         a, b = up32[n].flatten(), up16[n].flatten()
         cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
@@ -584,6 +602,8 @@ def test_twenty_step_trajectory_fp32_and_bf16_against_the_reference():
         # in another order - same products bit for bit, mean / invstd equal to 1e-6 (test_small_grids_on_64_column_tiles...) - is
         # another realisation: 0.84 - 0.87 and 1.10 - 1.17 over eleven runs with the 64-column tiles of round 4, 0.88 with them on
         # the N = 256 layers only, 0.90 - 0.94 on earlier kernel generations.  The floors leave room for that spread.
+        # PINNED: these floors may not be lowered to follow a code change - a build that falls below them needs a new
+        # explanation AND the reference comparison above still green; the fp32-vs-reference bound (0.99) is the tight one.
         floor = 0.78 if n.startswith("body.") else 0.98
         assert cos > floor and 0.85 < ratio < 1.25, (n, cos, ratio)
 
@@ -632,27 +652,36 @@ def _scheduled_steps(step_graph, steps=8, batch=3, crop=257, reload_at=None):
         switches.unset("UCD_STEP_GRAPH")
 
 
-def test_whole_step_graph_replays_the_eager_iteration():
+@pytest.mark.parametrize("stat_atomic", ["0", "1"])
+def test_whole_step_graph_replays_the_eager_iteration(stat_atomic):
     """The captured iteration (Trainer._graph_step: teacher + student forward, losses, backward, bucket hand-over, one-launch
     optimiser with its hyper-parameters on the device) is the eager iteration: same losses at every step, same parameters and
     running statistics after 8 steps on two alternating batches under a steep PolyLR - the learning rate reaches the replayed
     optimiser kernel, the inputs reach the static buffers, and nothing that ran on the host during the capture is missing from
-    the replay."""
-    eager, pe, n_e, lrs_e, _ = _scheduled_steps("0")
-    graph, pg, n_g, lrs_g, err = _scheduled_steps("1")
+    the replay.  stat_atomic 0: the deterministic statistics path (tight bounds: two runs differ by the library's stem weight
+    gradient alone); 1: the default since round 5 - fp32-atomic column sums whose order changes from run to run AND the arena's
+    one-fill-per-step inside the captured graph - held to the bounds two EAGER runs of that mode keep between each other."""
+    from ucd_amd import switches
+    switches.set("UCD_STAT_ATOMIC", stat_atomic)
+    try:
+        eager, pe, n_e, lrs_e, _ = _scheduled_steps("0")
+        graph, pg, n_g, lrs_g, err = _scheduled_steps("1")
+    finally:
+        switches.unset("UCD_STAT_ATOMIC")
     assert err is None, err
     assert n_e == 0 and n_g == 8 - 3, (n_e, n_g)          # three eager warm-up iterations, then replays only
     assert lrs_e == lrs_g and lrs_e[-1] < 0.35 * lrs_e[0]
     print("eager vs graph losses, max rel:", np.abs(eager - graph).max(0) / np.abs(eager).max(0))
-    np.testing.assert_allclose(graph, eager, rtol=2e-3)
+    np.testing.assert_allclose(graph, eager, rtol=2e-3 if stat_atomic == "0" else 1e-2)
     for n in pe:
         d = ((pe[n] - pg[n]).norm() / pe[n].norm()).item()
-        assert d < 1e-4, (n, d)
+        assert d < (1e-4 if stat_atomic == "0" else 5e-3), (n, d)
     # and the update itself took the schedule: against a run whose optimiser never saw the decay the weights differ visibly
     first = eager[0]
     assert np.all(np.isfinite(graph)) and graph[-1][3] < first[3]
 
 
+@pytest.mark.usefixtures("deterministic_stats")
 def test_step_graph_is_dropped_and_rebuilt_when_the_optimiser_state_moves():
     """``optim.load_state_dict`` (resume) replaces the momentum buffers: the captured optimiser launch would update the OLD ones.
     The trainer notices (``SGD.plan_is_current``), drops the graph, runs eagerly and captures again after its warm-up count - the

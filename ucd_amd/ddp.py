@@ -364,6 +364,20 @@ class GradReducer:
         self._inflight = []
         self._reset_step()
 
+    def enable_direct(self):
+        """Move the fp32 gradient buckets to the library-owned RCCL communicator (``UCD_DDP_DIRECT`` decided against it at
+        construction: a plain multi-rank run keeps c10d's AVG all-reduce).  A collective: every rank calls it.  Returns True when
+        the buckets now run on the direct path - what a captured multi-rank step needs (c10d's asynchronous work objects crash
+        hipStreamEndCapture on this stack)."""
+        if self.direct is not None:
+            return True
+        if not (self.collective and self.on_gpu and self.wire_dtype in (None, torch.float32) and dist.get_backend(self.group) == "nccl"
+                and _switches.get("UCD_DIRECT_RCCL", "1") != "0" and _switches.get("UCD_DDP_DIRECT", "auto") != "0"):
+            return False
+        from .comm import direct_comm
+        self.direct = direct_comm(self.group)
+        return self.direct is not None
+
     def _reset_step(self):
         """Per-step bucket state back to 'nothing arrived' (also done by zero_grad): a loop that never calls the reducer's
         zero_grad (the reference's optim.zero_grad()) must find fresh counters at its next backward."""

@@ -109,6 +109,27 @@ class Trainer:
         self.graph_steps = 0                # iterations served by a graph replay (bench.py reports it)
         self.step_graph_error = None
 
+    def enable_multi_rank_step_graph(self):
+        """Turn the captured iteration on for a run with more than one rank (or a one-rank group with forced collectives), AFTER the
+        eager iterations have been measured: both collective kinds must sit on library-owned RCCL communicators (the SyncBN exchanges:
+        ucd_amd.comm.direct_comm of the default group; the gradient buckets: GradReducer.enable_direct) and every rank must agree -
+        otherwise the run stays eager.  Collective: every rank calls it at the same point.  Returns True when the next iterations
+        will be captured."""
+        if self.device.type != "cuda" or _switches.get("UCD_STEP_GRAPH", "auto") == "0" or self.lde_flag:
+            return False
+        ok = True
+        if dist.is_available() and dist.is_initialized():
+            from . import abn as _abn
+            from .comm import _agree, direct_comm
+            reducer = getattr(self.model, "reducer", None)
+            ok = reducer is not None and reducer.enable_direct()
+            ok = _agree(ok, None, self.device)
+            if ok and (dist.get_world_size() > 1 or _abn._FORCE_SYNC):
+                ok = direct_comm(None) is not None                          # same answer on every rank (its own agreement rounds)
+        if ok:
+            self.step_graph, self._sg, self._sg_seen, self.step_graph_error = True, None, 0, None
+        return ok
+
     # ------------------------------------------------------------------------------------------
     def _autocast(self):
         return torch.autocast(device_type="cuda", dtype=torch.bfloat16, enabled=self.amp and self.device.type == "cuda")
