@@ -56,6 +56,9 @@ enum ucd_error {
 
 int ucd_version(void);
 const char* ucd_last_error(void);
+/* `bytes` zero bytes at `ptr`, in stream order (one memset node when the stream is being captured): the per-step fill of the
+ * statistics arena (ucd_conv1x1_desc.stat_acc; csrc/abn_node.cpp) - a plain memset, so no tensor version counter moves. */
+int ucd_fill_zero(void* ptr, size_t bytes, ucd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * ABN: fused BatchNorm + LeakyReLU(slope) / identity.  Replaces the inplace-abn==1.0.7 CUDA extension

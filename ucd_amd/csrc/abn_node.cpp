@@ -60,18 +60,21 @@ int64_t arena_gen(int dev) {
   return g_arena[dev].gen;
 }
 
-void stat_arena_reset(int64_t dev) {
+void stat_arena_reset(int64_t dev, int64_t stream) {
   std::lock_guard<std::mutex> lock(g_mu);
   auto it = g_arena.find((int)dev);
   if (it == g_arena.end() || !it->second.buf.defined()) return;
   StatArena& a = it->second;
-  if (a.off > 0) a.buf.narrow(0, 0, a.off).zero_();      // one fill on the current stream (a memset node in a captured step)
+  // one fill in stream order (a memset node in a captured step).  A raw memset, not Tensor::zero_(): slots handed out earlier are
+  // views of this buffer saved by autograd nodes, and an in-place ATen op would move their shared version counter - a backward that
+  // follows a reset must reach the generation check (and fall back), not autograd's "modified by an inplace operation"
+  if (a.off > 0) check(ucd_fill_zero(a.buf.data_ptr(), (size_t)a.off * sizeof(float), (ucd_stream_t)stream), "ucd_fill_zero");
   a.off = 0;
   a.gen += 1;
 }
 
 // n floats (rounded to 64) of zeros, or an undefined tensor (arena switched off by the caller / request larger than the arena)
-at::Tensor arena_alloc(const at::Tensor& like, int64_t n, int64_t* gen) {
+at::Tensor arena_alloc(const at::Tensor& like, int64_t n, int64_t* gen, int64_t stream) {
   const int dev = (int)like.get_device();
   n = (n + 63) / 64 * 64;
   {
@@ -86,7 +89,7 @@ at::Tensor arena_alloc(const at::Tensor& like, int64_t n, int64_t* gen) {
       return t;
     }
   }
-  stat_arena_reset(dev);                       // full (nobody resets per step): zero it, invalidate the outstanding slots
+  stat_arena_reset(dev, stream);               // full (nobody resets per step): zero it, invalidate the outstanding slots
   std::lock_guard<std::mutex> lock(g_mu);
   StatArena& a = g_arena[dev];
   at::Tensor t = a.buf.narrow(0, 0, n);
@@ -607,7 +610,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       if (stride > 1) { d.H = (int)H; d.W = (int)W; d.stride = (int)stride; }
       int64_t gen = 0;
       const int64_t R = ucd_conv1x1_stat_replicas((int)M);
-      at::Tensor acc = (stat_atomic && N % 8 == 0) ? arena_alloc(x, R * 2 * N, &gen) : at::Tensor();
+      at::Tensor acc = (stat_atomic && N % 8 == 0) ? arena_alloc(x, R * 2 * N, &gen, stream) : at::Tensor();
       if (acc.defined()) {
         // sums about the running mean (equal on every rank), straight into the layer's accumulator; SyncBN: one all-reduce of the
         // 2 N raw sums (they are additive about a common shift) instead of gather + Chan combination
@@ -684,7 +687,7 @@ class ConvABNTrainNode : public torch::autograd::Function<ConvABNTrainNode> {
       my_flag = at::zeros({6}, at::TensorOptions().dtype(at::kLong));   // {served, address of the consumer's dx, its version, generation, state, replicas}
       int64_t gen = 0;
       const int64_t R = ucd_conv1x1_stat_replicas((int)M);
-      if (stat_atomic && N % 8 == 0) my_partial = arena_alloc(x, (sync ? 2 : 1) * R * 2 * N, &gen);
+      if (stat_atomic && N % 8 == 0) my_partial = arena_alloc(x, (sync ? 2 : 1) * R * 2 * N, &gen, stream);
       if (my_partial.defined()) {
         my_partial = my_partial.narrow(0, 0, (sync ? 2 : 1) * R * 2 * N);
         my_flag.data_ptr<int64_t>()[3] = gen;

@@ -24,4 +24,13 @@ int check_launch(const char* what) {
 extern "C" {
 int ucd_version(void) { return UCD_VERSION; }
 const char* ucd_last_error(void) { return ucd::g_error; }
+
+int ucd_fill_zero(void* ptr, size_t bytes, ucd_stream_t stream) {
+  if (!ptr || bytes == 0) return 0;
+  hipError_t e = hipMemsetAsync(ptr, 0, bytes, (hipStream_t)stream);
+  if (e == hipSuccess) return 0;
+  (void)hipGetLastError();
+  ucd::set_error("ucd_fill_zero: hipMemsetAsync: %s", hipGetErrorString(e));
+  return (int)e;
+}
 }

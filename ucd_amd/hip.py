@@ -64,6 +64,7 @@ SIGNATURES = {
     "ucd_abn_eval_params": (_i, [_p, _p, _f, _i, _p, _p, _i, _p]),
     "ucd_abn_apply": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p]),
     "ucd_conv1x1_stat_replicas": (_i, [_i]),
+    "ucd_fill_zero": (_i, [_p, _z, _p]),
     "ucd_abn_apply_stats": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _p, _i, _p, _f, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _f, _p]),
     "ucd_abn_bwd_apply_raw": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _f, _i, _f, _p]),
     "ucd_abn_bwd_reduce": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _p, _z, _p]),

@@ -202,7 +202,7 @@ class IncrementalSegmentationModule(nn.Module):
             from . import abn as _abn
             node = _abn._abn_node()
             if node is not None and hasattr(node, "stat_arena_reset"):
-                node.stat_arena_reset(x.device.index if x.device.index is not None else torch.cuda.current_device())
+                node.stat_arena_reset(x.device.index if x.device.index is not None else torch.cuda.current_device(), hip.stream())
         sem, x_b, x_pl = self._network(x, x_b_old, x_pl_old, ret_intermediate)
         logits = F.interpolate(sem, size=out_size, mode="bilinear", align_corners=False) if upsample else None
         return logits, Features(x_b, x_pl, sem)
