@@ -140,10 +140,22 @@ def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
     overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
     out = {}
     for name, calls in rec.items():
-        per_call = [s.elapsed_time(e) for s, e, _ in calls]
+        per_call = [c[0].elapsed_time(c[1]) for c in calls]
         ms = sum(per_call)
-        work = sum(w for _, _, w in calls)
+        work = sum(c[2] for c in calls)
         out[name] = {"launches": len(calls), "ms_total": ms, "avg_us": 1e3 * ms / max(1, len(calls)), "work": work}
+        if calls and len(calls[0]) > 3:
+            # per-SHAPE bound: a 1x1 product is priced against whichever of its two roofs is the longer -
+            # bytes / 8 TB/s or flop / 2.5 PFLOP/s (2048 -> 512, 512 -> 2048 and 1024 -> 2048 are MFMA-bound, K N / (K + N) > 312)
+            mix = {"hbm": [0.0, 0.0], "mfma": [0.0, 0.0]}      # measured ms, roof ms
+            for t, c in zip(per_call, calls):
+                t_h, t_m = c[2] / (PEAK_HBM_GBS * 1e9) * 1e3, c[3] / (PEAK_F16_MFMA_TF * 1e12) * 1e3
+                k = "mfma" if t_m > t_h else "hbm"
+                mix[k][0] += t
+                mix[k][1] += max(t_h, t_m)
+            out[name]["bound_mix"] = {"hbm_ms": mix["hbm"][0], "mfma_ms": mix["mfma"][0],
+                                      "hbm_frac": mix["hbm"][1] / mix["hbm"][0] if mix["hbm"][0] else None,
+                                      "mfma_frac": mix["mfma"][1] / mix["mfma"][0] if mix["mfma"][0] else None}
     out["_event_pair_overhead_us"] = 1e3 * overhead_ms
     return out
 
@@ -331,12 +343,14 @@ def main():
             ach = k["work"] / (k["ms_total"] * 1e-3) / 1e9
             roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": ach / PEAK_HBM_GBS, "traffic": None}
+        if "bound_mix" in k:
+            roof["bound_mix"] = k["bound_mix"]       # the call type split by each call's own roof (ms in the instrumented pass, fractions)
         roof["avg_launch_us"] = k["avg_us"]
         roof["event_pair_overhead_us"] = ev_us       # empty event pair, for reference (not subtracted)
         roof["launches_per_step"] = k["launches"] / min(args.steps, 3)
         # HBM traffic of that kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_to_json.py); null if absent
-        for rnd in ("r04", "r03", "r02"):                   # the newest committed collection that has this call
+        for rnd in ("r05", "r04", "r03", "r02"):            # the newest committed collection that has this call
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench.json")
             if not os.path.exists(pmc):
                 continue
@@ -375,9 +389,17 @@ def main():
             out["lockstep"] = bool(lockstep)
         if first_losses is not None:
             out["first_step_losses"] = first_losses
-        print(json.dumps(out), flush=True)
     if world > 1 or (args.force_dist and dist.is_initialized()):
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's stdio buffer until exit and would
+        # otherwise land behind it (a multi-GPU line must stay parseable as "the last line")
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -69,7 +69,17 @@ with open(sys.argv[2], "w") as f:
     f.write("# ABN stream kernels by grid size (threads): ms/step, calls/step, avg us\n")
     for (k, g_), (d, c) in sorted(bygrid.items(), key=lambda kv: -kv[1][0])[:24]:
         f.write("#   %8.3f %6.1f %8.2f  %-28s grid %s\n" % (d / 2e6, c / 2, d / c / 1e3, k, g_))
+    # the GEMM / implicit-GEMM / weight-gradient kernels by launch geometry (= by layer shape; grid in threads)
+    bygrid = collections.defaultdict(lambda: [0, 0])
+    for r in win:
+        k = short(r["Kernel_Name"])
+        if any(n in k for n in ("conv1x1_kernel", "conv_lw_kernel", "conv_ra_kernel", "wgrad3_kernel", "wgrad_kernel")):
+            key = (k.split(None, 1)[1], "x".join(str(r[c]) for c in sorted(r) if c.startswith("Grid_Size")))
+            bygrid[key][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); bygrid[key][1] += 1
+    f.write("# GEMM kernels by grid size (threads): ms/step, calls/step, avg us\n")
+    for (k, g_), (d, c) in sorted(bygrid.items(), key=lambda kv: -kv[1][0])[:48]:
+        f.write("#   %8.3f %6.1f %8.2f  %-60s grid %s\n" % (d / 2e6, c / 2, d / c / 1e3, k, g_))
     f.write("# largest idle gaps of the two steps (us: after kernel -> before kernel)\n")
     for g_, a_, b_ in big[:14]:
         f.write("#   %8.1f  %s  ->  %s\n" % (g_ / 1e3, a_[:60], b_[:60]))
-print(open(sys.argv[2]).read()[:9000])
+print(open(sys.argv[2]).read()[:14000])

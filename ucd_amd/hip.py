@@ -178,8 +178,10 @@ def disable_call_timing():
 class _Timed:
     """with _timed(name, work): <library call>"""
 
-    def __init__(self, name, work):
-        self.name, self.work = name, work
+    def __init__(self, name, work, flops=None):
+        # work: the call type's roofline unit (bytes for the HBM-bound types, flop for the MFMA-bound ones); flops: for the 1x1
+        # products ALSO the flop count, so that bench.py can classify each call by min(bytes / 8 TB/s, flop / 2.5 PFLOP/s)
+        self.name, self.work, self.flops = name, work, flops
 
     def __enter__(self):
         self.start = torch.cuda.Event(enable_timing=True)
@@ -188,7 +190,8 @@ class _Timed:
 
     def __exit__(self, *exc):
         self.end.record(torch.cuda.current_stream())
-        _timing.setdefault(self.name, []).append((self.start, self.end, self.work))
+        _timing.setdefault(self.name, []).append((self.start, self.end, self.work) if self.flops is None
+                                                 else (self.start, self.end, self.work, self.flops))
         return False
 
 
@@ -203,8 +206,8 @@ class _NoTimer:
 _NO_TIMER = _NoTimer()
 
 
-def _timed(name, work):
-    return _NO_TIMER if _timing is None else _Timed(name, work)
+def _timed(name, work, flops=None):
+    return _NO_TIMER if _timing is None else _Timed(name, work, flops)
 
 
 def ptr(t):
@@ -557,7 +560,7 @@ def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, par
     # shapes), flop for the 3x3 implicit GEMM (9 K deep: MFMA-bound)
     work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)
                                                                                  + (side2 is not None)))
-    with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work):
+    with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work, None if conv3 is not None else 2 * M * K * N):
         _check(lib.ucd_conv1x1(C.byref(d), stream()), "ucd_conv1x1")
     return y
 
