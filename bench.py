@@ -262,6 +262,12 @@ def main():
     # untimed steps run before the clock starts
     multi = world > 1 or bool(args.force_dist)
     eager_ms = graph_ms = None
+    # the one-shot mailbox exchange (csrc/comm.hip) is measured LAST and under a watchdog (mailbox_phase below): the eager and the
+    # captured iterations are timed with the SyncBN exchanges on RCCL first, so a mailbox that misbehaves on a node this build has
+    # never seen cannot cost the run its number
+    mail_sw = switches.get("UCD_IPC_SYNC", "auto")
+    if world > 1:
+        switches.set("UCD_IPC_SYNC", "0")
     first_losses = None
     if args.first_step_losses:
         # the losses of iteration 1 depend on the initial weights alone: two equivalent arithmetics (plain / forced collectives,
@@ -309,8 +315,8 @@ def main():
                  # --force_dist: a one-rank RCCL group with every SyncBN / gradient collective issued (NOT a multi-GPU number)
                  "forced_collectives": bool(args.force_dist and world == 1)}
     own_kernels = switches.snapshot()
-    lockstep = None
-    if args.check_lockstep and world > 1:
+    own_kernels["UCD_IPC_SYNC"] = mail_sw       # as the caller set it (execution.mailbox says what the third phase did with it)
+    def check_lockstep():
         # data parallelism keeps every replica identical: after the timed steps all ranks must hold the same parameters AND
         # the same running statistics (SyncBN), bit for bit (gradients are averaged before the update, statistics are
         # combined from the same gathered table on every rank)
@@ -319,7 +325,14 @@ def main():
                            if t.is_floating_point()])
         gathered = [torch.zeros_like(sig) for _ in range(world)]
         dist.all_gather(gathered, sig)
-        lockstep = all(torch.equal(g, gathered[0]) for g in gathered)
+        same = all(torch.equal(g, gathered[0]) for g in gathered)
+        if not same and rank == 0:
+            names = [n for n, t in list(net.named_parameters()) + list(net.named_buffers()) if t.is_floating_point()]
+            bad = [(names[i], [float(g[i] - gathered[0][i]) for g in gathered]) for i in range(len(names))
+                   if any(g[i] != gathered[0][i] for g in gathered)]
+            print("UCD_BENCH_LOCKSTEP %d of %d tensors differ between the ranks; first: %s" % (len(bad), len(names), bad[:6]),
+                  file=sys.stderr, flush=True)
+        return same
 
     roof, kernels = None, None
     if not args.no_kernel_timing:
@@ -385,13 +398,12 @@ def main():
             "losses": last, "execution": execution, "own_kernels": own_kernels,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
         }
-        if lockstep is not None:
-            out["lockstep"] = bool(lockstep)
         if first_losses is not None:
             out["first_step_losses"] = first_losses
-    if world > 1 or (args.force_dist and dist.is_initialized()):
-        dist.destroy_process_group()
-    if rank == 0:
+    else:
+        out = None
+
+    def emit():
         # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's stdio buffer until exit and would
         # otherwise land behind it (a multi-GPU line must stay parseable as "the last line")
         try:
@@ -400,6 +412,55 @@ def main():
         except OSError:
             pass
         print(json.dumps(out), flush=True)
+
+    if world > 1 and mail_sw != "0":
+        # Third phase: the SyncBN exchanges on the mailbox.  `out` already holds the RCCL phases' result; a watchdog on every rank
+        # prints it (rank 0) and leaves if this phase does not come back, an exception does the same at once.
+        import threading
+        limit = float(os.environ.get("UCD_BENCH_MAILBOX_LIMIT_S", "240"))
+        finished = threading.Event()
+
+        def bail(why):
+            if rank == 0:
+                out["execution"]["mailbox"] = {"error": why}
+                emit()
+            sys.stderr.flush()
+            os._exit(0)
+
+        def watchdog():
+            if not finished.wait(limit):
+                bail("watchdog: the mailbox phase did not finish within %.0f s" % limit)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            from ucd_amd.comm import attach_mailbox, mailbox_timeouts
+            switches.set("UCD_IPC_SYNC", mail_sw)
+            if "UCD_IPC_TIMEOUT_MS" not in os.environ:
+                switches.set("UCD_IPC_TIMEOUT_MS", "10000")
+            info = {"attached": bool(attach_mailbox(None))}
+            if info["attached"]:
+                if not (graph_ms is not None and trainer.enable_multi_rank_step_graph()):
+                    trainer.step_graph = False
+                dt3, graphed3 = timed(trainer.step_graph_warmup + 3)
+                t = torch.tensor([float(mailbox_timeouts(None))], device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                info.update(ms_per_step=1e3 * dt3 / args.steps, step_graph=bool(graphed3), timeouts=int(t.item()))
+                if rank == 0 and info["timeouts"] == 0 and dt3 < dt:
+                    out.update(value=args.global_batch * args.steps / dt3, ms_per_step=1e3 * dt3 / args.steps)
+                    out["execution"]["step_graph"] = bool(graphed3)
+                    out["losses"] = {k: float(v) for k, v in trainer.last.items()}
+            if rank == 0:
+                out["execution"]["mailbox"] = info
+        except Exception as e:
+            bail("mailbox phase failed on rank %d: %s" % (rank, repr(e)[:300]))
+        finished.set()
+    if args.check_lockstep and world > 1:
+        same = check_lockstep()
+        if rank == 0:
+            out["lockstep"] = bool(same)
+    if world > 1 or (args.force_dist and dist.is_initialized()):
+        dist.destroy_process_group()
+    if rank == 0:
+        emit()
 
 
 if __name__ == "__main__":

@@ -32,7 +32,7 @@ extern "C" {
 #define UCD_VERSION 100 /* 0.1.0 */
 
 typedef void* ucd_stream_t; /* hipStream_t */
-typedef void* ucd_comm_t;   /* RCCL communicator owned by this library (ucd_comm_init) */
+typedef void* ucd_comm_t;   /* communicator owned by this library (ucd_comm_init: RCCL, optionally with an IPC mailbox) */
 
 enum ucd_dtype { UCD_F32 = 0, UCD_BF16 = 1 };
 enum ucd_act { UCD_ACT_IDENTITY = 0, UCD_ACT_LEAKY_RELU = 1, UCD_ACT_ELU = 2 /* slope = alpha */ };
@@ -49,7 +49,8 @@ enum ucd_error {
   UCD_EINVAL = -1,      /* bad argument (null pointer, negative size, unknown enum) */
   UCD_EALIGN = -2,      /* pointer / leading dimension / channel count not 16-byte friendly */
   UCD_EWORKSPACE = -3,  /* workspace too small */
-  UCD_EUNSUPPORTED = -4 /* shape outside what the kernels are built for */
+  UCD_EUNSUPPORTED = -4, /* shape outside what the kernels are built for */
+  UCD_ETIMEOUT = -5     /* a mailbox exchange of the communicator timed out earlier (a rank never wrote): the communicator is dead */
 #define UCD_ERCCL_BASE 100000 /* RCCL failures are returned as UCD_ERCCL_BASE + ncclResult_t */
 #define UCD_EBLAS_BASE 200000 /* hipBLASLt failures are returned as UCD_EBLAS_BASE + hipblasStatus_t */
 };
@@ -235,6 +236,23 @@ int ucd_comm_destroy(ucd_comm_t comm);
 int ucd_comm_all_gather(ucd_comm_t comm, const float* send, float* recv /* [nranks*count] */, size_t count,
                         ucd_stream_t stream);
 int ucd_comm_all_reduce_sum(ucd_comm_t comm, float* buf, size_t count, ucd_stream_t stream);
+
+/* One-shot mailbox exchange for the small collectives (round 5; SURVEY section 7 hard part 1): every rank owns a mailbox in device
+ * memory shared through hipIpcMemHandle; ucd_comm_all_gather / ucd_comm_all_reduce_sum of at most `slot_floats` floats then run as
+ * ONE kernel of one workgroup on the caller's stream - peer stores, system-scope fence, sequence flags, bounded spin, sum in rank
+ * order (bit-identical on every rank) - instead of an RCCL call; larger messages keep RCCL.  Set-up (every rank, collective):
+ *   ucd_comm_init (RCCL underneath) or ucd_comm_init_local (no RCCL: mailbox only - several ranks on ONE GPU, which RCCL refuses)
+ *   ucd_comm_ipc_create(comm, slot_floats, timeout_ms, handle)  -> exchange the ucd_comm_ipc_handle_bytes() bytes of every rank
+ *   ucd_comm_ipc_connect(comm, handles)      handles = [nranks][handle bytes] in rank order
+ * A peer that never writes makes the kernel give up after timeout_ms (<= 0: 2 s) and latch a word in pinned host memory
+ * (ucd_comm_ipc_timeouts); every later collective on the communicator returns UCD_ETIMEOUT.  ucd_comm_ipc_drop removes the mailbox
+ * (the collectives go back to RCCL). */
+int ucd_comm_init_local(int nranks, int rank, ucd_comm_t* comm_out);
+size_t ucd_comm_ipc_handle_bytes(void);
+int ucd_comm_ipc_create(ucd_comm_t comm, int slot_floats, int timeout_ms, void* handle_out);
+int ucd_comm_ipc_connect(ucd_comm_t comm, const void* handles);
+int ucd_comm_ipc_drop(ucd_comm_t comm);
+unsigned ucd_comm_ipc_timeouts(ucd_comm_t comm);
 
 /* Whole SyncBN layer in one call each way, collectives included (comm from ucd_comm_init, world = its size):
  *   forward   ucd_abn_sync_stats -> all-gather -> ucd_abn_sync_forward; buf = [6*C | pack 2*C | gathered world*2*C]

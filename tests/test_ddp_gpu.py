@@ -223,15 +223,22 @@ def test_library_owned_rccl_communicator_world1(tmp_path):
     assert "DIRECT_RCCL_OK" in r.stdout
 
 
-def test_bench_multi_rank_path_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("mailbox", ["auto", "1", "watchdog"])
+def test_bench_multi_rank_path_two_ranks_one_gpu(tmp_path, mailbox):
     """bench.py's N > 1 branch (rank-sharded batch, DDP + SyncBN, barrier-bracketed timing, MAX over ranks, one JSON line
-    from rank 0) with two ranks on one GPU over gloo, at a small crop."""
+    from rank 0) with two ranks on one GPU over gloo, at a small crop.  The third phase (the SyncBN exchanges on the IPC mailbox,
+    after the phases without it have produced the line's numbers): "auto" declines because the ranks share a GPU; "1" attaches the
+    mailbox, times the iterations on it without a timed-out exchange and leaves the ranks in lockstep; "watchdog" gives the phase no
+    time at all - every rank leaves with exit code 0 and rank 0 still prints the line of the earlier phases."""
     import json
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", UCD_IPC_SYNC="auto" if mailbox == "auto" else "1")
+    if mailbox == "watchdog":
+        env["UCD_BENCH_MAILBOX_LIMIT_S"] = "0.001"
+    port = {"auto": "29725", "1": "29723", "watchdog": "29721"}[mailbox]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29725", os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "3", "--warmup", "3", "--global_batch", "4", "--crop", "129",
-                        "--backend", "gloo", "--device", "0", "--no_miopen_find", "--no_cpu_baseline"],
+                        "--backend", "gloo", "--device", "0", "--no_miopen_find", "--no_cpu_baseline", "--check_lockstep"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -239,6 +246,15 @@ def test_bench_multi_rank_path_two_ranks_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["config"]["parallelism"] == "dp2"
     assert all(np.isfinite(v) for v in d["losses"].values())
+    assert d["execution"]["eager_ms"] > 0
+    box = d["execution"]["mailbox"]
+    if mailbox == "auto":
+        assert box == {"attached": False} and d["lockstep"] is True
+    elif mailbox == "1":
+        assert box["attached"] is True and box["timeouts"] == 0 and box["ms_per_step"] > 0, box
+        assert d["lockstep"] is True
+    else:
+        assert "watchdog" in box["error"], box
 
 
 def test_bench_four_ranks_one_gpu_stay_in_lockstep(tmp_path):
@@ -360,3 +376,150 @@ def test_aborted_backward_leaves_no_widening_copies_behind():
     switches.unset("UCD_STAT_ATOMIC")
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+_IPC_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ["UCD_IPC_SYNC"] = "1"        # the ranks share the GPU: "auto" would decline
+from ucd_amd import hip
+from ucd_amd.comm import direct_comm
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+comm = direct_comm(None)
+assert comm is not None and comm.ipc, "the mailbox communicator was not created"
+lib = hip.load()
+g = torch.Generator(dev).manual_seed(100 + rank)
+def exchange(n, seed):
+    mine = torch.randn(n, device=dev, generator=g)
+    red = mine.clone()
+    hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(red), n, hip.stream()), "all_reduce")
+    gat = torch.empty(world * n, device=dev)
+    hip._check(lib.ucd_comm_all_gather(comm.handle, hip.ptr(mine), hip.ptr(gat), n, hip.stream()), "all_gather")
+    return mine, red, gat
+for it in range(200):
+    n = (8, 512, 4096, 32768)[it % 4]
+    mine, red, gat = exchange(n, it)
+    ref = [torch.empty(n, device=dev) for _ in range(world)]
+    dist.all_gather(ref, mine)
+    assert torch.equal(gat, torch.cat(ref)), ("gather", it)
+    acc = torch.zeros(n, device=dev)
+    for r in ref:                       # rank order: the kernel's order, so the sums are bit-identical
+        acc += r
+    assert torch.equal(red, acc), ("reduce", it)
+# back to back, no host synchronisation between exchanges (the way a training step issues them): every rank can regenerate every
+# rank's vectors from (rank, exchange index), so the results are checked afterwards without any further communication; other
+# kernels of varying length run between the exchanges so that the ranks drift against each other
+def vec(r, j, n):
+    return torch.randn(n, device=dev, generator=torch.Generator(dev).manual_seed(7919 * j + r))
+sizes = (128, 4096, 260, 8192, 16384, 13, 32768, 1024)
+for burst in range(6):
+    outs = []
+    filler = torch.randn(1 << (14 + (burst + rank) % 5), device=dev)
+    for j in range(64):
+        n = sizes[j % len(sizes)]
+        idx = burst * 64 + j
+        buf = vec(rank, idx, n)
+        if j % 3 == 2:
+            gat = torch.empty(world * n, device=dev)
+            hip._check(lib.ucd_comm_all_gather(comm.handle, hip.ptr(buf), hip.ptr(gat), n, hip.stream()), "all_gather")
+            outs.append((idx, n, True, gat))
+        else:
+            hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(buf), n, hip.stream()), "all_reduce")
+            outs.append((idx, n, False, buf))
+        if (j + rank) % 4 == 0:
+            filler = filler * 1.0001 + 0.5
+    torch.cuda.synchronize()
+    for idx, n, is_gather, got in outs:
+        ref = [vec(r, idx, n) for r in range(world)]
+        if is_gather:
+            assert torch.equal(got, torch.cat(ref)), ("burst gather", idx, n)
+        else:
+            acc = torch.zeros(n, device=dev)
+            for r in ref:
+                acc += r
+            assert torch.equal(got, acc), ("burst reduce", idx, n)
+# inside a captured graph: the sequence counter lives on the device, so a replay is another pair of exchanges
+buf = torch.full((2048,), float(rank + 1), device=dev)
+work = buf.clone()
+torch.cuda.synchronize(); dist.barrier()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+    work.copy_(buf)
+    hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(work), 2048, hip.stream()), "all_reduce")
+    hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(work), 2048, hip.stream()), "all_reduce")
+for _ in range(5):
+    graph.replay()
+torch.cuda.synchronize()
+tot = world * (world + 1) // 2
+assert torch.equal(work, torch.full((2048,), float(tot * world), device=dev)), work[:4]
+assert lib.ucd_comm_ipc_timeouts(comm.handle) == 0
+dist.barrier()
+print("IPC_OK", rank, flush=True)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_ipc_mailbox_exchange_several_ranks_on_one_gpu(tmp_path, world):
+    """the one-shot mailbox exchange (csrc/comm.hip: hipIpcMemHandle-shared mailboxes, peer stores, system-scope
+    fence, sequence flags, bounded spin, sum in rank order) between real processes - which RCCL refuses on one device.  200 rounds of
+    all-reduce + all-gather over four message sizes against torch.distributed's results (bit-identical: the sum runs in rank order on
+    every rank), then two exchanges inside a captured graph replayed five times."""
+    script = tmp_path / "ipc_worker.py"
+    script.write_text(_IPC_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29741 + world), str(script), ROOT], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("IPC_OK") == world, r.stdout[-2000:]
+
+
+_IPC_TIMEOUT_WORKER = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+os.environ["UCD_IPC_TIMEOUT_MS"] = "300"
+os.environ["UCD_IPC_SYNC"] = "1"
+from ucd_amd import hip
+from ucd_amd.comm import direct_comm
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev)
+comm = direct_comm(None)
+assert comm is not None and comm.ipc
+lib = hip.load()
+v = torch.ones(16, device=dev)
+hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(v), 16, hip.stream()), "both ranks: a served exchange")
+torch.cuda.synchronize()
+assert torch.equal(v, torch.full((16,), 2.0, device=dev)) and lib.ucd_comm_ipc_timeouts(comm.handle) == 0
+dist.barrier()
+if rank == 0:
+    t0 = time.time()
+    hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(v), 16, hip.stream()), "rank 0 alone: the launch itself succeeds")
+    torch.cuda.synchronize()                                   # returns once the kernel gave up
+    dt = time.time() - t0
+    assert 0.2 < dt < 10.0, dt
+    assert lib.ucd_comm_ipc_timeouts(comm.handle) != 0
+    try:
+        hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(v), 16, hip.stream()), "next exchange")
+        raise SystemExit("the latched timeout was not reported")
+    except RuntimeError as e:
+        assert "timed out" in str(e), e
+    print("IPC_TIMEOUT_OK %.2f" % dt, flush=True)
+dist.barrier()                                                 # rank 1 never entered the second exchange
+dist.destroy_process_group()
+"""
+
+
+def test_ipc_mailbox_timeout_is_an_error_not_a_hang(tmp_path):
+    """A peer that never arrives: rank 0 of two real processes enters an exchange rank 1 skips.  The exchange kernel gives up after
+    UCD_IPC_TIMEOUT_MS (300 ms here), latches the word in pinned host memory, and the NEXT collective on that communicator returns
+    UCD_ETIMEOUT (a RuntimeError through the bindings) - the process does not hang and the step is not silently wrong."""
+    script = tmp_path / "ipc_timeout_worker.py"
+    script.write_text(_IPC_TIMEOUT_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29747", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "IPC_TIMEOUT_OK" in r.stdout, r.stdout[-2000:]

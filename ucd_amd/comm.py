@@ -26,6 +26,9 @@ _comms = {}
 class DirectComm:
     def __init__(self, handle, world, rank):
         self.handle, self.world, self.rank = handle, world, rank
+        self.ipc = False          # the small collectives run on the one-shot IPC mailbox exchange
+        self.ipc_tried = False    # the mailbox set-up ran once (whatever its outcome)
+        self.has_rccl = False     # an RCCL communicator sits behind the handle (False: mailbox only)
 
 
 def _loaded_rccl_path():
@@ -103,15 +106,170 @@ def _create(group):
     return comm
 
 
-def direct_comm(group=None):
-    """``DirectComm`` for ``group`` (default group when None), or None when the direct path is unavailable."""
+IPC_SLOT_FLOATS = 32768      # per rank and exchange: the largest replicated statistics accumulator of a SyncBN layer (R x 2 C floats)
+
+
+def _self_test(comm, group, dev):
+    """The mailbox against the process group itself before anything depends on it: all-gather + all-reduce of seeded random vectors at
+    the SyncBN message sizes (one chunk ... the whole slot, an odd length for the 4-byte path), several rounds each (both mailbox
+    parities, back-to-back exchanges in flight), results required BIT-identical to torch.distributed's all_gather of the same vectors
+    summed in rank order.  A node whose peer mappings misbehave (stale reads, lost stores) fails here, on every rank, and keeps RCCL."""
+    lib = hip.load()
+    world, rank = comm.world, comm.rank
+    gen = torch.Generator(dev).manual_seed(977 + rank)
+    for n in (8, 13, 512, 4096, 16384, IPC_SLOT_FLOATS):
+        sent, got = [], []
+        for rnd in range(4):
+            mine = torch.randn(n, device=dev, generator=gen)
+            red = mine.clone()
+            gat = torch.empty(world * n, device=dev)
+            hip._check(lib.ucd_comm_all_gather(comm.handle, hip.ptr(mine), hip.ptr(gat), n, hip.stream()), "ucd_comm_all_gather")
+            hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(red), n, hip.stream()), "ucd_comm_all_reduce_sum")
+            sent.append(mine); got.append((gat, red))
+        for mine, (gat, red) in zip(sent, got):
+            ref = [torch.empty(n, device=dev) for _ in range(world)]
+            dist.all_gather(ref, mine, group=group)
+            acc = torch.zeros(n, device=dev)
+            for r in ref:
+                acc += r
+            if not (torch.equal(gat, torch.cat(ref)) and torch.equal(red, acc)):
+                return False, "self-test mismatch at %d floats" % n
+    if lib.ucd_comm_ipc_timeouts(comm.handle):
+        return False, "self-test timed out"
+    return True, ""
+
+
+def _attach_ipc(comm, group, dev):
+    """Give ``comm`` a mailbox for the small collectives (csrc/comm.hip: one-shot IPC exchange; ``UCD_IPC_SYNC=0`` keeps RCCL).
+    Phased like _create: every phase ends in an agreement collective, a failure anywhere drops the mailbox on EVERY rank.
+    Returns True when the mailbox is in use."""
+    lib = hip.load()
+    world = comm.world
+    nb = lib.ucd_comm_ipc_handle_bytes()
+    mine = (C.c_ubyte * nb)()
+    ok, why = True, ""
+    try:
+        hip._check(lib.ucd_comm_ipc_create(comm.handle, IPC_SLOT_FLOATS, int(_switches.get("UCD_IPC_TIMEOUT_MS", "60000")),
+                                           C.addressof(mine)), "ucd_comm_ipc_create")
+    except Exception as e:
+        ok, why = False, repr(e)
+    if not _agree(ok, group, dev):
+        lib.ucd_comm_ipc_drop(comm.handle)
+        warnings.warn("IPC mailbox unavailable, the small collectives stay on RCCL: " + (why or "another rank could not create its mailbox"))
+        return False
+    gathered = [None] * world
+    dist.all_gather_object(gathered, bytes(mine), group=group)
+    table = (C.c_ubyte * (nb * world))(*b"".join(gathered))
+    try:
+        hip._check(lib.ucd_comm_ipc_connect(comm.handle, C.addressof(table)), "ucd_comm_ipc_connect")
+    except Exception as e:
+        ok, why = False, repr(e)
+    if not _agree(ok, group, dev):
+        lib.ucd_comm_ipc_drop(comm.handle)
+        warnings.warn("IPC mailbox unavailable, the small collectives stay on RCCL: " + (why or "another rank could not open a peer's mailbox"))
+        return False
+    try:
+        ok, why = _self_test(comm, group, dev)
+    except Exception as e:
+        ok, why = False, repr(e)
+    if not _agree(ok, group, dev):
+        torch.cuda.synchronize()
+        lib.ucd_comm_ipc_drop(comm.handle)
+        warnings.warn("IPC mailbox disabled: " + (why or "another rank failed its self-test"))
+        return False
+    return True
+
+
+def _create_local(group):
+    """A communicator WITHOUT RCCL (several ranks on one GPU - RCCL refuses that -, or a non-nccl process group): the mailbox
+    exchange alone.  None when the mailbox cannot be set up (same answer on every rank)."""
+    lib = hip.load()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    handle = C.c_void_p()
+    hip._check(lib.ucd_comm_init_local(world, rank, C.byref(handle)), "ucd_comm_init_local")
+    comm = DirectComm(handle.value, world, rank)
+    comm.ipc_tried = True
+    comm.ipc = _attach_ipc(comm, group, dev)
+    if not comm.ipc:
+        lib.ucd_comm_destroy(comm.handle)
+        return None
+    return comm
+
+
+def _ranks_own_their_devices(group):
+    """True when no two ranks of the group drive the same GPU (collective).  The mailbox exchange spins on the device: ranks that
+    SHARE a GPU are time-sliced by the hardware scheduler and every exchange then costs a scheduling quantum (measured: 10 ms at four
+    processes on one MI355X, profiles/r05_ipc_exchange.md) - correct, and useless."""
+    dev = torch.cuda.current_device()
+    props = torch.cuda.get_device_properties(dev)
+    mine = (os.uname().nodename, str(getattr(props, "uuid", "")) or str(dev), getattr(props, "pci_bus_id", dev))
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, mine, group=group)
+    return len(set(everyone)) == len(everyone)
+
+
+def _want_mailbox(group):
+    """UCD_IPC_SYNC: "auto" (default) - when every rank owns its GPU; "1" - always (ranks sharing a GPU: the tests); "0" - never."""
+    sw = _switches.get("UCD_IPC_SYNC", "auto")
+    if sw == "0" or dist.get_world_size(group) < 2:
+        return False
+    return True if sw == "1" else _ranks_own_their_devices(group)
+
+
+def attach_mailbox(group=None):
+    """Give the group's EXISTING communicator its mailbox now (collective; bench.py does this after the RCCL-only phases have been
+    measured).  True when the small collectives run on the mailbox from here on - graphs captured before still replay RCCL."""
+    key = id(group) if group is not None else None
+    comm = _comms.get(key)
+    if comm is None:
+        # no communicator yet (or a non-nccl group, which has no RCCL one): a mailbox-only communicator
+        if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()) or dist.get_backend(group) == "nccl":
+            return False
+        if not _want_mailbox(group):
+            return False
+        comm = _comms[key] = _create_local(group)
+        return comm is not None
+    if comm.world < 2:
+        return False
+    if not comm.ipc:
+        comm.ipc_tried = True
+        comm.ipc = _want_mailbox(group) and _attach_ipc(comm, group, torch.device("cuda", torch.cuda.current_device()))
+    return comm.ipc
+
+
+def mailbox_timeouts(group=None):
+    """Exchanges of the group's communicator that gave up waiting for a peer (0: none; their results are not to be trusted)."""
+    comm = _comms.get(id(group) if group is not None else None)
+    return int(hip.load().ucd_comm_ipc_timeouts(comm.handle)) if comm is not None and comm.ipc else 0
+
+
+def direct_comm(group=None, ipc=True):
+    """``DirectComm`` for ``group`` (default group when None), or None when the direct path is unavailable.  ``ipc``: also give it
+    the one-shot mailbox for small messages (the SyncBN exchanges; the gradient buckets' communicator does not need one)."""
     key = id(group) if group is not None else None
     if key in _comms:
-        return _comms[key]
+        comm = _comms[key]
+        # created by a caller that did not want the mailbox (the gradient buckets), asked for now (SyncBN): attach it once -
+        # collective over the group like the creation itself, every rank reaches it at the same first SyncBN layer
+        if comm is not None and ipc and not comm.ipc and not comm.ipc_tried and comm.world > 1:
+            comm.ipc_tried = True
+            comm.ipc = _want_mailbox(group) and _attach_ipc(comm, group, torch.device("cuda", torch.cuda.current_device()))
+        return comm
+    live = dist.is_available() and dist.is_initialized() and torch.cuda.is_available() and _switches.get("UCD_DIRECT_RCCL", "1") != "0"
+    if not live:
+        return None
     comm = None
-    usable = (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()
-              and dist.get_backend(group) == "nccl" and _switches.get("UCD_DIRECT_RCCL", "1") != "0")
-    if usable:
+    if dist.get_backend(group) == "nccl":
         comm = _create(group)
+        if comm is not None:
+            comm.has_rccl = True
+            if ipc and comm.world > 1:
+                comm.ipc_tried = True
+                comm.ipc = _want_mailbox(group) and _attach_ipc(comm, group, torch.device("cuda", torch.cuda.current_device()))
+    elif not ipc:
+        return None                                   # a mailbox-only communicator is of no use to this caller; leave the slot open
+    elif _want_mailbox(group):
+        comm = _create_local(group)
     _comms[key] = comm
     return comm

@@ -83,6 +83,12 @@ SIGNATURES = {
     "ucd_comm_destroy": (_i, [_p]),
     "ucd_comm_all_gather": (_i, [_p, _p, _p, _z, _p]),
     "ucd_comm_all_reduce_sum": (_i, [_p, _p, _z, _p]),
+    "ucd_comm_init_local": (_i, [_i, _i, C.POINTER(C.c_void_p)]),
+    "ucd_comm_ipc_handle_bytes": (_z, []),
+    "ucd_comm_ipc_create": (_i, [_p, _i, _i, _p]),
+    "ucd_comm_ipc_connect": (_i, [_p, _p]),
+    "ucd_comm_ipc_drop": (_i, [_p]),
+    "ucd_comm_ipc_timeouts": (C.c_uint, [_p]),
     "ucd_abn_sync_forward_comm": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _f, _f, _p, _i, _f,
                                        _p, _z, _p]),
     "ucd_abn_sync_backward_comm": (_i, [_p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _p,
