@@ -324,6 +324,263 @@ __global__ __launch_bounds__(kThreads) void seg_losses_kernel(
   }
 }
 
+// ---- round 5: the few-class form on packed fp32 math, old and new classes in separate register groups ------------------------------
+// The register form above spends ~1400 vector instructions per pixel (ISA count): nine scalar multiplies / adds and a select per
+// interpolated logit, a 0 / 1 multiplier or a select per class for every class set, 227 VGPRs with the class-set masks spilled to
+// VGPR lanes (v_readlane in the inner loop) - 630 us, 0.01 of any roof.  Here the classes are laid out by SET at staging time: LDS
+// slots [0, KT) hold the old classes 0 .. K-1, slots [KT, KT + NT) the new classes K .. Ctot-1, unused slots hold -1e30 (their
+// exponentials are exact zeros).  Which set a slot belongs to is then a compile-time fact: sum_old / sum_new are two unmasked sums
+// (sum_all = old + new, sum_bkg+new = new + e_0), the gradient coefficient of a slot is one of three per-pixel scalars, the label can
+// only hit one of the NT new slots.  All per-class arithmetic runs on class PAIRS (v_pk_mul / v_pk_fma / v_pk_add_f32), logits
+// come from LDS four slots at a time (ds_read_b128).  ~330 vector instructions per pixel.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRepPk = 8;          // copies of the LDS gradient accumulators (lane & 7): 45 KB of LDS at the worst-case 7 x 7 cells
+
+__device__ __forceinline__ f32x2 bc2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x4 bc4(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x4 fma4(f32x4 a, f32x4 b, f32x4 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 exp2_2(f32x2 a) { return f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+
+template <int KT, int NT>
+__global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
+    const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
+    int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
+    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int CT = KT + NT, NP = CT / 2, KP = KT / 2, kRep = kRepPk;
+  // logit rows in LDS are CT + 1 / KT + 1 floats apart: the lanes of a wave read from ~5 cells, sixteen lanes the same address - a
+  // ds_read_b32 broadcasts that, a ds_read_b128 serialises it (59 cycles per instruction measured; SQ_LDS_BANK_CONFLICT), and the
+  // odd stride keeps the compiler from merging the dword reads
+  constexpr int CTS = CT + 1, KTS = KT + 1;
+  static_assert(KT % 4 == 0 && NT % 4 == 0, "slot groups are read four at a time");
+  constexpr float kL2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f, kNegBig = -1e30f;
+  const int b = blockIdx.z, ty0 = blockIdx.y * kTileY, tx0 = blockIdx.x * kTileX;
+  int ya, yb, xa, xb, dummy;
+  float f0, f1;
+  up_src(ty0, h, scale_h, ya, dummy, f0, f1);
+  up_src(min(ty0 + kTileY, H) - 1, h, scale_h, dummy, yb, f0, f1);
+  up_src(tx0, w, scale_w, xa, dummy, f0, f1);
+  up_src(min(tx0 + kTileX, W) - 1, w, scale_w, dummy, xb, f0, f1);
+  const int ny = yb - ya + 1, nx = xb - xa + 1, ncell = ny * nx;
+  // copies 1 (mod 32) doubles apart: a lane's accumulator word sits at copy (lane & 7) * gstride + cell * CT + slot, and 24 * cell +
+  // copy (mod 32) then takes 32 different values over the lanes of a wave - every LDS bank pair is hit by two lanes.  (Copies a
+  // multiple of 32 doubles apart put all eight on the same banks: LDS busy 57 % of the kernel, SQ_LDS_BANK_CONFLICT.)
+  const int gstride = ((ncell * CT + 31) & ~31) + 1;
+  // gradient accumulators in DOUBLE: ds_add_f64 runs at 7.7 cycles per wave instruction, ds_add_f32 at 169 (tools/lds_atomic_probe.hip,
+  // profiles/r05_lds_atomics.txt) - the fp32 LDS atomics of the flush were 80 % of the round-3 kernel's 630 us
+  double* g_acc = reinterpret_cast<double*>(smem);                     // [kRep][ncell][CT] gradient accumulators by slot
+  float* s_log = reinterpret_cast<float*>(g_acc + kRep * gstride + 1);  // [ncell][CTS] student logits by slot
+  float* t_log = s_log + ncell * CTS;         // [ncell][KTS] teacher logits
+  float* red = t_log + ncell * KTS;           // [2][4] block loss partials
+  unsigned char* lab_s = reinterpret_cast<unsigned char*>(red + 8);      // [kRows][kThreads] label codes (0xFF: ignored)
+  // all of a thread's labels up front: sixteen independent loads in flight under the staging below.  Loaded inside the row loop
+  // the label is a ~2 us HBM round trip at the head of every iteration with two waves per SIMD to hide it - the round-3 form's
+  // 630 us were this latency, not its instruction count (packed arithmetic alone: 624 us)
+  {
+    const int Xl = tx0 + (threadIdx.x & 63), Yl = ty0 + (threadIdx.x >> 6) * kRows;
+    int64_t lv[kRows];
+#pragma unroll
+    for (int it = 0; it < kRows; ++it) lv[it] = (Xl < W && Yl + it < H) ? labels[((size_t)b * H + Yl + it) * W + Xl] : 0;
+#pragma unroll
+    for (int it = 0; it < kRows; ++it) lab_s[it * kThreads + threadIdx.x] = lv[it] == ignore_index ? 0xFF : (unsigned char)lv[it];
+  }
+  for (int i = threadIdx.x; i < ncell * CT; i += kThreads) {
+    const int cell = i / CT, sl = i - cell * CT;
+    const int cy = ya + cell / nx, cx = xa + cell % nx;
+    const int c = sl < KT ? sl : K + sl - KT;
+    const bool valid = sl < KT ? sl < K : c < Ctot;
+    s_log[cell * CTS + sl] = valid ? sem_s[((size_t)(b * h + cy) * w + cx) * ld_s + c] : kNegBig;
+  }
+  for (int i = threadIdx.x; i < kRep * gstride; i += kThreads) g_acc[i] = 0.0;
+  if (sem_t)
+    for (int i = threadIdx.x; i < ncell * KT; i += kThreads) {
+      const int cell = i / KT, c = i - cell * KT;
+      const int cy = ya + cell / nx, cx = xa + cell % nx;
+      t_log[cell * KTS + c] = c < K ? sem_t[((size_t)(b * h + cy) * w + cx) * ld_t + c] : kNegBig;
+    }
+  __syncthreads();
+
+  float ce_sum = 0.f, kd_sum = 0.f;
+  const int X = tx0 + (threadIdx.x & 63);
+  const float invK = 1.f / (float)K;
+  const float kdw = sem_t ? kd_scale * invK : 0.f;
+  f32x2 acc0[NP], acc1[NP];            // sum over rows of ly0 * g / ly1 * g for the current low-resolution row pair, by slot pair
+  int cur_y0 = -1, cur_y1 = -1, x0 = 0, x1 = 0;
+  float lx0 = 0.f, lx1 = 0.f;
+  if (X < W) up_src(X, w, scale_w, x0, x1, lx0, lx1);
+  const int cx0 = x0 - xa, cx1 = x1 - xa;
+  auto flush = [&]() {
+    if (cur_y0 < 0) return;
+    double* ga = g_acc + (threadIdx.x & (kRep - 1)) * gstride;
+    double* g00 = ga + ((cur_y0 - ya) * nx + cx0) * CT;
+    double* g01 = ga + ((cur_y0 - ya) * nx + cx1) * CT;
+    double* g10 = ga + ((cur_y1 - ya) * nx + cx0) * CT;
+    double* g11 = ga + ((cur_y1 - ya) * nx + cx1) * CT;
+    const f32x2 L0 = bc2(lx0), L1 = bc2(lx1);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const f32x2 a0 = L0 * acc0[p], a1 = L1 * acc0[p], b0 = L0 * acc1[p], b1 = L1 * acc1[p];
+      atomicAdd(g00 + 2 * p, (double)a0.x); atomicAdd(g00 + 2 * p + 1, (double)a0.y);
+      atomicAdd(g01 + 2 * p, (double)a1.x); atomicAdd(g01 + 2 * p + 1, (double)a1.y);
+      atomicAdd(g10 + 2 * p, (double)b0.x); atomicAdd(g10 + 2 * p + 1, (double)b0.y);
+      atomicAdd(g11 + 2 * p, (double)b1.x); atomicAdd(g11 + 2 * p + 1, (double)b1.y);
+    }
+  };
+  // The x half of the bilinear form is the same for every pixel row that shares a low-resolution row pair: u_y = w0 v(y, x0) +
+  // w1 v(y, x1) of the two source rows is formed ONCE per row pair (48 + 32 registers) and a pixel costs z = h0 u_y0 + h1 u_y1 -
+  // no LDS read.  (Reading the four corners per pixel - 40 ds_read_b128 of mostly identical addresses, which the LDS serialises
+  // lane by lane - kept the LDS pipe busy 80 % of the kernel: SQ_LDS_IDX_ACTIVE, 59 cycles per read; 548 us.)
+  f32x2 u0[NP], u1[NP], tu0[KP], tu1[KP];
+  for (int it = 0; it < kRows; ++it) {
+    const int Y = ty0 + (threadIdx.x >> 6) * kRows + it;
+    if (X >= W || Y >= H) continue;
+    int y0, y1;
+    float ly0, ly1;
+    up_src(Y, h, scale_h, y0, y1, ly0, ly1);
+    if (y0 != cur_y0 || y1 != cur_y1) {
+      flush();
+      cur_y0 = y0; cur_y1 = y1;
+      const int r0 = (y0 - ya) * nx, r1 = (y1 - ya) * nx;
+      const int c00 = r0 + cx0, c01 = r0 + cx1, c10 = r1 + cx0, c11 = r1 + cx1;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) { acc0[p] = bc2(0.f); acc1[p] = bc2(0.f); }
+      const f32x2 L0 = bc2(lx0), L1 = bc2(lx1);
+      const float *s00 = s_log + c00 * CTS, *s01 = s_log + c01 * CTS, *s10 = s_log + c10 * CTS, *s11 = s_log + c11 * CTS;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        u0[p] = fma2(L1, f32x2{s01[2 * p], s01[2 * p + 1]}, L0 * f32x2{s00[2 * p], s00[2 * p + 1]});
+        u1[p] = fma2(L1, f32x2{s11[2 * p], s11[2 * p + 1]}, L0 * f32x2{s10[2 * p], s10[2 * p + 1]});
+      }
+      if (sem_t) {
+        const float *t00 = t_log + c00 * KTS, *t01 = t_log + c01 * KTS, *t10 = t_log + c10 * KTS, *t11 = t_log + c11 * KTS;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+          tu0[p] = fma2(L1, f32x2{t01[2 * p], t01[2 * p + 1]}, L0 * f32x2{t00[2 * p], t00[2 * p + 1]});
+          tu1[p] = fma2(L1, f32x2{t11[2 * p], t11[2 * p + 1]}, L0 * f32x2{t10[2 * p], t10[2 * p + 1]});
+        }
+      }
+    }
+    const f32x2 LY0p = bc2(ly0), LY1p = bc2(ly1);
+    const int code = lab_s[it * kThreads + threadIdx.x];
+    const bool ignored = code == 0xFF;
+    int lab = ignored ? 0 : code;
+    if (lab < K) lab = 0;                                    // loss.py:104-105
+    const bool lab0 = lab == 0;
+    const int jlab = lab - K;                                // the label's new-class slot (negative: background / old / ignored)
+
+    // z = h0 u_y0 + h1 u_y1 is two packed instructions per slot pair: formed for the maximum, formed again for the exponentials
+    // (and for the old classes' KD term) instead of living in 24 registers
+    auto zpair = [&](int p) { return fma2(LY1p, u1[p], LY0p * u0[p]); };
+    f32x2 e[NP];
+    float mz = kNegBig;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const f32x2 zz = zpair(p);
+      mz = fmaxf(mz, fmaxf(zz.x, zz.y));
+    }
+    const f32x2 L2E = bc2(kL2e), MZL = bc2(-mz * kL2e);
+    f32x2 so = bc2(0.f), sn = bc2(0.f);
+    float z_lab = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const f32x2 zz = zpair(p);
+      e[p] = exp2_2(fma2(zz, L2E, MZL));
+      if (p < KP) {
+        so += e[p];
+      } else {
+        sn += e[p];
+        z_lab = jlab == 2 * (p - KP) ? zz.x : z_lab;
+        z_lab = jlab == 2 * (p - KP) + 1 ? zz.y : z_lab;
+      }
+    }
+    const float s_old = so.x + so.y, s_new = sn.x + sn.y;
+    const float s_all = s_old + s_new, s_bn = s_new + e[0].x;
+    const float den = mz + kLn2 * __builtin_amdgcn_logf(s_all);
+    const float lse_old = mz + kLn2 * __builtin_amdgcn_logf(s_old), lse_bn = mz + kLn2 * __builtin_amdgcn_logf(s_bn);
+    const float logp = lab0 ? lse_old - den : z_lab - den;
+    if (!ignored) ce_sum += -logp;
+    const float inv_all = 1.f / s_all, inv_old = 1.f / s_old, inv_bn = 1.f / s_bn;
+    const float ce_w = ignored ? 0.f : ce_scale;
+    // teacher soft-max over the old classes; q_c = te_c / sum te
+    f32x2 te[KP];
+    float inv_st = 0.f, q0 = 0.f, kd_pix = 0.f;
+    if (sem_t) {
+      float mt = kNegBig;
+#pragma unroll
+      for (int p = 0; p < KP; ++p) {
+        te[p] = fma2(LY1p, tu1[p], LY0p * tu0[p]);
+        mt = fmaxf(mt, fmaxf(te[p].x, te[p].y));
+      }
+      const f32x2 MTL = bc2(-mt * kL2e);
+      f32x2 st2 = bc2(0.f);
+#pragma unroll
+      for (int p = 0; p < KP; ++p) {
+        te[p] = exp2_2(fma2(te[p], L2E, MTL));
+        st2 += te[p];
+      }
+      inv_st = 1.f / (st2.x + st2.y);
+      q0 = te[0].x * inv_st;
+      kd_pix = q0 * (lse_bn - den);
+      // old classes 1 .. K-1: q_c (z_c - den); unused slots carry q = 0 against a finite z
+      const f32x2 IST = bc2(inv_st), DEN = bc2(den);
+      f32x2 kd2 = f32x2{0.f, te[0].y * inv_st} * (zpair(0) - DEN);
+#pragma unroll
+      for (int p = 1; p < KP; ++p) kd2 = fma2(te[p] * IST, zpair(p) - DEN, kd2);
+      kd_pix += kd2.x + kd2.y;
+    } else {
+#pragma unroll
+      for (int p = 0; p < KP; ++p) te[p] = bc2(0.f);
+    }
+    // g_c = e_c [(ce_w + kdw) / sum_all - [c old] ce_w [label bkg/old] / sum_old - [c bkg/new] kdw q_0 / sum_bn]
+    //       - ce_w [label new][c == label] - kdw q_c [1 <= c < K]
+    const float A = (ce_w + kdw) * inv_all, Bo = lab0 ? ce_w * inv_old : 0.f, Bb = kdw * q0 * inv_bn;
+    const float coef_old = A - Bo, coef_new = A - Bb, nkq = -kdw * inv_st;
+    const f32x2 COLD = bc2(coef_old), CNEW = bc2(coef_new), NKQ = bc2(nkq);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      f32x2 g;
+      if (p == 0) {
+        g = e[0] * f32x2{coef_old - Bb, coef_old};
+        g = fma2(te[0], f32x2{0.f, nkq}, g);
+      } else if (p < KP) {
+        g = fma2(te[p], NKQ, e[p] * COLD);
+      } else {
+        const int j = 2 * (p - KP);
+        g = e[p] * CNEW - f32x2{jlab == j ? ce_w : 0.f, jlab == j + 1 ? ce_w : 0.f};
+      }
+      acc0[p] = fma2(LY0p, g, acc0[p]);
+      acc1[p] = fma2(LY1p, g, acc1[p]);
+    }
+    kd_sum += -kd_pix * invK;
+  }
+  flush();
+  __syncthreads();
+  for (int i = threadIdx.x; i < ncell * CT; i += kThreads) {
+    double vd = g_acc[i];
+#pragma unroll
+    for (int r = 1; r < kRep; ++r) vd += g_acc[r * gstride + i];
+    const float v = (float)vd;
+    const int cell = i / CT, sl = i - cell * CT;
+    const int c = sl < KT ? sl : K + sl - KT;
+    const bool valid = sl < KT ? sl < K : c < Ctot;
+    if (valid && v != 0.f) {
+      const int cy = ya + cell / nx, cx = xa + cell % nx;
+      atomicAdd(&d_sem[((size_t)(b * h + cy) * w + cx) * ld_d + c], v);
+    }
+  }
+  // block loss sums (fixed order)
+  ce_sum = wave_sum(ce_sum);
+  kd_sum = wave_sum(kd_sum);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = ce_sum; red[4 + (threadIdx.x >> 6)] = kd_sum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int blk = (blockIdx.z * tiles_y + blockIdx.y) * tiles_x + blockIdx.x;
+    loss_part[2 * blk + 0] = red[0] + red[1] + red[2] + red[3];
+    loss_part[2 * blk + 1] = red[4] + red[5] + red[6] + red[7];
+  }
+}
+
 // ---- the same losses for MANY classes (ADE20K: 151 student / 101 teacher classes; any Ctot the LDS holds) ----------------------
 // The generic form above (CT == 0) re-interpolates every logit in each of its passes and adds every pixel's gradient to LDS with
 // four float atomics per class - 604 contended LDS atomics and ~900 exponentials per pixel at 151 classes: 4.8 ms for ONE rank's
@@ -663,11 +920,49 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const int tile_y = wide ? 4 * kRW : kTileY;
   const int tiles_x = ceil_div(W, kTileX), tiles_y = ceil_div(H, tile_y);
   // worst-case LDS: (tile/scale + 3) cells per dimension
-  const int ny = (int)(tile_y * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
+  int ny = (int)(tile_y * (float)h / H) + 3, nx = (int)(kTileX * (float)w / W) + 3;
+  {
+    // the exact footprint instead of the bound: the kernels' own source-index arithmetic (up_src, same float operations) over
+    // every tile origin - 6 x 6 cells instead of 7 x 7 at 513 / 33, which is what lets two workgroups share a CU's LDS
+    auto lo = [](int dst, int in_size, float scale) {
+      float src = scale * ((float)dst + 0.5f) - 0.5f;
+      src = src < 0.f ? 0.f : src;
+      const int i0 = (int)src < in_size - 1 ? (int)src : in_size - 1;
+      return i0;
+    };
+    auto span = [&](int out, int in_size, float scale, int tile) {
+      int m = 1;
+      for (int t0 = 0; t0 < out; t0 += tile) {
+        const int a = lo(t0, in_size, scale);
+        const int last = (t0 + tile < out ? t0 + tile : out) - 1;
+        const int i0 = lo(last, in_size, scale);
+        const int bnd = i0 + (i0 < in_size - 1 ? 1 : 0);
+        if (bnd - a + 1 > m) m = bnd - a + 1;
+      }
+      return m;
+    };
+    const int ey = span(H, h, (float)h / (float)H, tile_y), ex = span(W, w, (float)w / (float)W, kTileX);
+    if (ey < ny) ny = ey;
+    if (ex < nx) nx = ex;
+  }
   const int CS = (Ctot + 3) & ~3, KS = sem_t ? ((K + 3) & ~3) : 0;
+  // few classes: the packed form with old / new classes in separate slot groups (UCD_SEG_PK=0: the round-3 register form, A/B)
+  static const int pk_on = getenv("UCD_SEG_PK") ? atoi(getenv("UCD_SEG_PK")) : 1;
+  int pk_kt = 0, pk_nt = 0;
+  if (pk_on && !wide) {
+    const int nnew = Ctot - K;
+    if (K <= 16 && nnew <= 8) { pk_kt = 16; pk_nt = 8; }
+    else if (K <= 20 && nnew <= 4) { pk_kt = 20; pk_nt = 4; }
+    else if (K <= 12 && nnew <= 12) { pk_kt = 12; pk_nt = 12; }
+  }
   const size_t lds = wide ? ((size_t)ny * nx * ((1 + kRepW) * CS + KS) + 8) * sizeof(float)
+                   : pk_kt ? (size_t)kRepPk * (((ny * nx * (pk_kt + pk_nt) + 31) & ~31) + 1) * 8 + 8
+                                 + ((size_t)ny * nx * ((pk_kt + pk_nt) + pk_kt + 2) + 8) * sizeof(float) + kRows * kThreads
                           : ((size_t)ny * nx * (17 * Ctot + K) + 8) * sizeof(float);
   UCD_REQUIRE(lds <= 150 * 1024, UCD_EUNSUPPORTED, "%s: %d classes exceed the LDS budget", fn, Ctot);
+  UCD_TRY_LDS((seg_losses_pk_kernel<16, 8>), 150 * 1024);
+  UCD_TRY_LDS((seg_losses_pk_kernel<20, 4>), 150 * 1024);
+  UCD_TRY_LDS((seg_losses_pk_kernel<12, 12>), 150 * 1024);
   UCD_TRY_LDS((seg_losses_kernel<24, 16>), 150 * 1024);
   UCD_TRY_LDS((seg_losses_kernel<24, 24>), 150 * 1024);
   UCD_TRY_LDS(seg_losses_wide_kernel, 150 * 1024);
@@ -676,7 +971,15 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const float inv_pix = 1.f / ((float)B * H * W);
   float* part = (float*)workspace;
   // torch computes the up-sampling scale as float(in) / out
-  if (Ctot <= 24 && K <= 16)
+#define UCD_SEG_PK_LAUNCH(KT_, NT_)                                                                                              \
+  seg_losses_pk_kernel<KT_, NT_><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(                                               \
+      sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,             \
+      ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y)
+  if (pk_kt == 16) UCD_SEG_PK_LAUNCH(16, 8);
+  else if (pk_kt == 20) UCD_SEG_PK_LAUNCH(20, 4);
+  else if (pk_kt == 12) UCD_SEG_PK_LAUNCH(12, 12);
+#undef UCD_SEG_PK_LAUNCH
+  else if (Ctot <= 24 && K <= 16)
     seg_losses_kernel<24, 16><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
         sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
         ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
