@@ -65,7 +65,8 @@ def test_cpp_gemm_node_equals_python_function():
 
 
 @pytest.mark.parametrize("ci,co,hw,d,B", [(256, 256, 33, 1, 8), (512, 512, 33, 2, 8), (2048, 256, 33, 12, 8), (64, 64, 65, 1, 8),
-                                           (2048, 256, 33, 12, 24), (256, 256, 33, 1, 24)])
+                                           (2048, 256, 33, 12, 24), (256, 256, 33, 1, 24), (2048, 256, 33, 6, 24),
+                                           (2048, 256, 33, 18, 24)])
 def test_conv3x3_input_gradient_on_the_forward_solver(ci, co, hw, d, B):
     """ucd_amd/blocks.py::Conv3x3 computes dx with the forward solver on the flipped / transposed weight: the same
     arithmetic as conv2d's own backward (reference: nn.Conv2d(k=3, padding=dilation), modules/residual.py:69,
@@ -89,6 +90,36 @@ def test_conv3x3_input_gradient_on_the_forward_solver(ci, co, hw, d, B):
     yr.backward(dy32.to(torch.bfloat16).float())
     rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
     assert rel(y, yr) < 1e-2 and rel(x.grad, xr.grad) < 1e-2 and rel(conv.weight.grad, wr.grad) < 1e-2
+
+
+@pytest.mark.parametrize("K,N,hw,d,B", [(64, 128, 33, 18, 3), (64, 128, 33, 12, 5), (128, 256, 33, 6, 4), (64, 64, 33, 16, 2),
+                                         (64, 128, 33, 32, 2), (128, 256, 17, 12, 9), (256, 256, 33, 18, 24)])
+def test_dilated_3x3_skips_only_kernel_rows_that_read_padding(K, N, hw, d, B):
+    """Round 5: a tile of the implicit-GEMM 3x3 kernels drops the K steps of a kernel ROW whose every tap reads padding for all of the
+    tile's rows (csrc/conv1x1.hip live_taps: dy = -d for tiles within d rows of the top edge, dy = +d near the bottom edge) - 12 / 24 /
+    33 % of the work of the ASPP branches (modules/deeplab.py:27-29, dilations 6 / 12 / 18 on 33 x 33).  Every output element against
+    F.conv2d on the bf16-rounded operands, at batch sizes whose 128- and 256-row tiles start at every phase of the image (tiles
+    inside one image, tiles across an image boundary, the last partial tile), dilations up to the map size."""
+    from ucd_amd import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator(dev).manual_seed(K + N + d + B)
+    cl = torch.channels_last
+    x = torch.randn(B, K, hw, hw, device=dev, generator=g).bfloat16().contiguous(memory_format=cl)
+    w = (torch.randn(N, K, 3, 3, device=dev, generator=g) * (2.0 / (9 * K)) ** 0.5).bfloat16().contiguous(memory_format=cl)
+    y = torch.empty(B, N, hw, hw, device=dev, dtype=torch.bfloat16).contiguous(memory_format=cl)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])
+    hip.conv1x1(rows(x), w.permute(0, 2, 3, 1).reshape(N, 9 * K), rows(y), conv3=(hw, hw, d))
+    ref = F.conv2d(x.float(), w.float(), None, 1, d, d)
+    err = (y.float() - ref).abs().max().item()
+    assert err < 0.03 * ref.abs().max().item(), (err, ref.abs().max().item())       # one bf16 rounding of the output
+    # and the input gradient (the same kernel on the flipped / transposed weight)
+    dy = torch.randn(B, N, hw, hw, device=dev, generator=g).bfloat16().contiguous(memory_format=cl)
+    wt = w.flip(2, 3).transpose(0, 1).contiguous(memory_format=cl)
+    dx = torch.empty_like(x)
+    hip.conv1x1(rows(dy), wt.permute(0, 2, 3, 1).reshape(K, 9 * N), rows(dx), conv3=(hw, hw, d))
+    refdx = torch.nn.grad.conv2d_input(x.shape, w.float(), dy.float(), 1, d, d)
+    err = (dx.float() - refdx).abs().max().item()
+    assert err < 0.03 * refdx.abs().max().item(), (err, refdx.abs().max().item())
 
 
 @pytest.mark.parametrize("ci,co,hw", [(256, 64, 65), (64, 256, 65), (512, 128, 33), (256, 40, 65), (72, 256, 33)])

@@ -123,6 +123,21 @@ template <int OUT> constexpr int kEpilogueBarriers = 4 + (OUT >= 2 ? 2 : 0);
 // 257 .. 640 workgroups (every 33 x 33 layer at B = 24); <64, 4> (128 KB, ONE workgroup per CU) is for grids that give a CU at most
 // one workgroup anyway (the 3 - 6 images per GPU of the multi-GPU split: 26 - 104 workgroups, where a K step is one exposed
 // memory round trip - 36 of them in a row for a 256-channel 3x3 layer).
+// CONV3, stride 1: the contiguous range of kernel ROWS of a 3 x 3 tap grid that can meet the map for a tile of consecutive output rows
+// [m0, m1) (raster order over the images).  Kernel row kh shifts every pixel by dy = (kh - 1) d; with d >= the tile's distance
+// from the map's top / bottom edge all of its rows read padding and the whole kernel row contributes nothing - at the ASPP
+// dilations (6, 12, 18 on a 33 x 33 map) that is 12 / 24 / 33 % of the K steps of a 128-row tile.  Returns the first live tap
+// (0 or 3) and the number of live taps (3, 6 or 9); uniform integer arithmetic on the tile bounds, no reduction.
+__device__ __forceinline__ void live_taps(int m0, int m1, int ohw, int oW, int iH, int dil, int& tap0, int& ntap) {
+  tap0 = 0; ntap = 9;
+  if (dil <= 1 || m1 - m0 >= ohw) return;                  // a tile that spans a whole image sees every row of the map
+  const int first = m0 % ohw, last = (m1 - 1) % ohw;
+  int ymin = first / oW, ymax = last / oW;
+  if (first > last) { ymin = 0; ymax = iH - 1; }           // the tile crosses an image boundary: bottom rows of one, top rows of the next
+  if (ymax < dil) { tap0 = 3; ntap -= 3; }                 // dy = -d: no row has a pixel d rows above it
+  if (ymin >= iH - dil) ntap -= 3;                         // dy = +d
+}
+
 template <int BN, bool PRO, int OUT, bool CONV3 = false, bool DB = false, int BK = 64, int NST = 2>
 __global__ __launch_bounds__(kThreads, DB ? (BK * NST >= 256 ? 1 : 2) : ((PRO || OUT >= 3) && BN == 128 ? 3 : 4)) void conv1x1_kernel(Args p) {
   static_assert(!DB || !PRO, "the double-buffered form has no input transform");
@@ -203,7 +218,9 @@ __global__ __launch_bounds__(kThreads, DB ? (BK * NST >= 256 ? 1 : 2) : ((PRO ||
   const int fr = lane & 31, fh = lane >> 5;
   static_assert(!PRO || BK == 64, "the register-staged input transform walks K in steps of 64");
   const int kpt = p.K / BK;                            // K steps per tap
-  const int nk = CONV3 ? 9 * kpt : kpt;
+  int tap0 = 0, ntap = 9;
+  if (CONV3 && p.stride == 1) live_taps(m0, min(m0 + kBM, p.M), p.ohw, p.oW, p.iH, p.dil, tap0, ntap);
+  const int nk = CONV3 ? ntap * kpt : kpt;             // K steps of the live taps; step kb belongs to tap tap0 + kb / kpt
   uint4 ra[4];
   if (PRO) {
 #pragma unroll
@@ -237,8 +254,8 @@ __global__ __launch_bounds__(kThreads, DB ? (BK * NST >= 256 ? 1 : 2) : ((PRO ||
     atap = tap;
   };
   auto fill3 = [&](int kb, unsigned char* Ad, unsigned char* Bd) {   // LDS-DMA fill of step kb (double-buffered form)
-    const int tap = CONV3 ? kb / kpt : 0;
-    const int k0 = (kb - tap * kpt) * BK;
+    const int kt = CONV3 ? kb / kpt : 0, tap = tap0 + kt;
+    const int k0 = (kb - kt * kpt) * BK;
     if (CONV3) {
       if (tap != atap) set_tap(tap);
 #pragma unroll
@@ -259,8 +276,8 @@ __global__ __launch_bounds__(kThreads, DB ? (BK * NST >= 256 ? 1 : 2) : ((PRO ||
       if (st < nk) fill3(st, As + st * kStage, Bs + st * kStage);
   }
   for (int kb = 0; kb < nk; ++kb) {
-    const int tap = CONV3 ? kb / kpt : 0;
-    const int k0 = (kb - tap * kpt) * BK;
+    const int kt = CONV3 ? kb / kpt : 0, tap = tap0 + kt;
+    const int k0 = (kb - kt * kpt) * BK;
     const int wk0 = CONV3 ? tap * p.K + k0 : k0;       // column offset inside a weight row (pitch 9 K)
     if (kb) {                                          // the previous step's fragment reads are done
       if (DB) {   // raw barrier: __syncthreads() would wait for the fill in flight as well
@@ -406,7 +423,9 @@ __global__ __launch_bounds__(BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 
   const int m0w = tmw * BM, n0 = tn * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kpt = p.K / BK;
-  const int nk = CONV3 ? 9 * kpt : kpt;
+  int tap0 = 0, ntap = 9;
+  if (CONV3 && p.stride == 1) live_taps(m0w, min(m0w + BM, p.M), p.ohw, p.oW, p.iH, p.dil, tap0, ntap);
+  const int nk = CONV3 ? ntap * kpt : kpt;             // K steps of the live taps (loader and MFMA waves count the same steps)
 
   if (wave >= NC) {
     // ================================ loader waves ================================
@@ -456,8 +475,8 @@ __global__ __launch_bounds__(BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 
     auto fill = [&](int kb, int st) {
       unsigned char* Ad = As + st * kStage;
       unsigned char* Bd = Bs + st * kStage;
-      const int tap = CONV3 ? kb / kpt : 0;
-      const int k0 = (kb - tap * kpt) * BK;
+      const int kt = CONV3 ? kb / kpt : 0, tap = tap0 + kt;
+      const int k0 = (kb - kt * kpt) * BK;
       if (CONV3) {
         if (tap != atap) set_tap(tap);
 #pragma unroll
