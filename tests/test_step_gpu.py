@@ -694,7 +694,10 @@ def test_step_graph_is_dropped_and_rebuilt_when_the_optimiser_state_moves():
     assert err is None, err
     # replays: steps 3, 4, 5 (captured at step 3), eager again from the reload at step 6 for the warm-up count, replays from step 9
     assert n_e == 0 and n_g == 3 + 3, (n_e, n_g)
-    np.testing.assert_allclose(graph, eager, rtol=2e-3)
+    # two runs of the SAME mode already differ from iteration 2 on (global fp32 atomics of the logit-loss gradient and the library's
+    # stem weight gradient: 2e-4 on a loss after one update) and twelve updates under a steep schedule amplify that: 3.2e-3 seen on the
+    # contrastive term in 1 of 3 full-suite runs - the claim here is "the rebuilt graph updates the NEW buffers", an error of order 1
+    np.testing.assert_allclose(graph, eager, rtol=6e-3)
     for n in pe:
         d = ((pe[n] - pg[n]).norm() / pe[n].norm()).item()
         # 12 steps: the library's weight-gradient kernel of the stem is not bit-reproducible between two runs (1.7e-4 on its weight

@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05e
+timeout 3000 python -m pytest tests -q -m gpu 2>&1 | tail -30 > gpurun_out/r05e/tests_gpu.txt
+tail -6 gpurun_out/r05e/tests_gpu.txt
