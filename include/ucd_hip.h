@@ -605,6 +605,9 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
  * per-layer flip + copy of the "input gradient on the forward solver" trick (ucd_amd/blocks.py::_StrideOneConvFn). */
 int ucd_flip_weights_batched(const void* src_flat, void* dst_flat, const int* blocks, int n_blocks, const long long* entries,
                              ucd_stream_t stream);
+/* The same with blocks = {entry, spatial tap, out-channel tile of 64, in-channel tile of 64}: 16-byte accesses on both sides. */
+int ucd_flip_weights_batched64(const void* src_flat, void* dst_flat, const int* blocks, int n_blocks, const long long* entries,
+                               ucd_stream_t stream);
 
 /* dst[cols, rows] = src[rows, cols]^T (bf16): the [K, N] weight of the input-gradient product. */
 int ucd_transpose_bf16(const void* src, int rows, int cols, void* dst, ucd_stream_t stream);

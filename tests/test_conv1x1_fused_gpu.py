@@ -198,6 +198,42 @@ def test_residual_block_training_fused_node_equals_module_path(cin, chans, with_
         assert _rel(gf[n], gp[n]) < 5e-2, n
 
 
+@pytest.mark.parametrize("tile", [32, 64])
+def test_batched_flip_kernels_on_ragged_shapes(tile):
+    """ucd_flip_weights_batched (32 x 32 tiles, 2-byte accesses) and ucd_flip_weights_batched64 (64 x 64 tiles, 16-byte accesses where
+    the addresses allow) on a table of layers whose channel counts are not multiples of the tile, of 8, and whose offsets into the
+    flat buffers are odd: dst_e == src_e.flip(2, 3).transpose(0, 1) in channels-last memory order, nothing outside the entries written."""
+    from ucd_amd import hip
+    lib = hip.load()
+    shapes = [(64, 64, 3), (256, 128, 3), (21, 256, 1), (40, 72, 3), (72, 40, 1), (130, 66, 3), (8, 8, 1), (1, 300, 1)]
+    g = torch.Generator(DEV).manual_seed(11)
+    entries, blocks, srcs, off_s, off_d = [], [], [], 3, 5                     # odd starts: no 16-byte alignment for free
+    for e, (co, ci, k) in enumerate(shapes):
+        n = co * ci * k * k
+        entries.append([off_s, off_d, co, ci, k * k])
+        for sp in range(k * k):
+            for a in range((co + tile - 1) // tile):
+                for b in range((ci + tile - 1) // tile):
+                    blocks.append([e, sp, a, b])
+        srcs.append((off_s, off_d, n))
+        off_s += n + (e % 3)                                                      # ragged gaps between the entries
+        off_d += n + ((e + 1) % 4)
+    src = torch.randint(-30000, 30000, (off_s + 8,), device=DEV, generator=g, dtype=torch.int16)
+    dst = torch.full((off_d + 8,), 12345, device=DEV, dtype=torch.int16)
+    ent = torch.tensor(entries, dtype=torch.int64, device=DEV)
+    blk = torch.tensor(blocks, dtype=torch.int32, device=DEV)
+    fn = lib.ucd_flip_weights_batched if tile == 32 else lib.ucd_flip_weights_batched64
+    hip._check(fn(src.data_ptr(), dst.data_ptr(), blk.data_ptr(), blk.shape[0], ent.data_ptr(), hip.stream()), "flip")
+    torch.cuda.synchronize()
+    covered = torch.zeros_like(dst, dtype=torch.bool)
+    for (so, do, n), (co, ci, k) in zip(srcs, shapes):
+        w = src[so:so + n].view(co, k, k, ci).permute(0, 3, 1, 2)                 # [co, ci, kh, kw] behind channels-last memory
+        ref = w.flip(2, 3).transpose(0, 1).permute(0, 2, 3, 1).reshape(-1)       # [ci][kh][kw][co] memory order
+        assert torch.equal(dst[do:do + n], ref), (co, ci, k)
+        covered[do:do + n] = True
+    assert (dst[~covered] == 12345).all()
+
+
 def test_cached_flipped_weights_equal_flip_transpose():
     """ucd_flip_weights_batched (one launch for every stride-1 layer, refreshed with the bf16 working copies) against
     w.flip(2, 3).transpose(0, 1) per layer, before and after an optimiser step; and the step with the cached copies gives the

@@ -124,6 +124,7 @@ SIGNATURES = {
     "ucd_conv_wgrad_strided": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
     "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
+    "ucd_flip_weights_batched64": (_i, [_p, _p, _p, _i, _p, _p]),
     "ucd_sgd_chunk": (_i, []),
     "ucd_sgd_step": (_i, [_p, _p, _i, _p, _p]),
     "ucd_sgd_hyper_store": (_i, [_p, _p, _p]),

@@ -113,8 +113,8 @@ class Bf16Weights:
             src_off = (m._w16.data_ptr() - base) // 2
             entries.append([src_off, off, co, ci, kh * kw])
             for sp in range(kh * kw):
-                for a in range((co + 31) // 32):
-                    for b in range((ci + 31) // 32):
+                for a in range((co + 63) // 64):
+                    for b in range((ci + 63) // 64):
                         blocks.append([e, sp, a, b])
             off += co * ci * kh * kw
         self.flat16_flip = torch.empty(off, dtype=torch.bfloat16, device=dev)
@@ -132,9 +132,9 @@ class Bf16Weights:
         if self.flat16_flip is None:
             return
         from . import hip
-        hip._check(hip.load().ucd_flip_weights_batched(self.flat16.data_ptr(), self.flat16_flip.data_ptr(),
-                                                       self._flip_blocks.data_ptr(), self._flip_blocks.shape[0],
-                                                       self._flip_entries.data_ptr(), hip.stream()), "ucd_flip_weights_batched")
+        hip._check(hip.load().ucd_flip_weights_batched64(self.flat16.data_ptr(), self.flat16_flip.data_ptr(),
+                                                         self._flip_blocks.data_ptr(), self._flip_blocks.shape[0],
+                                                         self._flip_entries.data_ptr(), hip.stream()), "ucd_flip_weights_batched64")
 
     def mark_stale(self):
         self._dirty = True
