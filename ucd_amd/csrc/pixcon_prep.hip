@@ -168,6 +168,78 @@ __global__ __launch_bounds__(1024) void prep_scan_kernel(int32_t* __restrict__ c
   }
 }
 
+// Stage 2, tables that fit in LDS (round 5): the kernel above walks a table in 1024-entry slices with three barriers per slice -
+// 26 slices x 2 tables = 67 us for 2 x 105 KB at the benchmark shape, on the dependent chain in front of the contrastive loss.
+// Here a table is copied into LDS with coalesced loads, every thread sums its own contiguous run, ONE block scan orders the runs,
+// the runs are rewritten in place and copied back: three barriers per table.
+__global__ __launch_bounds__(1024) void prep_scan_lds_kernel(int32_t* __restrict__ cnt_a, int32_t* __restrict__ cnt_o, int nblk,
+                                                             const int32_t* __restrict__ scalars,
+                                                             ucd_pixcon_meta* __restrict__ meta, int sort_by_label) {
+  extern __shared__ int32_t tab[];                     // [n + n / 32]: one pad word per 32 entries (the runs start 26 words apart)
+  __shared__ int warp_tot[16];
+  const int n = 256 * nblk;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int per = (n + 1023) / 1024;
+  const int i0 = min(n, tid * per), i1 = min(n, i0 + per);
+  auto at = [](int i) { return i + (i >> 5); };
+  for (int which = 0; which < 2; ++which) {
+    int32_t* cnt = which == 0 ? cnt_a : cnt_o;
+    int32_t* lstart = which == 0 ? meta->label_start_a : meta->label_start_o;
+    for (int i = tid; i < n; i += 1024) tab[at(i)] = cnt[i];
+    __syncthreads();
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += tab[at(i)];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) warp_tot[wv] = incl;
+    __syncthreads();
+    int run = incl - sum, total = 0;
+    for (int i = 0; i < 16; ++i) {
+      if (i < wv) run += warp_tot[i];
+      total += warp_tot[i];
+    }
+    for (int i = i0; i < i1; ++i) {
+      const int v = tab[at(i)];
+      tab[at(i)] = run;
+      run += v;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) cnt[i] = tab[at(i)];
+    if (tid < 256) lstart[tid] = tab[at(tid * nblk)];  // first block of a label: start of its segment
+    if (tid == 0) {
+      lstart[256] = total;
+      if (which == 0) meta->A = total; else meta->Co = total;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int A = meta->A, Co = meta->Co;
+    meta->min_new = scalars[1] ? scalars[0] : 0x7fffffff;
+    meta->n_new = scalars[1];
+    meta->Apad = (A + kPixTile - 1) / kPixTile * kPixTile;
+    meta->Cpad = (meta->Apad + Co + kPixTile - 1) / kPixTile * kPixTile;
+    meta->sorted = sort_by_label;
+  }
+  // per-label counts and the number of rows with at least one positive (anchors whose label occurs at least twice in the contrast
+  // set; loss.py:464-466)
+  int nv = 0;
+  if (tid < 256) {
+    const int ca = scalars[2 + tid], cc = ca + scalars[258 + tid];
+    meta->label_count_a[tid] = ca;
+    meta->label_count_c[tid] = cc;
+    nv = cc - 1 > 0 ? ca : 0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) nv += __shfl_xor(nv, off, 64);
+  if (lane == 0) warp_tot[wv] = nv;
+  __syncthreads();
+  if (tid == 0) meta->n_valid = warp_tot[0] + warp_tot[1] + warp_tot[2] + warp_tot[3];
+}
+
 // Stage 3: scatter pixel indices / labels to their compacted rows.
 __global__ __launch_bounds__(kBlock) void prep_scatter_kernel(const uint8_t* __restrict__ mix, const uint8_t* __restrict__ kind,
                                                              int BHW, int sort_by_label, const int32_t* __restrict__ off_a,
@@ -175,21 +247,32 @@ __global__ __launch_bounds__(kBlock) void prep_scatter_kernel(const uint8_t* __r
                                                              const ucd_pixcon_meta* __restrict__ meta,
                                                              int32_t* __restrict__ anchor_pix, int32_t* __restrict__ old_pix,
                                                              uint8_t* __restrict__ row_label) {
-  __shared__ uint8_t s_key[kBlock], s_kind[kBlock];
-  const int tid = threadIdx.x;
+  // rank of a row among the EARLIER rows of its block with the same key (the order-preserving compaction): per wave by ballots over
+  // the wave's distinct keys (a handful), across waves by a [wave][key] count table.  (Was: every thread walks all earlier threads
+  // of the block, 255 LDS reads for the last one: 38 us on the chain in front of the contrastive loss.)
+  __shared__ unsigned short w_a[4][256], w_o[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int p = blockIdx.x * kBlock + tid;
   const int m = p < BHW ? mix[p] : 0, kd = p < BHW ? kind[p] : 0;
   const int key = sort_by_label ? m : 0;
-  s_key[tid] = (uint8_t)key;
-  s_kind[tid] = (uint8_t)kd;
+  for (int i = tid; i < 4 * 256; i += kBlock) { (&w_a[0][0])[i] = 0; (&w_o[0][0])[i] = 0; }
+  __syncthreads();
+  int ra = 0, ro = 0;
+  {
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    unsigned long long todo = __ballot(kd != 0);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int k = __shfl(key, leader, 64);
+      const unsigned long long same_a = __ballot(kd != 0 && key == k), same_o = __ballot(kd == 2 && key == k);
+      if (kd != 0 && key == k) { ra = __popcll(same_a & below); ro = __popcll(same_o & below); }
+      if (lane == leader) { w_a[wv][k] = (unsigned short)__popcll(same_a); w_o[wv][k] = (unsigned short)__popcll(same_o); }
+      todo &= ~same_a;
+    }
+  }
   __syncthreads();
   if (!kd) return;
-  int ra = 0, ro = 0;  // earlier threads of this block with the same key
-  for (int j = 0; j < tid; ++j) {
-    const bool same = s_key[j] == key;
-    ra += (same && s_kind[j] != 0) ? 1 : 0;
-    ro += (same && s_kind[j] == 2) ? 1 : 0;
-  }
+  for (int i = 0; i < wv; ++i) { ra += w_a[i][key]; ro += w_o[i][key]; }
   const int ia = off_a[(size_t)key * nblk + blockIdx.x] + ra;
   anchor_pix[ia] = p;
   row_label[ia] = (uint8_t)m;
@@ -328,7 +411,15 @@ int ucd_pixcon_prep(const int64_t* labels, int B, int H, int W, int h, int w, in
                                                        prob, cnt_a, cnt_o, nblk, scalars);
   int rc = check_launch(fn);
   if (rc) return rc;
-  prep_scan_kernel<<<1, 1024, 0, s>>>(cnt_a, cnt_o, nblk, scalars, meta, sort_by_label);
+  {
+    const size_t n = (size_t)256 * nblk, scan_lds = (n + n / 32 + 1) * sizeof(int32_t);
+    if (scan_lds <= 150 * 1024) {
+      UCD_TRY_LDS(prep_scan_lds_kernel, 150 * 1024);
+      prep_scan_lds_kernel<<<1, 1024, scan_lds, s>>>(cnt_a, cnt_o, nblk, scalars, meta, sort_by_label);
+    } else {
+      prep_scan_kernel<<<1, 1024, 0, s>>>(cnt_a, cnt_o, nblk, scalars, meta, sort_by_label);
+    }
+  }
   rc = check_launch(fn);
   if (rc) return rc;
   prep_scatter_kernel<<<nblk, kBlock, 0, s>>>(mix, kind, BHW, sort_by_label, cnt_a, cnt_o, nblk, meta, anchor_pix,
