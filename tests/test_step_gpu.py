@@ -608,7 +608,7 @@ def test_twenty_step_trajectory_fp32_and_bf16_against_the_reference():
         assert cos > floor and 0.85 < ratio < 1.25, (n, cos, ratio)
 
 
-def _scheduled_steps(step_graph, steps=8, batch=3, crop=257, reload_at=None):
+def _scheduled_steps(step_graph, steps=8, batch=3, crop=257, reload_at=None, extra_args=(), probe=None):
     """``steps`` iterations of the benchmarked mode with PolyLR stepping every iteration (train.py:150-151), with or without the
     whole-step graph; returns losses per step, a few parameters afterwards and the number of replayed iterations."""
     from ucd_amd import switches
@@ -619,7 +619,7 @@ def _scheduled_steps(step_graph, steps=8, batch=3, crop=257, reload_at=None):
     dev = torch.device("cuda:0")
     opts = argparser.modify_command_options(argparser.get_argparser().parse_args(
         ["--method", "UCD", "--dataset", "voc", "--task", "15-5", "--step", "1", "--lr", "0.001", "--no_pretrained",
-         "--norm_act", "iabn_sync", "--opt_level", "O1"]))
+         "--norm_act", "iabn_sync", "--opt_level", "O1"] + list(extra_args)))
     classes = tasks.get_per_task_classes("voc", "15-5", 1)
     model, model_old = build_models(opts, dev, classes)
     state = synth.fill_state_dict({k: v.cpu() for k, v in model_old.state_dict().items()}, 42, calibrated=True)
@@ -646,10 +646,45 @@ def _scheduled_steps(step_graph, steps=8, batch=3, crop=257, reload_at=None):
         params = dict(net.named_parameters())
         after = {n: params[n].detach().float().cpu().clone() for n in TRAJ_UPDATE_NAMES}
         after["running_var"] = net.body.mod4.block5.convs.bn2.running_var.cpu().clone()
+        if probe is not None:
+            probe(net, after)
         return np.asarray(rec), after, trainer.graph_steps, lrs, trainer.step_graph_error
     finally:
         torch.backends.cudnn.deterministic = False
         switches.unset("UCD_STEP_GRAPH")
+
+
+@pytest.mark.usefixtures("deterministic_stats")
+def test_fix_bn_freezes_the_norm_parameters_and_nothing_else():
+    """``--fix_bn`` (run.py:169-170 -> segmentation_module.py:138-143: every norm layer .eval(), weight / bias requires_grad False) is
+    followed by ``model.train()`` at the head of every epoch (train.py:94), which puts the norm layers back into training mode: the
+    flag's lasting effect is on the norm PARAMETERS - batch statistics still normalise and still move the running statistics.  Three
+    captured-graph-free iterations with and without the flag from the same checkpoint: the first iteration's losses agree (same
+    forward), gamma / beta stay bit-identical under the flag and move without it, the running statistics move in both, the
+    convolution weights move in both and by the same first update."""
+    names = {}
+
+    def probe(net, after):
+        bn = net.body.mod3.block2.convs.bn2
+        after["bn_weight"], after["bn_bias"] = bn.weight.detach().float().cpu().clone(), bn.bias.detach().float().cpu().clone()
+        after["bn_rm"] = bn.running_mean.detach().float().cpu().clone()
+        after["frozen"] = sum(1 for m in net.modules() if hasattr(m, "running_mean") and not m.weight.requires_grad)
+        after["norms"] = sum(1 for m in net.modules() if hasattr(m, "running_mean"))
+        after["conv"] = net.body.mod3.block2.convs.conv2.weight.detach().float().cpu().clone()
+
+    ref0 = {}
+    _scheduled_steps("0", steps=0, probe=lambda net, after: (probe(net, after), ref0.update(after)))
+    plain_l, plain, _, _, _ = _scheduled_steps("0", steps=3, probe=probe)
+    fixed_l, fixed, _, _, _ = _scheduled_steps("0", steps=3, extra_args=("--fix_bn",), probe=probe)
+    assert fixed["frozen"] == fixed["norms"] > 100 and plain["frozen"] == 0
+    np.testing.assert_allclose(fixed_l[0], plain_l[0], rtol=2e-4)                  # iteration 1: the same forward
+    assert torch.equal(fixed["bn_weight"], ref0["bn_weight"]) and torch.equal(fixed["bn_bias"], ref0["bn_bias"])
+    assert not torch.equal(plain["bn_weight"], ref0["bn_weight"]) and not torch.equal(plain["bn_bias"], ref0["bn_bias"])
+    assert not torch.equal(fixed["bn_rm"], ref0["bn_rm"]) and not torch.equal(plain["bn_rm"], ref0["bn_rm"])
+    d_fixed, d_plain = fixed["conv"] - ref0["conv"], plain["conv"] - ref0["conv"]
+    assert d_fixed.norm() > 0 and d_plain.norm() > 0
+    cos = (d_fixed * d_plain).sum() / (d_fixed.norm() * d_plain.norm())
+    assert cos > 0.9, cos            # three updates from the same start; they part ways only through the norm parameters
 
 
 @pytest.mark.parametrize("stat_atomic", ["0", "1"])
