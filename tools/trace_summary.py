@@ -1,6 +1,6 @@
 """Summarise a rocprofv3 --kernel-trace CSV of bench.py into a small per-kernel table of the LAST two steps
 (step boundaries = pixcon_reduce_kernel launches).  usage: trace_summary.py <kernel_trace.csv> <out.txt> [title]"""
-import collections, csv, re, sys
+import collections, csv, os, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "pixcon_reduce_kernel" in r["Kernel_Name"]]
@@ -56,7 +56,7 @@ with open(sys.argv[2], "w") as f:
             ((t1 - t0) / 2e6, sum(v[0] for v in agg.values()) / 2e6, len(win) // 2))
     f.write("# by group (ms/step): " + ", ".join("%s %.2f" % kv for kv in sorted(grp.items(), key=lambda kv: -kv[1])) + "\n")
     f.write("%10s %10s %10s  %s\n" % ("ms/step", "calls/step", "avg_us", "kernel"))
-    for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+    for k, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:int(os.environ.get("UCD_TRACE_TOP", "70"))]:
         f.write("%10.3f %10.1f %10.2f  %s\n" % (d / 2e6, c / 2, d / c / 1e3, k))
     # the HBM-stream ABN kernels by launch geometry (= by layer shape): where the small layers sit against the large ones
     bygrid = collections.defaultdict(lambda: [0, 0])

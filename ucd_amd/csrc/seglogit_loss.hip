@@ -346,7 +346,7 @@ template <int KT, int NT>
 __global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
     const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
     int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
-    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y) {
+    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y, int cell_cap) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CT = KT + NT, NP = CT / 2, KP = KT / 2, kRep = kRepPk;
   // logit rows in LDS are CT + 1 / KT + 1 floats apart: the lanes of a wave read from ~5 cells, sixteen lanes the same address - a
@@ -363,6 +363,9 @@ __global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
   up_src(tx0, w, scale_w, xa, dummy, f0, f1);
   up_src(min(tx0 + kTileX, W) - 1, w, scale_w, dummy, xb, f0, f1);
   const int ny = yb - ya + 1, nx = xb - xa + 1, ncell = ny * nx;
+  // the host sized the LDS for the exact footprint it computed with the same arithmetic; a disagreement must not become a silent
+  // overrun of the accumulators
+  if (ncell > cell_cap) __builtin_trap();
   // copies 1 (mod 32) doubles apart: a lane's accumulator word sits at copy (lane & 7) * gstride + cell * CT + slot, and 24 * cell +
   // copy (mod 32) then takes 32 different values over the lanes of a wave - every LDS bank pair is hit by two lanes.  (Copies a
   // multiple of 32 doubles apart put all eight on the same banks: LDS busy 57 % of the kernel, SQ_LDS_BANK_CONFLICT.)
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
 #pragma unroll
     for (int it = 0; it < kRows; ++it) lv[it] = (Xl < W && Yl + it < H) ? labels[((size_t)b * H + Yl + it) * W + Xl] : 0;
 #pragma unroll
-    for (int it = 0; it < kRows; ++it) lab_s[it * kThreads + threadIdx.x] = lv[it] == ignore_index ? 0xFF : (unsigned char)lv[it];
+    for (int it = 0; it < kRows; ++it)      // as the generic form reads them: negative -> background, above the classes -> no class
+      lab_s[it * kThreads + threadIdx.x] = lv[it] == ignore_index ? 0xFF : (unsigned char)(lv[it] < 0 ? 0 : lv[it] > 254 ? 254 : lv[it]);
   }
   for (int i = threadIdx.x; i < ncell * CT; i += kThreads) {
     const int cell = i / CT, sl = i - cell * CT;
@@ -974,7 +978,7 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
 #define UCD_SEG_PK_LAUNCH(KT_, NT_)                                                                                              \
   seg_losses_pk_kernel<KT_, NT_><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(                                               \
       sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,             \
-      ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y)
+      ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y, ny * nx)
   if (pk_kt == 16) UCD_SEG_PK_LAUNCH(16, 8);
   else if (pk_kt == 20) UCD_SEG_PK_LAUNCH(20, 4);
   else if (pk_kt == 12) UCD_SEG_PK_LAUNCH(12, 12);
