@@ -598,7 +598,8 @@ __global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
 //     pair and flushed with one LDS atomic per class and corner (RW-fold fewer atomics, kRepW copies against column conflicts);
 //   * logits are read from LDS four classes at a time (rows padded to a multiple of four with -1e30: their exponentials are 0).
 constexpr int kRW = 8;            // rows per thread: a 32 x 64 pixel tile per workgroup
-constexpr int kRepW = 4;
+constexpr int kRepW = 4;          // (LDS sizing: the accumulators take the bytes of four fp32 copies)
+constexpr int kRepWD = 2;         // fp64 copies actually kept
 
 __device__ __forceinline__ float4 interp4(const float* base, int o00, int o01, int o10, int o11, int c, float lx0, float lx1,
                                           float ly0, float ly1) {
@@ -627,15 +628,17 @@ __global__ __launch_bounds__(kThreads) void seg_losses_wide_kernel(
   const int ny = yb - ya + 1, nx = xb - xa + 1, ncell = ny * nx;
   float* s_log = smem;                         // [ncell][CS]
   float* t_log = s_log + ncell * CS;           // [ncell][KS]
-  float* g_acc = t_log + ncell * KS;           // [kRepW][ncell][CS]
-  float* red = g_acc + kRepW * ncell * CS;     // [2][4]
-  const int gstride = ncell * CS;
+  // fp64 accumulators, two copies in the bytes of four fp32 ones: ds_add_f64 is 20x the rate of ds_add_f32 on gfx950 (section 3.5 of
+  // DESIGN.md, profiles/r05_lds_atomics.txt); copies 4 (mod 32) doubles apart keep them off each other's banks
+  const int gstride = ((ncell * CS + 31) & ~31) + 4;
+  double* g_acc = reinterpret_cast<double*>(t_log + ncell * KS);   // [kRepWD][gstride]
+  float* red = reinterpret_cast<float*>(g_acc + kRepWD * gstride);  // [2][4]
   for (int i = threadIdx.x; i < ncell * CS; i += kThreads) {
     const int cell = i / CS, c = i - cell * CS;
     const int cy = ya + cell / nx, cx = xa + cell % nx;
     s_log[i] = c < Ctot ? sem_s[((size_t)(b * h + cy) * w + cx) * ld_s + c] : kNegBig;
   }
-  for (int i = threadIdx.x; i < kRepW * gstride; i += kThreads) g_acc[i] = 0.f;
+  for (int i = threadIdx.x; i < kRepWD * gstride; i += kThreads) g_acc[i] = 0.0;
   for (int i = threadIdx.x; i < ncell * KS; i += kThreads) {
     const int cell = i / KS, c = i - cell * KS;
     const int cy = ya + cell / nx, cx = xa + cell % nx;
@@ -729,22 +732,22 @@ __global__ __launch_bounds__(kThreads) void seg_losses_wide_kernel(
     rbq[it] = kdw * inv_st;
   }
   // ---- phase B: gradients, 16 classes at a time ------------------------------------------------------------------------------
-  float* ga = g_acc + (threadIdx.x & (kRepW - 1)) * gstride;
+  double* ga = g_acc + (threadIdx.x & (kRepWD - 1)) * gstride;
   for (int cb = 0; cb < CS; cb += 16) {
     float acc0[16], acc1[16];
     int cur_y0 = -1, cur_y1 = -1;
     auto flush = [&]() {
       if (cur_y0 < 0) return;
       const int r0 = (cur_y0 - ya) * nx, r1 = (cur_y1 - ya) * nx;
-      float* g00 = ga + (r0 + cx0) * CS + cb; float* g01 = ga + (r0 + cx1) * CS + cb;
-      float* g10 = ga + (r1 + cx0) * CS + cb; float* g11 = ga + (r1 + cx1) * CS + cb;
+      double* g00 = ga + (r0 + cx0) * CS + cb; double* g01 = ga + (r0 + cx1) * CS + cb;
+      double* g10 = ga + (r1 + cx0) * CS + cb; double* g11 = ga + (r1 + cx1) * CS + cb;
 #pragma unroll
       for (int k = 0; k < 16; ++k)
         if (cb + k < Ctot) {
-          atomicAdd(g00 + k, lx0 * acc0[k]);
-          atomicAdd(g01 + k, lx1 * acc0[k]);
-          atomicAdd(g10 + k, lx0 * acc1[k]);
-          atomicAdd(g11 + k, lx1 * acc1[k]);
+          atomicAdd(g00 + k, (double)(lx0 * acc0[k]));
+          atomicAdd(g01 + k, (double)(lx1 * acc0[k]));
+          atomicAdd(g10 + k, (double)(lx0 * acc1[k]));
+          atomicAdd(g11 + k, (double)(lx1 * acc1[k]));
         }
     };
 #pragma unroll
@@ -795,9 +798,10 @@ __global__ __launch_bounds__(kThreads) void seg_losses_wide_kernel(
   for (int i = threadIdx.x; i < ncell * CS; i += kThreads) {
     const int cell = i / CS, c = i - cell * CS;
     if (c >= Ctot) continue;
-    float v = g_acc[i];
+    double vd = g_acc[i];
 #pragma unroll
-    for (int r = 1; r < kRepW; ++r) v += g_acc[r * gstride + i];
+    for (int r = 1; r < kRepWD; ++r) vd += g_acc[r * gstride + i];
+    const float v = (float)vd;
     if (v != 0.f) {
       const int cy = ya + cell / nx, cx = xa + cell % nx;
       atomicAdd(&d_sem[((size_t)(b * h + cy) * w + cx) * ld_d + c], v);
@@ -959,7 +963,7 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
     else if (K <= 20 && nnew <= 4) { pk_kt = 20; pk_nt = 4; }
     else if (K <= 12 && nnew <= 12) { pk_kt = 12; pk_nt = 12; }
   }
-  const size_t lds = wide ? ((size_t)ny * nx * ((1 + kRepW) * CS + KS) + 8) * sizeof(float)
+  const size_t lds = wide ? ((size_t)ny * nx * (CS + KS) + 8) * sizeof(float) + (size_t)kRepWD * (((ny * nx * CS + 31) & ~31) + 4) * 8
                    : pk_kt ? (size_t)kRepPk * (((ny * nx * (pk_kt + pk_nt) + 31) & ~31) + 1) * 8 + 8
                                  + ((size_t)ny * nx * ((pk_kt + pk_nt) + pk_kt + 2) + 8) * sizeof(float) + kRows * kThreads
                           : ((size_t)ny * nx * (17 * Ctot + K) + 8) * sizeof(float);
