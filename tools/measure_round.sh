@@ -1,7 +1,7 @@
 # Round measurement set -> gpurun_out/r05/ (copied to profiles/r05_* by hand).  Every profiler / probe call under its own timeout.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r05; mkdir -p $O
 cd $R
-if [ -z "$SKIP_TESTS" ]; then timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/gputests.log; fi
+if [ -z "$SKIP_TESTS" ]; then timeout 3000 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/gputests.log; fi
 timeout 900 python bench.py --steps 20 --warmup 6 > $O/bench_final.json 2> $O/bench_final.err
 brief() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'ms_per_step', round(d['ms_per_step'],3), 'img/s', round(d['value'],1), 'step_graph', d['execution']['step_graph'])"; }
 # the per-rank batches of the multi-GPU split on one GPU, with the captured step and without
@@ -9,9 +9,8 @@ brief() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().spli
 # A/B of this round's switches on this box (alternating, two repetitions)
 (for rep in 1 2; do
   for sa in 0 1; do UCD_STAT_ATOMIC=$sa timeout 300 python bench.py --steps 20 --warmup 6 --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "rep $rep UCD_STAT_ATOMIC=$sa"; done
-  for ra in 0 2; do UCD_CONV_RA=$ra timeout 300 python bench.py --steps 20 --warmup 6 --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "rep $rep UCD_CONV_RA=$ra"; done
+  for pk in 0 1; do UCD_SEG_PK=$pk timeout 300 python bench.py --steps 20 --warmup 6 --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "rep $rep UCD_SEG_PK=$pk"; done
 done) > $O/kernel_ab.txt 2>&1
-(for ra in 0 2; do UCD_CONV_RA=$ra timeout 300 python tools/conv_ra_probe.py 2>&1 | grep -v amdgpu.ids; done) > $O/conv_ra_probe.txt 2>&1
 # the multi-rank step with its collectives, as far as one GPU can run it: eager first, then captured (bench.py --force_dist)
 (for gb in 3 6 12; do timeout 400 python bench.py --force_dist --steps 16 --warmup 6 --global_batch $gb --no_cpu_baseline --no_kernel_timing 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('--force_dist global_batch $gb', 'ms_per_step', round(d['ms_per_step'],3), 'eager_ms', d['execution']['eager_ms'], 'graph_ms', d['execution']['graph_ms'], d['execution']['step_graph_error'])"; done) > $O/forced_collectives.txt 2>&1
 timeout 300 python tools/conv1x1_probe.py > $O/conv1x1_probe.txt 2>&1
