@@ -42,6 +42,14 @@ void* workspace(const at::Tensor& like, size_t bytes, int64_t stream, int tag = 
   return it->second.data_ptr();
 }
 
+// test hook (tests/diag/poison_step_diag.py): fill every cached scratch buffer with a byte pattern - a kernel that reads scratch it has
+// not written shows up as a changed (or NaN) result
+void poison_workspaces(int64_t byte, int64_t tag) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  for (auto& kv : g_ws)
+    if (tag < 0 || kv.first.first % 4 == tag) kv.second.fill_(byte);
+}
+
 // ---- statistics arena (round 5) ----------------------------------------------------------------------------------------------------
 // The per-layer [2 C] accumulators that the GEMM epilogues add their column sums to with fp32 atomics (ucd_conv1x1 stat_acc) live in
 // ONE zero-filled buffer per device: a slot is handed out per layer and direction during the forward, and stat_arena_reset - called
@@ -982,6 +990,7 @@ at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::opti
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node of the training-mode ABN layer over libucd_hip.so";
+  m.def("poison_workspaces", &poison_workspaces);
   m.def("stat_arena_reset", &stat_arena_reset, "zero the used part of the statistics arena of a device and start a new generation");
   m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
   m.def("dense_channels_last", &dense_channels_last);
