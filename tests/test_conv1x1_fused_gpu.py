@@ -1244,8 +1244,9 @@ def test_atomic_links_survive_an_arena_reset_and_refuse_a_second_fill():
         torch.cuda.synchronize()
         grads.append([x.grad.float().clone()] + [p.grad.float().clone() for p in net.parameters()])
     for a, b in zip(*grads):
-        # a link served or not: one more bf16 rounding of a gradient map (the link tests' bound: 3e-2; measured 2.2e-2 here)
-        assert torch.isfinite(a).all() and _rel(a, b) < 4e-2
+        # a link served or not: one more bf16 rounding of a gradient map (the link tests' bound: 3e-2; here, with fp32-atomic sums on
+        # top, 2.2e-2 - 4.5e-2 from run to run on the d bias vectors, whose terms cancel); a lost or doubled link term is off by O(1)
+        assert torch.isfinite(a).all() and _rel(a, b) < 8e-2
     # (2) the whole backward run twice (retain_graph): the slots are in state "read" after the first pass, so the second pass's
     # consumers do not serve the links (a second fill would double the sums) and the producers reduce for themselves - the same
     # gradients again, not twice the link terms
@@ -1264,7 +1265,7 @@ def test_atomic_links_survive_an_arena_reset_and_refuse_a_second_fill():
     torch.cuda.synchronize()
     second = [x.grad.float().clone()] + [p.grad.float().clone() for p in net.parameters()]
     for a, b in zip(first, second):
-        assert torch.isfinite(b).all() and _rel(b, a) < 4e-2
+        assert torch.isfinite(b).all() and _rel(b, a) < 8e-2
 
 
 _RA_CHILD = r"""
