@@ -1,4 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2 3; do for b in 0 127 63; do
-echo "== rep $rep byte $b: $(DIAG_POISON=cpp DIAG_POISON_BYTE=$b timeout 600 python tests/diag/poison_step_diag.py 2>&1 | grep 'poisoned\|huge  ' | sed 's/.*\] identical: \([A-Za-z]*\) *\(nan: [A-Za-z]*\)*.*/\1 \2/' | tr '\n' ' ')"
+for ov in 0 1; do for rep in 1 2 3 4 5; do
+echo "== overlap $ov rep $rep: $(UCD_TEACHER_OVERLAP=$ov DIAG_POISON=cpp DIAG_POISON_BYTE=0 timeout 600 python tests/diag/poison_step_diag.py 2>&1 | grep 'poisoned\|huge  ' | sed 's/.*\] identical: \([A-Za-z]*\).*/\1/' | tr '\n' ' ')"
 done; done
