@@ -569,6 +569,13 @@ int ucd_abn_sync_finalize(const float* gathered, int world, int M, int C, const 
  * bf16 weight in channels-last memory order [64][7][7][3], z [B, OH, OW, 64] dense channels-last bf16, OH = (H - 1) / 2 + 1. */
 int ucd_stem_conv7x7(const float* x, long long sb, long long sc, long long sh, long long sw, int B, int H, int W, const void* w,
                      void* z, ucd_stream_t stream);
+
+/* The same convolution followed by the frozen-statistics norm + activation + 3x3 / 2 max pool (models/resnet.py:58-64 in evaluation
+ * mode: the teacher) in ONE kernel: out [B, PH, PW, 64] bf16 = max_pool2d(act((conv(x) - mean) * scale + beta), 3, 2, 1), the
+ * convolution output rounded to bf16 in between as ucd_stem_conv7x7 stores it - bit-identical to ucd_stem_conv7x7 followed by
+ * ucd_stem_apply_pool, without the 257 x 257 x 64 map in memory.  leaky_relu / identity; mean, scale, beta [64] fp32, 16-byte aligned. */
+int ucd_stem_conv_pool(const float* x, long long sb, long long sc, long long sh, long long sw, int B, int H, int W, const void* w,
+                       const float* mean, const float* scale, const float* beta, int act, float slope, void* out, ucd_stream_t stream);
 int ucd_stem_pooled_size(int n);
 size_t ucd_stem_pool_workspace_bytes(int C);
 int ucd_stem_apply_pool(const void* z, int B, int H, int W, int C, const float* mean, const float* scale, const float* beta, int act,

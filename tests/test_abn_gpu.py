@@ -632,6 +632,66 @@ def test_stem_conv7x7_matches_conv2d(B, H, W, nchw):
     err = ((z.float() - ref).norm() / ref.norm()).item()
     assert err < 3e-3, err
 
+@pytest.mark.parametrize("B,H,W,nchw,slope", [(2, 65, 65, False, 0.01), (3, 129, 97, True, 0.01), (24, 513, 513, False, 0.01),
+                                              (1, 9, 11, False, 1.0), (2, 33, 61, False, 0.2), (1, 8, 8, False, 0.01)])
+def test_stem_conv_norm_pool_in_one_kernel_equals_the_two_kernels(B, H, W, nchw, slope):
+    """Round 5: ucd_stem_conv_pool (the frozen-statistics stem of the teacher: conv1 -> norm -> activation -> 3x3 / 2 max pool,
+    models/resnet.py:58-64 in evaluation mode, as ONE kernel that never writes the convolution output) against ucd_stem_conv7x7
+    followed by ucd_stem_apply_pool: bit-identical, at map sizes whose pooled tiles (3 x 15) end everywhere - one row, one column,
+    full - and in both image memory formats."""
+    from ucd_amd import hip
+    DEV = "cuda:0"
+    g = torch.Generator(DEV).manual_seed(B * H + W + 7)
+    cl = torch.channels_last
+    x = torch.randn(B, 3, H, W, device=DEV, generator=g) * 1.5 + 0.3
+    if not nchw:
+        x = x.contiguous(memory_format=cl)
+    w = (torch.randn(64, 3, 7, 7, device=DEV, generator=g) * 0.1).bfloat16().contiguous(memory_format=cl)
+    mean = torch.randn(64, device=DEV, generator=g) * 0.2
+    scale = torch.rand(64, device=DEV, generator=g) + 0.5
+    scale[3] = -0.8                                                      # a negative scale: the maximum moves to the smallest z
+    beta = torch.randn(64, device=DEV, generator=g) * 0.3
+    act = 1 if slope != 1.0 else 0
+    z = hip.stem_conv7x7(x, w)
+    ref, _ = hip.stem_apply_pool(z, mean, scale, beta, act, slope, False)
+    out = hip.stem_conv_pool(x, w, mean, scale, beta, act, slope)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=cl)
+    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+    out2 = hip.stem_conv_pool(x, w, mean, scale, None, act, slope)
+    ref2, _ = hip.stem_apply_pool(z, mean, scale, None, act, slope, False)
+    assert torch.equal(out2, ref2)
+
+
+def test_teacher_stem_takes_the_one_kernel_path_and_matches():
+    """The evaluation-mode stem of the backbone (ucd_amd/backbone.py::_stem) under no_grad + bf16 autocast goes through
+    ucd_stem_conv_pool and returns what the two-kernel path (UCD_STEM_EVAL_FUSED=0) returns, bit for bit."""
+    from functools import partial
+    from ucd_amd import abn, backbone, hip, switches
+    DEV = "cuda:0"
+    norm = partial(abn.InPlaceABNSync, activation="leaky_relu", activation_param=0.01)
+    net = backbone.ResNet([1, 1, 1, 1], True, norm_act=norm, output_stride=16) if hasattr(backbone, "ResNet") else None
+    if net is None:
+        pytest.skip("backbone.ResNet not exposed")
+    net = net.to(DEV).to(memory_format=torch.channels_last).eval()
+    with torch.no_grad():
+        net.mod1.bn1.running_mean.normal_(0, 0.2); net.mod1.bn1.running_var.uniform_(0.5, 1.5)
+        net.mod1.bn1.weight.normal_(1, 0.3); net.mod1.bn1.bias.normal_(0, 0.2)
+    x = torch.randn(2, 3, 129, 129, device=DEV).contiguous(memory_format=torch.channels_last)
+    calls = []
+    orig = hip.stem_conv_pool
+    hip.stem_conv_pool = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            y1 = net._stem(x)
+            switches.set("UCD_STEM_EVAL_FUSED", "0")
+            y0 = net._stem(x)
+    finally:
+        hip.stem_conv_pool = orig
+        switches.unset("UCD_STEM_EVAL_FUSED")
+    assert len(calls) == 1
+    assert torch.equal(y1, y0)
+
+
 _PACKED_VS_GENERIC = r"""
 import sys, torch
 from ucd_amd import hip

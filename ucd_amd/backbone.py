@@ -70,6 +70,9 @@ class ResNet(nn.Module):
             pool = m.pool1
             if (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False):
                 from .abn import stem_norm_pool
+                y = _stem_eval_fused(m.conv1, m.bn1, x)
+                if y is not None:
+                    return y
                 z = _stem_conv(m.conv1, x)
                 y = stem_norm_pool(m.bn1, z)
                 return y if y is not None else pool(m.bn1(z))
@@ -120,6 +123,27 @@ def _stem_conv(conv, x):
         return _StemConvFunction.apply(x, w)
     from . import hip
     return hip.stem_conv7x7(x, w)
+
+
+def _stem_eval_fused(conv, bn, x):
+    """conv1 -> bn1 (frozen statistics) -> pool of the stem as ONE kernel when no gradient is wanted (the teacher, validation):
+    csrc/stem.hip::stem_conv_pool_kernel, bit-identical to the two-kernel path without the 203 MB convolution output in memory.
+    None when the layers / the input are not what it takes (``UCD_STEM_EVAL_FUSED=0`` switches it off)."""
+    from . import abn as _abn
+    if (torch.is_grad_enabled() or bn.training or _switches.get("UCD_STEM_EVAL_FUSED", "1") == "0" or _switches.get("UCD_OWN_STEM", "1") == "0"
+            or _switches.get("UCD_STEM_FOLD", "1") == "0" or not getattr(bn, "ucd_fused_abn", False)
+            or bn.activation not in ("leaky_relu", "identity")):             # (|gamma| + eps is part of the cached scale)
+        return None
+    w = conv.working_weight() if hasattr(conv, "working_weight") else None
+    if w is None and x.is_cuda and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        w = conv.weight.to(torch.bfloat16)
+    if (w is None or not x.is_cuda or x.dim() != 4 or x.dtype != torch.float32 or conv.bias is not None
+            or tuple(conv.weight.shape) != (64, 3, 7, 7) or conv.stride != (2, 2) or conv.padding != (3, 3) or conv.dilation != (1, 1)
+            or w.dtype != torch.bfloat16 or not w.is_contiguous(memory_format=torch.channels_last) or x.shape[2] < 8 or x.shape[3] < 8):
+        return None
+    from . import hip
+    invstd, scale = bn._eval_constants()
+    return hip.stem_conv_pool(x, w, bn.running_mean, scale, bn.bias, _abn._act_code(bn.activation), bn.activation_param)
 
 
 _NETS = {

@@ -360,6 +360,153 @@ __global__ __launch_bounds__(kThreads) void stem_conv7x7_kernel(StemConvArgs p) 
   }
 }
 
+// ---- frozen statistics (the teacher): convolution + norm + activation + 3x3 / 2 max pool in ONE kernel (round 5) --------------------
+// Without gradients nobody needs the 257 x 257 x 64 convolution output (203 MB at 24 images): here it exists as one 8 x 32 tile in
+// LDS.  A workgroup tile is 3 x 15 POOLED pixels; it computes the 8 x 32 convolution outputs around them with the product code of
+// stem_conv7x7_kernel (origin 2 ph0 - 1, 2 pw0 - 1: one row and one column of halo are recomputed by the neighbours, 1.42x the
+// MFMA work of a kernel that is bound by its 76 MB image read), rounds them to bf16 as the two-kernel path stores them, applies
+// norm + activation with the same expression as stem_apply_pool_kernel - bit-identical results - and pools from LDS.
+constexpr int kFPH = 3, kFPW = 15;                    // pooled tile
+struct StemFusedArgs {
+  StemConvArgs c;                                     // c.z unused; c.tiles_* count POOLED tiles
+  const float *mean, *scale, *beta;
+  float slope;
+  bf16* out;                                          // [B, PH, PW, 64]
+  int PH, PW;
+};
+
+__global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs q) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  const StemConvArgs& p = q.c;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fs_raw[];
+  unsigned short* Wl = reinterpret_cast<unsigned short*>(fs_raw);                   // [64][kSWP]
+  unsigned short* In = Wl + 64 * kSWP;                                              // [kSIR][kSIP]
+  unsigned short* Tl = In + kSIR * kSIP;                                            // [8][32][64] activated tile (bf16 bits)
+  float* Pl = reinterpret_cast<float*>(Tl + kSTH * kSTW * 64);                      // [3][64] mean | scale | shift
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 64 * kSWP; i += kThreads) Wl[i] = 0;
+  if (tid < 64) { Pl[tid] = q.mean[tid]; Pl[64 + tid] = q.scale[tid]; Pl[128 + tid] = q.beta ? q.beta[tid] : 0.f; }
+  __syncthreads();
+  for (int i = tid; i < 64 * 147; i += kThreads) {
+    const int n = i / 147, r = i - n * 147, ky = r / 21, j = r - ky * 21;
+    Wl[n * kSWP + ky * 24 + j] = reinterpret_cast<const unsigned short*>(p.w)[i];
+  }
+  const int col = lane & 31, h = lane >> 5;
+  const int fe = tid < kSIP ? tid : kSIP - 1, fpx = fe / 3, fc = fe - fpx * 3;
+  float pre[kSIR];
+  auto origin = [&](int tile, int& b, int& oy0, int& ox0) {
+    b = tile / (p.tiles_y * p.tiles_x);
+    const int rem = tile - b * p.tiles_y * p.tiles_x;
+    oy0 = 2 * (rem / p.tiles_x) * kFPH - 1;
+    ox0 = 2 * (rem % p.tiles_x) * kFPW - 1;
+  };
+  auto fetch = [&](int tile) {
+    int b, oy0, ox0;
+    origin(tile, b, oy0, ox0);
+    const int ix = 2 * ox0 - 3 + fpx;
+    const bool colok = fpx < 2 * kSTW + 5 && (unsigned)ix < (unsigned)p.W;
+    const float* src = p.x + b * p.sb + fc * p.sc + (colok ? ix : 0) * p.sw;
+#pragma unroll
+    for (int r = 0; r < kSIR; ++r) {
+      const int iy = 2 * oy0 - 3 + r;
+      const bool ok = colok && (unsigned)iy < (unsigned)p.H;
+      const float v = src[(ok ? iy : 0) * p.sh];
+      pre[r] = ok ? v : 0.f;
+    }
+  };
+  if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int b, oy0, ox0;
+    origin(tile, b, oy0, ox0);
+    __syncthreads();                                   // the previous tile's reads (patch and pooled tile) are done
+    if (tid < kSIP) {
+#pragma unroll
+      for (int r = 0; r < kSIR; ++r) {
+        const bf16 v = __float2bfloat16(pre[r]);
+        In[r * kSIP + tid] = *reinterpret_cast<const unsigned short*>(&v);
+      }
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < p.ntiles) fetch(tile + gridDim.x);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < kSK / 16; ++s) {
+      const int t0 = 2 * s, t1 = 2 * s + 1;
+      const int ky = h ? (t1 / 3 > 6 ? 6 : t1 / 3) : t0 / 3, j0 = h ? 8 * (t1 % 3) : 8 * (t0 % 3);
+      bf16x8 wf[2], pf[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) wf[c] = *reinterpret_cast<const bf16x8*>(&Wl[(c * 32 + col) * kSWP + 16 * s + 8 * h]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int orow = wave * 2 + a;
+        const unsigned* src = reinterpret_cast<const unsigned*>(&In[(2 * orow + ky) * kSIP + 6 * col + j0]);
+        union { unsigned u[4]; bf16x8 v; } f;
+        f.u[0] = src[0]; f.u[1] = src[1]; f.u[2] = src[2]; f.u[3] = src[3];
+        pf[a] = f.v;
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[c], pf[a], acc[a][c], 0, 0, 0);
+    }
+    // norm + activation of the bf16-rounded outputs into the LDS tile; positions outside the map are the pooling's padding (-inf)
+    const int ox = ox0 + col;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int orow = wave * 2 + a, oy = oy0 + orow;
+      const bool inside = (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
+      unsigned short* dst = Tl + (orow * kSTW + col) * 64;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = c * 32 + 8 * g + 4 * h;
+          const float4 mu = *reinterpret_cast<const float4*>(Pl + ch), sc = *reinterpret_cast<const float4*>(Pl + 64 + ch);
+          const float4 sh = *reinterpret_cast<const float4*>(Pl + 128 + ch);
+          const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, s4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sh.x, sh.y, sh.z, sh.w};
+          union { bf16 v[4]; uint2 u; } o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float zq = bf16_round(acc[a][c][g * 4 + e]);                       // what stem_conv7x7_kernel stores
+            o.v[e] = __float2bfloat16(leaky((zq - m4[e]) * s4[e] + b4[e], q.slope));  // what stem_apply_pool_kernel compares
+          }
+          if (!inside) o.u = make_uint2(0xFF80FF80u, 0xFF80FF80u);
+          *reinterpret_cast<uint2*>(dst + ch) = o.u;
+        }
+    }
+    __syncthreads();
+    // 3 x 15 pooled pixels x 8 channel groups of 8
+    for (int i = tid; i < kFPH * kFPW * 8; i += kThreads) {
+      const int cg = i & 7, pp = i >> 3, pr = pp / kFPW, pc = pp - pr * kFPW;
+      const int ph = (oy0 + 1) / 2 + pr, pw = (ox0 + 1) / 2 + pc;
+      if (ph >= q.PH || pw >= q.PW) continue;
+      float best[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) best[e] = -INFINITY;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          Vec<bf16> v;
+          v.raw = *reinterpret_cast<const uint4*>(Tl + ((2 * pr + kh) * kSTW + 2 * pc + kw) * 64 + cg * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v.get(e));
+        }
+      Vec<bf16> o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.set(e, best[e]);
+      o.store(q.out + (((size_t)b * q.PH + ph) * q.PW + pw) * 64 + cg * 8);
+    }
+  }
+}
+
 bool stem_args_ok(const void* z, int B, int H, int W, int C) {
   return z && B > 0 && B < 65536 && H > 1 && H < 65536 && W > 1 && C >= 8 && (C & (C - 1)) == 0 && C <= 2048 && aligned16(z);
 }
@@ -401,6 +548,27 @@ int ucd_stem_conv7x7(const float* x, long long sb, long long sc, long long sh, l
   p.tiles_y = ceil_div(p.OH, kSTH); p.tiles_x = ceil_div(p.OW, kSTW); p.ntiles = B * p.tiles_y * p.tiles_x;
   const int grid = p.ntiles < 768 ? p.ntiles : 768;          // three resident workgroups per CU, each walking its tiles
   stem_conv7x7_kernel<<<grid, kThreads, 0, (hipStream_t)stream>>>(p);
+  return check_launch(fn);
+}
+
+int ucd_stem_conv_pool(const float* x, long long sb, long long sc, long long sh, long long sw, int B, int H, int W, const void* w,
+                       const float* mean, const float* scale, const float* beta, int act, float slope, void* out, ucd_stream_t stream) {
+  static const char* fn = "ucd_stem_conv_pool";
+  UCD_REQUIRE(x && w && out && mean && scale && B > 0 && H > 0 && W > 0 && aligned16(out) && (reinterpret_cast<uintptr_t>(w) & 1) == 0 &&
+              aligned16(mean) && aligned16(scale) && (!beta || aligned16(beta)), UCD_EINVAL, "%s: bad arguments", fn);
+  const int a = act & UCD_ACT_MASK;
+  UCD_REQUIRE(a != UCD_ACT_ELU && !(act & UCD_NORM_ABS_GAMMA), UCD_EUNSUPPORTED, "%s: leaky_relu / identity with given scale only", fn);
+  StemFusedArgs q{};
+  StemConvArgs& p = q.c;
+  p.x = x; p.sb = sb; p.sc = sc; p.sh = sh; p.sw = sw; p.w = (const bf16*)w; p.z = nullptr;
+  p.B = B; p.H = H; p.W = W; p.OH = (H + 6 - 7) / 2 + 1; p.OW = (W + 6 - 7) / 2 + 1;
+  q.PH = ucd_stem_pooled_size(p.OH); q.PW = ucd_stem_pooled_size(p.OW);
+  p.tiles_y = ceil_div(q.PH, kFPH); p.tiles_x = ceil_div(q.PW, kFPW); p.ntiles = B * p.tiles_y * p.tiles_x;
+  q.mean = mean; q.scale = scale; q.beta = beta; q.slope = a == UCD_ACT_IDENTITY ? 1.f : slope; q.out = (bf16*)out;
+  const size_t lds = (size_t)(64 * kSWP + kSIR * kSIP + kSTH * kSTW * 64) * 2 + 3 * 64 * 4;
+  UCD_TRY_LDS(stem_conv_pool_kernel, 80 * 1024);
+  const int grid = p.ntiles < 512 ? p.ntiles : 512;          // two resident workgroups per CU (66 KB of LDS each), each walking its tiles
+  stem_conv_pool_kernel<<<grid, kThreads, lds, (hipStream_t)stream>>>(q);
   return check_launch(fn);
 }
 

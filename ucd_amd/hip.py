@@ -121,6 +121,7 @@ SIGNATURES = {
     "ucd_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "ucd_conv_wgrad": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_stem_conv7x7": (_i, [_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p, _p]),
+    "ucd_stem_conv_pool": (_i, [_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p, _p]),
     "ucd_conv_wgrad_strided": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
     "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
@@ -629,6 +630,21 @@ def stem_conv7x7(x, w):
     with _timed("ucd_stem_conv7x7", x.numel() * 4 + z.numel() * 2):
         _check(lib.ucd_stem_conv7x7(ptr(x), sb, sc, sh, sw, B, H, W, ptr(w), ptr(z), stream()), "ucd_stem_conv7x7")
     return z
+
+
+def stem_conv_pool(x, w, mean, scale, beta, act, slope):
+    """conv1 + frozen norm + activation + 3x3 / 2 max pool of the stem in one kernel (ucd_stem_conv_pool): ``x`` fp32 [B, 3, H, W],
+    ``w`` bf16 [64, 3, 7, 7] channels-last; returns the pooled bf16 map [B, 64, PH, PW] (channels-last)."""
+    lib = load()
+    B, _, H, W = x.shape
+    OH, OW = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    PH, PW = lib.ucd_stem_pooled_size(OH), lib.ucd_stem_pooled_size(OW)
+    out = torch.empty((B, 64, PH, PW), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    sb, sc, sh, sw = x.stride()
+    with _timed("ucd_stem_conv7x7", x.numel() * 4 + out.numel() * 2):
+        _check(lib.ucd_stem_conv_pool(ptr(x), sb, sc, sh, sw, B, H, W, ptr(w), ptr(mean), ptr(scale), ptr(beta), act, float(slope),
+                                      ptr(out), stream()), "ucd_stem_conv_pool")
+    return out
 
 
 def stem_apply_pool(z, mean, scale, beta, act, slope, want_idx):
