@@ -367,6 +367,8 @@ __global__ __launch_bounds__(kThreads) void stem_conv7x7_kernel(StemConvArgs p) 
 // MFMA work of a kernel that is bound by its 76 MB image read), rounds them to bf16 as the two-kernel path stores them, applies
 // norm + activation with the same expression as stem_apply_pool_kernel - bit-identical results - and pools from LDS.
 constexpr int kFPH = 3, kFPW = 15;                    // pooled tile
+constexpr int kFTP = 72;                              // bf16 pitch of a pixel of the activated tile: 64 channels + 8 (144 B: the 32 pixels of
+                                                      // a row land on 16 different bank offsets instead of 2 - SQ_LDS_BANK_CONFLICT 0.62 at 64)
 struct StemFusedArgs {
   StemConvArgs c;                                     // c.z unused; c.tiles_* count POOLED tiles
   const float *mean, *scale, *beta;
@@ -382,8 +384,8 @@ __global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs 
   extern __shared__ __attribute__((aligned(16))) unsigned char fs_raw[];
   unsigned short* Wl = reinterpret_cast<unsigned short*>(fs_raw);                   // [64][kSWP]
   unsigned short* In = Wl + 64 * kSWP;                                              // [kSIR][kSIP]
-  unsigned short* Tl = In + kSIR * kSIP;                                            // [8][32][64] activated tile (bf16 bits)
-  float* Pl = reinterpret_cast<float*>(Tl + kSTH * kSTW * 64);                      // [3][64] mean | scale | shift
+  unsigned short* Tl = In + kSIR * kSIP;                                            // [8][32][kFTP] activated tile (bf16 bits)
+  float* Pl = reinterpret_cast<float*>(Tl + kSTH * kSTW * kFTP);                    // [3][64] mean | scale | shift
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < 64 * kSWP; i += kThreads) Wl[i] = 0;
   if (tid < 64) { Pl[tid] = q.mean[tid]; Pl[64 + tid] = q.scale[tid]; Pl[128 + tid] = q.beta ? q.beta[tid] : 0.f; }
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs 
     for (int a = 0; a < 2; ++a) {
       const int orow = wave * 2 + a, oy = oy0 + orow;
       const bool inside = (unsigned)oy < (unsigned)p.OH && (unsigned)ox < (unsigned)p.OW;
-      unsigned short* dst = Tl + (orow * kSTW + col) * 64;
+      unsigned short* dst = Tl + (orow * kSTW + col) * kFTP;
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs 
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           Vec<bf16> v;
-          v.raw = *reinterpret_cast<const uint4*>(Tl + ((2 * pr + kh) * kSTW + 2 * pc + kw) * 64 + cg * 8);
+          v.raw = *reinterpret_cast<const uint4*>(Tl + ((2 * pr + kh) * kSTW + 2 * pc + kw) * kFTP + cg * 8);
 #pragma unroll
           for (int e = 0; e < 8; ++e) best[e] = fmaxf(best[e], v.get(e));
         }
@@ -565,7 +567,7 @@ int ucd_stem_conv_pool(const float* x, long long sb, long long sc, long long sh,
   q.PH = ucd_stem_pooled_size(p.OH); q.PW = ucd_stem_pooled_size(p.OW);
   p.tiles_y = ceil_div(q.PH, kFPH); p.tiles_x = ceil_div(q.PW, kFPW); p.ntiles = B * p.tiles_y * p.tiles_x;
   q.mean = mean; q.scale = scale; q.beta = beta; q.slope = a == UCD_ACT_IDENTITY ? 1.f : slope; q.out = (bf16*)out;
-  const size_t lds = (size_t)(64 * kSWP + kSIR * kSIP + kSTH * kSTW * 64) * 2 + 3 * 64 * 4;
+  const size_t lds = (size_t)(64 * kSWP + kSIR * kSIP + kSTH * kSTW * kFTP) * 2 + 3 * 64 * 4;
   UCD_TRY_LDS(stem_conv_pool_kernel, 80 * 1024);
   const int grid = p.ntiles < 512 ? p.ntiles : 512;          // two resident workgroups per CU (66 KB of LDS each), each walking its tiles
   stem_conv_pool_kernel<<<grid, kThreads, lds, (hipStream_t)stream>>>(q);
