@@ -283,7 +283,9 @@ __global__ __launch_bounds__(kThreads) void stem_conv7x7_kernel(StemConvArgs p) 
   // them (the first version loaded and stored element by element: 18 exposed round trips per tile, 20 us per tile and workgroup).
   const int fe = tid < kSIP ? tid : kSIP - 1, fpx = fe / 3, fc = fe - fpx * 3;
   float pre[kSIR];
+  unsigned premask = 0;                                // rows of `pre` that lie inside the image
   auto fetch = [&](int tile) {
+    unsigned okm = 0;
     const int b = tile / (p.tiles_y * p.tiles_x), rem = tile - b * p.tiles_y * p.tiles_x;
     const int oy0 = (rem / p.tiles_x) * kSTH, ox0 = (rem % p.tiles_x) * kSTW;
     const int ix = 2 * ox0 - 3 + fpx;
@@ -294,8 +296,13 @@ __global__ __launch_bounds__(kThreads) void stem_conv7x7_kernel(StemConvArgs p) 
       const int iy = 2 * oy0 - 3 + r;
       const bool ok = colok && (unsigned)iy < (unsigned)p.H;        // clamped address + select: no branch around the load
       const float v = src[(ok ? iy : 0) * p.sh];
+      // the select HERE makes the compiler wait for all 21 loads in front of the MFMAs (vmcnt(0)) - measured better for this kernel
+      // (102 vs 126 us: three workgroups per CU cover the round trip, and the tile's 16 stores do not queue behind the loads); the
+      // one-kernel frozen stem below, two workgroups per CU and no global stores of the tile, defers it (188 -> 142 us)
       pre[r] = ok ? v : 0.f;
+      okm |= 1u << r;
     }
+    premask = okm;
   };
   if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void stem_conv7x7_kernel(StemConvArgs p) 
     if (tid < kSIP) {
 #pragma unroll
       for (int r = 0; r < kSIR; ++r) {
-        const bf16 v = __float2bfloat16(pre[r]);
+        const bf16 v = __float2bfloat16((premask >> r) & 1u ? pre[r] : 0.f);
         In[r * kSIP + tid] = *reinterpret_cast<const unsigned short*>(&v);
       }
     }
@@ -397,6 +404,7 @@ __global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs 
   const int col = lane & 31, h = lane >> 5;
   const int fe = tid < kSIP ? tid : kSIP - 1, fpx = fe / 3, fc = fe - fpx * 3;
   float pre[kSIR];
+  unsigned premask = 0;
   auto origin = [&](int tile, int& b, int& oy0, int& ox0) {
     b = tile / (p.tiles_y * p.tiles_x);
     const int rem = tile - b * p.tiles_y * p.tiles_x;
@@ -404,6 +412,7 @@ __global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs 
     ox0 = 2 * (rem % p.tiles_x) * kFPW - 1;
   };
   auto fetch = [&](int tile) {
+    unsigned okm = 0;
     int b, oy0, ox0;
     origin(tile, b, oy0, ox0);
     const int ix = 2 * ox0 - 3 + fpx;
@@ -413,9 +422,10 @@ __global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs 
     for (int r = 0; r < kSIR; ++r) {
       const int iy = 2 * oy0 - 3 + r;
       const bool ok = colok && (unsigned)iy < (unsigned)p.H;
-      const float v = src[(ok ? iy : 0) * p.sh];
-      pre[r] = ok ? v : 0.f;
+      pre[r] = src[(ok ? iy : 0) * p.sh];
+      okm |= ok ? (1u << r) : 0u;
     }
+    premask = okm;
   };
   if ((int)blockIdx.x < p.ntiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(kThreads) void stem_conv_pool_kernel(StemFusedArgs 
     if (tid < kSIP) {
 #pragma unroll
       for (int r = 0; r < kSIR; ++r) {
-        const bf16 v = __float2bfloat16(pre[r]);
+        const bf16 v = __float2bfloat16((premask >> r) & 1u ? pre[r] : 0.f);
         In[r * kSIP + tid] = *reinterpret_cast<const unsigned short*>(&v);
       }
     }
