@@ -27,6 +27,11 @@ def poison(pattern, value):
     node = abn._abn_node()
     if "cpp" in WHAT and node is not None and hasattr(node, "poison_workspaces"):
         node.poison_workspaces(int(os.environ.get("DIAG_POISON_BYTE", "255")), int(os.environ.get("DIAG_POISON_TAG", "-1")))                         # 0xFFFFFFFF: a NaN in fp32, in bf16 pairs too
+    if "dummy" in WHAT:                                      # the same kind of work on memory nothing uses
+        global _dummy
+        _dummy = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
+        for _ in range(6):
+            _dummy.fill_(0)
     if "alloc" in WHAT:
         blocks = [torch.full((64 << 20,), value, device=dev) for _ in range(12)]
         small = [torch.full((n,), value, device=dev) for n in (64, 256, 512, 2048, 8192, 65536, 1 << 20, 1 << 22) for _ in range(64)]

@@ -346,7 +346,8 @@ template <int KT, int NT>
 __global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
     const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
     int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
-    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y, int cell_cap) {
+    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y, int cell_cap,
+    float fx_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int CT = KT + NT, NP = CT / 2, KP = KT / 2, kRep = kRepPk;
   // logit rows in LDS are CT + 1 / KT + 1 floats apart: the lanes of a wave read from ~5 cells, sixteen lanes the same address - a
@@ -564,13 +565,17 @@ __global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
     double vd = g_acc[i];
 #pragma unroll
     for (int r = 1; r < kRep; ++r) vd += g_acc[r * gstride + i];
-    const float v = (float)vd;
     const int cell = i / CT, sl = i - cell * CT;
     const int c = sl < KT ? sl : K + sl - KT;
     const bool valid = sl < KT ? sl < K : c < Ctot;
-    if (valid && v != 0.f) {
+    if (valid && vd != 0.0) {
+      // up to four tiles meet in a low-resolution cell: their sums are added as 32-bit FIXED-POINT integers (d_sem's own words,
+      // turned into floats by seg_grad_unfix_kernel) - integer addition has no order, so the gradient is the same bit pattern on
+      // every run.  (fp32 atomics here made one bf16 rounding of the logit gradient flip in about one run in eight: two discrete
+      // training trajectories 5e-4 apart after one update, DESIGN.md "Open" of round 5.)  fx_scale = 2^17 / (largest |gradient| of
+      // one pixel): a tile's 4096 pixels stay below 2^29, four tiles below 2^31; resolution 7.6e-6 of one pixel's largest gradient.
       const int cy = ya + cell / nx, cx = xa + cell % nx;
-      atomicAdd(&d_sem[((size_t)(b * h + cy) * w + cx) * ld_d + c], v);
+      atomicAdd(reinterpret_cast<int*>(d_sem) + ((size_t)(b * h + cy) * w + cx) * ld_d + c, __double2int_rn(vd * (double)fx_scale));
     }
   }
   // block loss sums (fixed order)
@@ -885,6 +890,18 @@ __global__ __launch_bounds__(kThreads) void seg_confusion_kernel(const float* __
   }
 }
 
+// fixed-point gradient words (seg_losses_pk_kernel) -> fp32, in place
+__global__ __launch_bounds__(kThreads) void seg_grad_unfix_kernel(float* __restrict__ d, size_t n, double inv_scale) {
+  const size_t i = ((size_t)blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (i + 4 <= n) {
+    const int4 v = *reinterpret_cast<const int4*>(d + i);
+    *reinterpret_cast<float4*>(d + i) = make_float4((float)((double)v.x * inv_scale), (float)((double)v.y * inv_scale),
+                                                    (float)((double)v.z * inv_scale), (float)((double)v.w * inv_scale));
+  } else {
+    for (size_t j = i; j < n; ++j) d[j] = (float)((double)reinterpret_cast<const int*>(d)[j] * inv_scale);
+  }
+}
+
 __global__ __launch_bounds__(1024) void seg_losses_reduce_kernel(const float* __restrict__ part, int n, float inv_pix,
                                                                 float* __restrict__ out) {
   __shared__ double red[2][16];
@@ -957,7 +974,7 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   // few classes: the packed form with old / new classes in separate slot groups (UCD_SEG_PK=0: the round-3 register form, A/B)
   static const int pk_on = getenv("UCD_SEG_PK") ? atoi(getenv("UCD_SEG_PK")) : 1;
   int pk_kt = 0, pk_nt = 0;
-  if (pk_on && !wide) {
+  if (pk_on && !wide && (reinterpret_cast<uintptr_t>(d_sem) & 15) == 0) {       // (its fixed-point words are converted four at a time)
     const int nnew = Ctot - K;
     if (K <= 16 && nnew <= 8) { pk_kt = 16; pk_nt = 8; }
     else if (K <= 20 && nnew <= 4) { pk_kt = 20; pk_nt = 4; }
@@ -979,10 +996,13 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   const float inv_pix = 1.f / ((float)B * H * W);
   float* part = (float*)workspace;
   // torch computes the up-sampling scale as float(in) / out
+  // fixed-point scale of the packed form's gradient words: one pixel's gradient is at most ce + 2 kd / K in magnitude
+  const float fx_gmax = fabsf(ce_weight * inv_pix) + 2.f * fabsf(kd_weight * inv_pix) / (float)K;
+  const float fx_scale = fx_gmax > 0.f ? 131072.f / fx_gmax : 1.f;
 #define UCD_SEG_PK_LAUNCH(KT_, NT_)                                                                                              \
   seg_losses_pk_kernel<KT_, NT_><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(                                               \
       sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,             \
-      ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y, ny * nx)
+      ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y, ny * nx, fx_scale)
   if (pk_kt == 16) UCD_SEG_PK_LAUNCH(16, 8);
   else if (pk_kt == 20) UCD_SEG_PK_LAUNCH(20, 4);
   else if (pk_kt == 12) UCD_SEG_PK_LAUNCH(12, 12);
@@ -1001,6 +1021,12 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
         ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
   int rc = check_launch(fn);
   if (rc) return rc;
+  if (pk_kt) {
+    const size_t n = (size_t)B * h * w * ld_d;
+    seg_grad_unfix_kernel<<<(unsigned)((n / 4 + kThreads) / kThreads), kThreads, 0, s>>>(d_sem, n, 1.0 / (double)fx_scale);
+    rc = check_launch(fn);
+    if (rc) return rc;
+  }
   seg_losses_reduce_kernel<<<1, 1024, 0, s>>>(part, B * tiles_x * tiles_y, inv_pix, loss_out);
   return check_launch(fn);
 }
