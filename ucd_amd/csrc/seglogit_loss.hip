@@ -618,7 +618,7 @@ __device__ __forceinline__ float4 interp4(const float* base, int o00, int o01, i
 __global__ __launch_bounds__(kThreads) void seg_losses_wide_kernel(
     const float* __restrict__ sem_s, int ld_s, const float* __restrict__ sem_t, int ld_t, const int64_t* __restrict__ labels,
     int H, int W, int h, int w, int Ctot, int K, int ignore_index, float scale_h, float scale_w, float ce_scale,
-    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y) {
+    float kd_scale, float* __restrict__ loss_part, float* __restrict__ d_sem, int ld_d, int tiles_x, int tiles_y, float fx_scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kTY = 4 * kRW;
   constexpr float kL2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f, kNegBig = -1e30f;
@@ -806,10 +806,11 @@ __global__ __launch_bounds__(kThreads) void seg_losses_wide_kernel(
     double vd = g_acc[i];
 #pragma unroll
     for (int r = 1; r < kRepWD; ++r) vd += g_acc[r * gstride + i];
-    const float v = (float)vd;
-    if (v != 0.f) {
+    if (vd != 0.0) {       // fixed-point words, like the packed form: the same bits on every run (fx_scale 0: fp32 atomics)
       const int cy = ya + cell / nx, cx = xa + cell % nx;
-      atomicAdd(&d_sem[((size_t)(b * h + cy) * w + cx) * ld_d + c], v);
+      float* dst = d_sem + ((size_t)(b * h + cy) * w + cx) * ld_d + c;
+      if (fx_scale > 0.f) atomicAdd(reinterpret_cast<int*>(dst), __double2int_rn(vd * (double)fx_scale));
+      else atomicAdd(dst, (float)vd);
     }
   }
   ce_sum = wave_sum(ce_sum);
@@ -999,6 +1000,7 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   // fixed-point scale of the packed form's gradient words: one pixel's gradient is at most ce + 2 kd / K in magnitude
   const float fx_gmax = fabsf(ce_weight * inv_pix) + 2.f * fabsf(kd_weight * inv_pix) / (float)K;
   const float fx_scale = fx_gmax > 0.f ? 131072.f / fx_gmax : 1.f;
+  const bool fx_wide = wide && (reinterpret_cast<uintptr_t>(d_sem) & 15) == 0;
 #define UCD_SEG_PK_LAUNCH(KT_, NT_)                                                                                              \
   seg_losses_pk_kernel<KT_, NT_><<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(                                               \
       sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,             \
@@ -1018,10 +1020,10 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   else
     seg_losses_wide_kernel<<<dim3(tiles_x, tiles_y, B), kThreads, lds, s>>>(
         sem_s, ld_s, sem_t, ld_t, labels, H, W, h, w, Ctot, K, ignore_index, (float)h / (float)H, (float)w / (float)W,
-        ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y);
+        ce_weight * inv_pix, kd_weight * inv_pix, part, d_sem, ld_d, tiles_x, tiles_y, fx_wide ? fx_scale : 0.f);
   int rc = check_launch(fn);
   if (rc) return rc;
-  if (pk_kt) {
+  if (pk_kt || fx_wide) {
     const size_t n = (size_t)B * h * w * ld_d;
     seg_grad_unfix_kernel<<<(unsigned)((n / 4 + kThreads) / kThreads), kThreads, 0, s>>>(d_sem, n, 1.0 / (double)fx_scale);
     rc = check_launch(fn);
