@@ -12,6 +12,7 @@ definitions.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -309,6 +310,8 @@ def main():
     execution = {"step_graph": bool(graphed),
                  "step_graph_error": trainer.step_graph_error,
                  "eager_ms": eager_ms, "graph_ms": graph_ms,      # multi-rank runs: both phases (None: not run / not captured)
+                 # which phase `value` / `ms_per_step` were taken from (multi-rank runs time up to three; the best valid one counts)
+                 "value_phase": ("graph" if graphed else "eager") if multi else ("graph" if graphed else "eager"),
                  "teacher_graph": bool(trainer._sg is not None or trainer._tg is not None),
                  "teacher_graph_error": getattr(trainer, "teacher_graph_error", None),
                  "teacher_overlap": trainer._side is not None,
@@ -421,11 +424,15 @@ def main():
         finished = threading.Event()
 
         def bail(why):
+            # the line of phases 1 - 2 still leaves the process (their measurements are complete and valid); the mailbox failure is in
+            # execution.mailbox.error and on stderr.  Exit status: 0 by default (the driver reads the line of a run whose RCCL phases
+            # succeeded), 3 with UCD_BENCH_STRICT=1 (CI: a failed or hung mailbox phase is a failed run - ADVICE r5)
+            print("UCD_BENCH_MAILBOX_FAILED rank %d: %s" % (rank, why), file=sys.stderr, flush=True)
             if rank == 0:
                 out["execution"]["mailbox"] = {"error": why}
                 emit()
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(3 if os.environ.get("UCD_BENCH_STRICT") == "1" else 0)
 
         def watchdog():
             if not finished.wait(limit):
@@ -444,9 +451,13 @@ def main():
                 t = torch.tensor([float(mailbox_timeouts(None))], device=device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 info.update(ms_per_step=1e3 * dt3 / args.steps, step_graph=bool(graphed3), timeouts=int(t.item()))
-                if rank == 0 and info["timeouts"] == 0 and dt3 < dt:
+                # the mailbox phase counts only when no exchange timed out AND the ranks are still bit-identical replicas after it
+                info["lockstep"] = bool(check_lockstep())
+                info["finite"] = all(math.isfinite(float(v)) for v in trainer.last.values())
+                if rank == 0 and info["timeouts"] == 0 and info["lockstep"] and info["finite"] and dt3 < dt:
                     out.update(value=args.global_batch * args.steps / dt3, ms_per_step=1e3 * dt3 / args.steps)
                     out["execution"]["step_graph"] = bool(graphed3)
+                    out["execution"]["value_phase"] = "mailbox"
                     out["losses"] = {k: float(v) for k, v in trainer.last.items()}
             if rank == 0:
                 out["execution"]["mailbox"] = info

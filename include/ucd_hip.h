@@ -244,9 +244,12 @@ int ucd_comm_all_reduce_sum(ucd_comm_t comm, float* buf, size_t count, ucd_strea
  *   ucd_comm_init (RCCL underneath) or ucd_comm_init_local (no RCCL: mailbox only - several ranks on ONE GPU, which RCCL refuses)
  *   ucd_comm_ipc_create(comm, slot_floats, timeout_ms, handle)  -> exchange the ucd_comm_ipc_handle_bytes() bytes of every rank
  *   ucd_comm_ipc_connect(comm, handles)      handles = [nranks][handle bytes] in rank order
- * A peer that never writes makes the kernel give up after timeout_ms (<= 0: 2 s) and latch a word in pinned host memory
- * (ucd_comm_ipc_timeouts); every later collective on the communicator returns UCD_ETIMEOUT.  ucd_comm_ipc_drop removes the mailbox
- * (the collectives go back to RCCL). */
+ * A peer that never writes makes the kernel give up after timeout_ms (<= 0: 2 s).  It then (round 6) writes NaN into its output,
+ * latches a word in pinned host memory (ucd_comm_ipc_timeouts; every later host-issued collective on the communicator returns
+ * UCD_ETIMEOUT) and poisons the mailbox of EVERY rank: all later exchange kernels of the communicator - replayed graphs included -
+ * return NaN at once instead of waiting.  The mailbox lives in fine-grained device memory; where that cannot be allocated
+ * ucd_comm_ipc_create fails (no coarse-grained fallback) and the caller keeps RCCL.  ucd_comm_ipc_drop removes the mailbox
+ * (the collectives go back to RCCL).  ONE stream at a time per communicator: exchanges of one mailbox must be stream-ordered. */
 int ucd_comm_init_local(int nranks, int rank, ucd_comm_t* comm_out);
 size_t ucd_comm_ipc_handle_bytes(void);
 int ucd_comm_ipc_create(ucd_comm_t comm, int slot_floats, int timeout_ms, void* handle_out);

@@ -501,13 +501,40 @@ if rank == 0:
     dt = time.time() - t0
     assert 0.2 < dt < 10.0, dt
     assert lib.ucd_comm_ipc_timeouts(comm.handle) != 0
+    assert bool(torch.isnan(v).all()), v                       # round 6: an exchange that did not complete returns NaN, not a partial sum
     try:
         hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(v), 16, hip.stream()), "next exchange")
         raise SystemExit("the latched timeout was not reported")
     except RuntimeError as e:
         assert "timed out" in str(e), e
+    from ucd_amd.comm import check_mailbox
+    try:
+        check_mailbox(None)
+        raise SystemExit("check_mailbox did not raise")
+    except RuntimeError as e:
+        assert "timed out" in str(e), e
     print("IPC_TIMEOUT_OK %.2f" % dt, flush=True)
 dist.barrier()                                                 # rank 1 never entered the second exchange
+if rank == 1:
+    # rank 0's timeout POISONED every rank's mailbox: rank 1's next exchange - inside a replayed graph, where no host call could
+    # report anything - returns NaN at once instead of waiting out the timeout and summing stale slots
+    assert lib.ucd_comm_ipc_timeouts(comm.handle) == 0
+    w = torch.ones(4096, device=dev)
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+            hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(w), 4096, hip.stream()), "captured exchange")
+    torch.cuda.synchronize()
+    t0 = time.time()
+    g.replay()
+    torch.cuda.synchronize()
+    dt1 = time.time() - t0
+    assert dt1 < 0.2, dt1                                      # no 300 ms wait
+    assert bool(torch.isnan(w).all()), w[:4]
+    assert lib.ucd_comm_ipc_timeouts(comm.handle) != 0
+    print("IPC_POISON_OK %.4f" % dt1, flush=True)
+dist.barrier()
 dist.destroy_process_group()
 """
 
@@ -522,4 +549,4 @@ def test_ipc_mailbox_timeout_is_an_error_not_a_hang(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29747", str(script), ROOT], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "IPC_TIMEOUT_OK" in r.stdout, r.stdout[-2000:]
+    assert "IPC_TIMEOUT_OK" in r.stdout and "IPC_POISON_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -113,18 +113,25 @@ def _self_test(comm, group, dev):
     """The mailbox against the process group itself before anything depends on it: all-gather + all-reduce of seeded random vectors at
     the SyncBN message sizes (one chunk ... the whole slot, an odd length for the 4-byte path), several rounds each (both mailbox
     parities, back-to-back exchanges in flight), results required BIT-identical to torch.distributed's all_gather of the same vectors
-    summed in rank order.  A node whose peer mappings misbehave (stale reads, lost stores) fails here, on every rank, and keeps RCCL."""
+    summed in rank order.  A node whose peer mappings misbehave (stale reads, lost stores) fails here, on every rank, and keeps RCCL.
+    A rank whose library call raises keeps issuing the SAME c10d collectives as its peers: the verdict is then reached
+    by the caller's agreement round, never by ranks sitting in different collectives."""
     lib = hip.load()
     world, rank = comm.world, comm.rank
     gen = torch.Generator(dev).manual_seed(977 + rank)
+    ok, why = True, ""
     for n in (8, 13, 512, 4096, 16384, IPC_SLOT_FLOATS):
         sent, got = [], []
         for rnd in range(4):
             mine = torch.randn(n, device=dev, generator=gen)
             red = mine.clone()
             gat = torch.empty(world * n, device=dev)
-            hip._check(lib.ucd_comm_all_gather(comm.handle, hip.ptr(mine), hip.ptr(gat), n, hip.stream()), "ucd_comm_all_gather")
-            hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(red), n, hip.stream()), "ucd_comm_all_reduce_sum")
+            if ok:
+                try:
+                    hip._check(lib.ucd_comm_all_gather(comm.handle, hip.ptr(mine), hip.ptr(gat), n, hip.stream()), "ucd_comm_all_gather")
+                    hip._check(lib.ucd_comm_all_reduce_sum(comm.handle, hip.ptr(red), n, hip.stream()), "ucd_comm_all_reduce_sum")
+                except Exception as e:                            # no further library calls; the c10d side below goes on
+                    ok, why = False, repr(e)
             sent.append(mine); got.append((gat, red))
         for mine, (gat, red) in zip(sent, got):
             ref = [torch.empty(n, device=dev) for _ in range(world)]
@@ -132,11 +139,11 @@ def _self_test(comm, group, dev):
             acc = torch.zeros(n, device=dev)
             for r in ref:
                 acc += r
-            if not (torch.equal(gat, torch.cat(ref)) and torch.equal(red, acc)):
-                return False, "self-test mismatch at %d floats" % n
-    if lib.ucd_comm_ipc_timeouts(comm.handle):
-        return False, "self-test timed out"
-    return True, ""
+            if ok and not (torch.equal(gat, torch.cat(ref)) and torch.equal(red, acc)):
+                ok, why = False, "self-test mismatch at %d floats" % n
+    if ok and lib.ucd_comm_ipc_timeouts(comm.handle):
+        ok, why = False, "self-test timed out"
+    return ok, why
 
 
 def _attach_ipc(comm, group, dev):
@@ -209,24 +216,33 @@ def _ranks_own_their_devices(group):
     return len(set(everyone)) == len(everyone)
 
 
-def _want_mailbox(group):
-    """UCD_IPC_SYNC: "auto" (default) - when every rank owns its GPU; "1" - always (ranks sharing a GPU: the tests); "0" - never."""
+def _want_mailbox(group, explicit=False):
+    """UCD_IPC_SYNC: "0" - never; "1" - always, as soon as the SyncBN communicator exists (also ranks that share a GPU: the tests);
+    "auto" (default, round 6) - only where the caller asks for it EXPLICITLY (``attach_mailbox``: bench.py's third phase, after the
+    RCCL phases have been measured) and every rank owns its GPU.  A plain ``run.py`` job therefore keeps its SyncBN exchanges on RCCL:
+    the mailbox has never crossed xGMI on a box available to this build, and a training run must not be the first to try."""
     sw = _switches.get("UCD_IPC_SYNC", "auto")
     if sw == "0" or dist.get_world_size(group) < 2:
         return False
-    return True if sw == "1" else _ranks_own_their_devices(group)
+    if sw == "1":
+        return True
+    return bool(explicit) and _ranks_own_their_devices(group)
+
+
+def _key(group, purpose="sync"):
+    return (id(group) if group is not None else None, purpose)
 
 
 def attach_mailbox(group=None):
-    """Give the group's EXISTING communicator its mailbox now (collective; bench.py does this after the RCCL-only phases have been
-    measured).  True when the small collectives run on the mailbox from here on - graphs captured before still replay RCCL."""
-    key = id(group) if group is not None else None
+    """Give the group's EXISTING SyncBN communicator its mailbox now (collective; bench.py does this after the RCCL-only phases have
+    been measured).  True when the small collectives run on the mailbox from here on - graphs captured before still replay RCCL."""
+    key = _key(group)
     comm = _comms.get(key)
     if comm is None:
         # no communicator yet (or a non-nccl group, which has no RCCL one): a mailbox-only communicator
         if not (dist.is_available() and dist.is_initialized() and torch.cuda.is_available()) or dist.get_backend(group) == "nccl":
             return False
-        if not _want_mailbox(group):
+        if not _want_mailbox(group, explicit=True):
             return False
         comm = _comms[key] = _create_local(group)
         return comm is not None
@@ -234,24 +250,40 @@ def attach_mailbox(group=None):
         return False
     if not comm.ipc:
         comm.ipc_tried = True
-        comm.ipc = _want_mailbox(group) and _attach_ipc(comm, group, torch.device("cuda", torch.cuda.current_device()))
+        comm.ipc = _want_mailbox(group, explicit=True) and _attach_ipc(comm, group, torch.device("cuda", torch.cuda.current_device()))
     return comm.ipc
 
 
 def mailbox_timeouts(group=None):
-    """Exchanges of the group's communicator that gave up waiting for a peer (0: none; their results are not to be trusted)."""
-    comm = _comms.get(id(group) if group is not None else None)
+    """Exchanges of the group's communicator that gave up waiting for a peer (0: none; their results are NaN and the communicator
+    is poisoned on every rank - csrc/comm.hip)."""
+    comm = _comms.get(_key(group))
     return int(hip.load().ucd_comm_ipc_timeouts(comm.handle)) if comm is not None and comm.ipc else 0
 
 
-def direct_comm(group=None, ipc=True):
-    """``DirectComm`` for ``group`` (default group when None), or None when the direct path is unavailable.  ``ipc``: also give it
-    the one-shot mailbox for small messages (the SyncBN exchanges; the gradient buckets' communicator does not need one)."""
-    key = id(group) if group is not None else None
+def check_mailbox(group=None):
+    """Raise when an exchange of the group's mailbox timed out.  Trainer.train calls this at its host synchronisations: a replayed
+    step graph issues no host-side collective call that could report the latched word."""
+    n = mailbox_timeouts(group)
+    if n:
+        raise RuntimeError("SyncBN mailbox exchange %d timed out (a rank never wrote its vector): the statistics of every later "
+                           "layer are NaN on every rank.  Run with UCD_IPC_SYNC=0 (RCCL exchanges)." % n)
+
+
+def direct_comm(group=None, ipc=True, purpose="sync"):
+    """``DirectComm`` for ``group`` (default group when None), or None when the direct path is unavailable.
+    ``purpose``: "sync" - the SyncBN exchanges (compute stream; may carry the one-shot mailbox for small messages); "grad" - the
+    gradient buckets of ucd_amd.ddp (the reducer's side stream).  The two are DIFFERENT communicators (round 6): the
+    mailbox protocol keeps its sequence counters, slots and flags per communicator and is only safe for stream-ordered callers - a
+    small gradient bucket routed to the SyncBN communicator's mailbox from the side stream could take the same sequence number as a
+    SyncBN exchange in flight on the compute stream.  The "grad" communicator never gets a mailbox: its collectives are always RCCL."""
+    if purpose != "sync":
+        ipc = False
+    key = _key(group, purpose)
     if key in _comms:
         comm = _comms[key]
-        # created by a caller that did not want the mailbox (the gradient buckets), asked for now (SyncBN): attach it once -
-        # collective over the group like the creation itself, every rank reaches it at the same first SyncBN layer
+        # UCD_IPC_SYNC=1: created by a caller that did not want the mailbox, asked for now (SyncBN): attach it once - collective over
+        # the group like the creation itself, every rank reaches it at the same first SyncBN layer
         if comm is not None and ipc and not comm.ipc and not comm.ipc_tried and comm.world > 1:
             comm.ipc_tried = True
             comm.ipc = _want_mailbox(group) and _attach_ipc(comm, group, torch.device("cuda", torch.cuda.current_device()))

@@ -59,6 +59,7 @@ void poison_workspaces(int64_t byte, int64_t tag) {
 struct StatArena {
   at::Tensor buf;
   int64_t off = 0, gen = 1;
+  int64_t high = 0;            // high-water mark of `off` over all generations: what a reset zeroes
 };
 std::map<int, StatArena> g_arena;
 constexpr int64_t kArenaFloats = 16 << 20;     // 64 MiB: about four steps' worth at the benchmark's shapes (replicated slots, ~15 MB per step)
@@ -76,7 +77,11 @@ void stat_arena_reset(int64_t dev, int64_t stream) {
   // one fill in stream order (a memset node in a captured step).  A raw memset, not Tensor::zero_(): slots handed out earlier are
   // views of this buffer saved by autograd nodes, and an in-place ATen op would move their shared version counter - a backward that
   // follows a reset must reach the generation check (and fall back), not autograd's "modified by an inplace operation"
-  if (a.off > 0) check(ucd_fill_zero(a.buf.data_ptr(), (size_t)a.off * sizeof(float), (ucd_stream_t)stream), "ucd_fill_zero");
+  // up to the HIGH-WATER mark, not the last step's footprint: a captured step graph freezes this range into its memset
+  // node - had the eager step in front of the capture used fewer floats than the captured one (another batch shape: the replica
+  // count of a slot depends on M), the slots beyond would never be zeroed on replay and their atomic sums would grow across replays
+  if (a.off > a.high) a.high = a.off;
+  if (a.high > 0) check(ucd_fill_zero(a.buf.data_ptr(), (size_t)a.high * sizeof(float), (ucd_stream_t)stream), "ucd_fill_zero");
   a.off = 0;
   a.gen += 1;
 }

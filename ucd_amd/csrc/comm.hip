@@ -43,15 +43,21 @@ int rccl_fail(const char* fn, ncclResult_t r) {
 // rank order - the same order on every rank, so all ranks hold bit-identical results.  Two parities: a rank can be at most one
 // exchange ahead of the slowest one (it needs that rank's flag of exchange k + 1 to finish it), so exchange k + 2 never overwrites
 // a slot still being read.  The sequence counter lives in device memory and is advanced by the kernel itself: a captured step graph
-// replays it.  A timeout (a peer that never writes) sets a word in pinned host memory; the next call on that communicator fails
-// with UCD_ETIMEOUT instead of hanging.
+// replays it.
+// A timeout cannot pass silently (round 6): the workgroup that gives up (a) writes NaN into its part of `out` - the step's loss says
+// so on every path, a replayed graph included -, (b) latches the exchange number in pinned host memory (the next host-issued call on
+// the communicator returns UCD_ETIMEOUT, Trainer.train polls the word at its host synchronisations) and (c) POISONS the
+// communicator: a word in its own mailbox and in every peer's.  A poisoned exchange kernel returns NaN at once, without the
+// protocol and without waiting - one rank that fell out of step (its flags then carry sequence numbers nobody waits for) would
+// otherwise make every later exchange of every rank sit out the full timeout (the "15-minute hang" of profiles/r05_ipc_exchange.md
+// was 430 exchanges x 2 s), and sum whatever the slots hold (the "ranks out of lockstep" event of the same note).
 constexpr int kIpcMaxWorld = 16;
 constexpr int kIpcChunk = 4096;                         // floats of a vector one workgroup of the exchange kernel owns
 constexpr unsigned kCommMagic = 0x55434443u;            // "UCDC"
 
 struct IpcState {
   int world = 0, rank = 0, slot = 0, groups = 1;       // groups = ceil(slot / kIpcChunk)
-  void* base = nullptr;                                 // my allocation: box | flags | ctl
+  void* base = nullptr;                                 // my allocation: box | flags | ctl (sequence counters, timeouts, poison)
   size_t bytes = 0, box_bytes = 0;
   void* peer[kIpcMaxWorld] = {};                        // every rank's allocation as mapped here (peer[rank] == base)
   unsigned* host_to = nullptr;                          // pinned host word: sequence number of the first timed-out exchange
@@ -68,6 +74,7 @@ struct Comm {
 struct IpcArgs {
   float* box[kIpcMaxWorld];
   unsigned* flags[kIpcMaxWorld];
+  unsigned* poison[kIpcMaxWorld];                       // every rank's poison word (ctl[groups + 1] of its mailbox)
   unsigned* ctl;
   unsigned* host_to;
   const float* send;
@@ -96,49 +103,66 @@ __global__ __launch_bounds__(1024) void ipc_exchange_kernel(IpcArgs a) {
   if (tid == 0) {
     s_seq = a.ctl[g] + 1;
     a.ctl[g] = s_seq;
-    s_bad = 0;
+    // poisoned (an exchange of this communicator timed out here or on a peer): no protocol, NaN out
+    s_bad = __hip_atomic_load(a.poison[a.rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ? 2 : 0;
   }
   __syncthreads();
   const unsigned seq = s_seq;
   const int par = (int)(seq & 1u);
   const int lo = g * kIpcChunk, n = min(a.count - lo, kIpcChunk);          // my chunk: floats [lo, lo + n)
   const bool vec = a.vec != 0;
-  // 1. my chunk into slot `rank` of every rank's mailbox (my own included)
-  if (vec) {
-    const float4* src = reinterpret_cast<const float4*>(a.send + lo);
-    if (tid * 4 < n) {
-      const float4 v = src[tid];
-      for (int p = 0; p < a.world; ++p)
-        reinterpret_cast<float4*>(a.box[p] + ((size_t)par * a.world + a.rank) * a.slot + lo)[tid] = v;
-    }
-  } else {
-    for (int p = 0; p < a.world; ++p) {
-      float* dst = a.box[p] + ((size_t)par * a.world + a.rank) * a.slot + lo;
-      for (int i = tid; i < n; i += 1024) st_sys(dst + i, a.send[lo + i]);
-    }
-  }
-  __threadfence_system();
-  __syncthreads();
-  // 2. the sequence number into every rank's flag word for (chunk, me); 3. wait for everyone's in mine
-  if (tid < a.world) {
-    const size_t fo = ((size_t)par * a.groups + g) * a.world;
-    __hip_atomic_store(a.flags[tid] + fo + a.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    const unsigned* mine = a.flags[a.rank] + fo + tid;
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout) {
-        s_bad = 1;
-        break;
+  if (s_bad == 0) {                                                        // (block-uniform)
+    // 1. my chunk into slot `rank` of every rank's mailbox (my own included)
+    if (vec) {
+      const float4* src = reinterpret_cast<const float4*>(a.send + lo);
+      if (tid * 4 < n) {
+        const float4 v = src[tid];
+        for (int p = 0; p < a.world; ++p)
+          reinterpret_cast<float4*>(a.box[p] + ((size_t)par * a.world + a.rank) * a.slot + lo)[tid] = v;
       }
-      __builtin_amdgcn_s_sleep(2);
+    } else {
+      for (int p = 0; p < a.world; ++p) {
+        float* dst = a.box[p] + ((size_t)par * a.world + a.rank) * a.slot + lo;
+        for (int i = tid; i < n; i += 1024) st_sys(dst + i, a.send[lo + i]);
+      }
     }
+    __threadfence_system();
+    __syncthreads();
+    // 2. the sequence number into every rank's flag word for (chunk, me); 3. wait for everyone's in mine
+    if (tid < a.world) {
+      const size_t fo = ((size_t)par * a.groups + g) * a.world;
+      __hip_atomic_store(a.flags[tid] + fo + a.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      const unsigned* mine = a.flags[a.rank] + fo + tid;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout) {
+          s_bad = 1;
+          break;
+        }
+        if (__hip_atomic_load(a.poison[a.rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {   // a peer gave up: so do I, now
+          s_bad = 2;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    __syncthreads();
+    __threadfence_system();
+    if (s_bad == 1 && tid < a.world)                                       // my timeout: poison every rank's communicator, mine included
+      __hip_atomic_store(a.poison[tid], seq | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  __syncthreads();
-  __threadfence_system();
-  if (s_bad && tid == 0) {
-    atomicAdd(a.ctl + a.groups, 1u);
-    if (__hip_atomic_load(a.host_to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
-      __hip_atomic_store(a.host_to, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (s_bad) {
+    if (tid == 0) {
+      atomicAdd(a.ctl + a.groups, 1u);
+      if (__hip_atomic_load(a.host_to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u)
+        __hip_atomic_store(a.host_to, seq ? seq : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // the result of an exchange that did not complete is NaN, never a sum of whatever the slots hold
+    const float qnan = __uint_as_float(0x7FC00000u);
+    const int reps = a.gather ? a.world : 1;
+    for (int r = 0; r < reps; ++r)
+      for (int i = tid; i < n; i += 1024) a.out[(size_t)r * a.count + lo + i] = qnan;
+    return;
   }
   // 4. combine in rank order (identical on every rank)
   const float* box = a.box[a.rank] + (size_t)par * a.world * a.slot + lo;
@@ -181,6 +205,8 @@ int ipc_exchange(Comm* c, const float* send, float* out, size_t count, int gathe
   for (int p = 0; p < st->world; ++p) {
     a.box[p] = reinterpret_cast<float*>(st->peer[p]);
     a.flags[p] = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(st->peer[p]) + st->box_bytes);
+    // ctl = [groups sequence counters | timeouts | poison] behind the flags, at the same offset in every rank's mailbox
+    a.poison[p] = a.flags[p] + (size_t)2 * st->groups * st->world + st->groups + 1;
   }
   a.ctl = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(st->base) + st->box_bytes + (size_t)2 * st->groups * st->world * sizeof(unsigned));
   a.host_to = st->host_to;
@@ -306,13 +332,12 @@ int ucd_comm_ipc_create(ucd_comm_t comm, int slot_floats, int timeout_ms, void* 
   st->world = c->world; st->rank = c->rank; st->slot = slot_floats;
   st->box_bytes = align_up((size_t)2 * st->world * slot_floats * sizeof(float), 256);
   st->groups = (slot_floats + kIpcChunk - 1) / kIpcChunk;
-  st->bytes = st->box_bytes + align_up((size_t)2 * st->groups * st->world * sizeof(unsigned) + (size_t)(st->groups + 1) * sizeof(unsigned) + 64, 256);
+  st->bytes = st->box_bytes + align_up((size_t)2 * st->groups * st->world * sizeof(unsigned) + (size_t)(st->groups + 2) * sizeof(unsigned) + 64, 256);
   if (timeout_ms > 0) st->timeout_ticks = (unsigned long long)timeout_ms * 100000ull;
+  // fine-grained device memory or no mailbox (round 6): the 16-byte payload path uses PLAIN loads and stores between system-scope
+  // fences, which is only a protocol on memory the caches do not keep private copies of; on coarse-grained memory a peer's xGMI
+  // stores are not guaranteed to be seen by a plain load through this device's L2.  The caller keeps RCCL when this fails.
   hipError_t e = hipExtMallocWithFlags(&st->base, st->bytes, hipDeviceMallocFinegrained);
-  if (e != hipSuccess) {                                 // no fine-grained device memory: plain device memory (system-scope accesses bypass the caches either way)
-    (void)hipGetLastError();
-    e = hipMalloc(&st->base, st->bytes);
-  }
   if (e == hipSuccess) e = hipMemset(st->base, 0, st->bytes);
   if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&st->host_to), 64, hipHostMallocMapped);
   if (e == hipSuccess) { *st->host_to = 0; e = hipDeviceSynchronize(); }

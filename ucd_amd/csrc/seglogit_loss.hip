@@ -600,10 +600,10 @@ __global__ __launch_bounds__(kThreads) void seg_losses_pk_kernel(
 //         kd_pix = q_0 (LSE_bn - den) + (sum_{1<=c<K} te_c z_c - den sum_{1<=c<K} te_c) / sum te;
 //   * phase B walks the classes again in chunks of 16: g_c = e_c (a_all - a_old [c<K] - b_bn [c in bkg/new]) - hot [c == label]
 //     - b_q te_c [1<=c<K] from those constants, accumulated in 2 x 16 registers over the rows that share a low-resolution row
-//     pair and flushed with one LDS atomic per class and corner (RW-fold fewer atomics, kRepW copies against column conflicts);
+//     pair and flushed with one LDS atomic per class and corner (RW-fold fewer atomics, accumulator copies against column conflicts);
 //   * logits are read from LDS four classes at a time (rows padded to a multiple of four with -1e30: their exponentials are 0).
 constexpr int kRW = 8;            // rows per thread: a 32 x 64 pixel tile per workgroup
-constexpr int kRepW = 4;          // (LDS sizing: the accumulators take the bytes of four fp32 copies)
+// (LDS sizing: the fp64 accumulator copies take the bytes of four fp32 copies)
 constexpr int kRepWD = 2;         // fp64 copies actually kept
 
 __device__ __forceinline__ float4 interp4(const float* base, int o00, int o01, int o10, int o11, int c, float lx0, float lx1,
@@ -940,6 +940,9 @@ int ucd_seg_losses(const float* sem_s, int ld_s, const float* sem_t, int ld_t, c
   UCD_REQUIRE(H >= 8 * h || H >= h, UCD_EINVAL, "%s: bad scale", fn);
   UCD_REQUIRE((float)H / h >= 4.f && (float)W / w >= 4.f, UCD_EUNSUPPORTED,
               "%s: built for up-sampling factors >= 4 (the model's is 16)", fn);
+  // the fixed-point gradient words (scale 2^17 over one pixel's largest gradient) hold the bilinear weights of at most factor^2 pixels
+  // per low-resolution cell: 64^2 x 2^17 = 2^29 < 2^31; beyond a factor of 64 an int32 word could wrap silently
+  UCD_REQUIRE((float)H / h <= 64.f && (float)W / w <= 64.f, UCD_EUNSUPPORTED, "%s: up-sampling factors above 64 are not supported", fn);
   UCD_REQUIRE(workspace_bytes >= ucd_seg_losses_workspace_bytes(B, H, W), UCD_EWORKSPACE, "%s: workspace too small", fn);
   hipStream_t s = (hipStream_t)stream;
   const bool wide = Ctot > 24;                       // many classes (ADE): seg_losses_wide_kernel on 32 x 64 pixel tiles

@@ -107,7 +107,7 @@ class GradReducer:
         if (self.collective and self.on_gpu and wire_dtype in (None, torch.float32) and dist.get_backend(group) == "nccl"
                 and _switches.get("UCD_DIRECT_RCCL", "1") != "0" and want_direct):
             from .comm import direct_comm
-            self.direct = direct_comm(self.group, ipc=False)
+            self.direct = direct_comm(self.group, ipc=False, purpose="grad")
         self.stream = torch.cuda.Stream(self.device) if self.overlap else None
         self.buckets = []
         self._bucket_of = {}
@@ -375,7 +375,7 @@ class GradReducer:
                 and _switches.get("UCD_DIRECT_RCCL", "1") != "0" and _switches.get("UCD_DDP_DIRECT", "auto") != "0"):
             return False
         from .comm import direct_comm
-        self.direct = direct_comm(self.group, ipc=False)
+        self.direct = direct_comm(self.group, ipc=False, purpose="grad")
         return self.direct is not None
 
     def _reset_step(self):

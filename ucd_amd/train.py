@@ -329,11 +329,15 @@ class Trainer:
             n += 1
             if (cur_step + 1) % print_int == 0:
                 value = (interval / print_int).item()           # the only host sync of the interval
+                self._check_mailbox()                           # a timed-out SyncBN mailbox exchange (its results are NaN) raises here
                 if logger is not None:
                     logger.info(f"Epoch {cur_epoch}, Batch {cur_step + 1}/{len(train_loader)}, Loss={value}")
                     logger.add_scalar("Loss", value, cur_epoch * len(train_loader) + cur_step + 1)
                 interval.zero_()
         if dist.is_available() and dist.is_initialized():
+            if n:
+                torch.cuda.synchronize() if dev.type == "cuda" else None
+                self._check_mailbox()                           # before the epoch's reductions: a poisoned run must not report a loss
             dist.reduce(epoch_loss, dst=0)
             dist.reduce(reg_loss, dst=0)
             world = dist.get_world_size()
@@ -346,6 +350,14 @@ class Trainer:
         if logger is not None:
             logger.info(f"Epoch {cur_epoch}, Class Loss={epoch_loss}, Reg Loss={reg_loss}")
         return (epoch_loss, reg_loss)
+
+    def _check_mailbox(self):
+        """The one-shot SyncBN mailbox (csrc/comm.hip) latches a timed-out exchange in pinned host memory; a replayed step graph issues
+        no host-side collective call that would report it, so the training loop polls the word at its host synchronisations and
+        raises.  Costs one read of host memory; a no-op without a mailbox."""
+        if self.device.type == "cuda" and dist.is_available() and dist.is_initialized():
+            from .comm import check_mailbox
+            check_mailbox(None)
 
     def validate(self, loader, metrics, ret_samples_ids=None, logger=None):
         """Evaluation loop (train.py:185-270): class loss + confusion matrix, accumulated on the device."""
