@@ -116,6 +116,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // vmcnt, so it lands under them.  64 KB of LDS, two workgroups per CU.
 // barriers executed by the epilogue (conv1x1_epilogue.inc): waves that only load run as many
 template <int OUT> constexpr int kEpilogueBarriers = 4 + (OUT >= 2 ? 2 : 0);
+template <int OUT, int HALVES> constexpr int kEpilogueBarriersH = 2 * HALVES + (OUT >= 2 ? 2 : 0);
 
 // Pipeline depth of the DB form (round 4): NST stages of K steps of BK columns, fills NST - 1 steps ahead behind counted vmcnt
 // waits.  <64, 2> is the original double buffer (64 KB, two workgroups per CU); <32, 4> keeps two workgroups per CU (4 x 16 KB
@@ -406,10 +407,17 @@ __global__ __launch_bounds__(kThreads, DB ? (BK * NST >= 256 ? 1 : 2) : ((PRO ||
 // turns on its matrix pipe with no DMA issue between their instructions.  For the grids of 257 .. 640 128-row tiles (every 33 x 33
 // layer at 24 images).  The two 128-row halves run the shared epilogue side by side (conv1x1_epilogue.inc, 256 threads and an LDS
 // region each; the per-tile partial rows stay those of 128-row tiles).
+// BM = 64 (round 6): TWO MFMA waves (one 64 x BN tile as two column halves) and four loader waves, for grids that leave most of the
+// chip without a workgroup (3 images per GPU: 26 row tiles of 128).  What bounds a loader-wave workgroup that has a CU to itself is
+// the CU's LDS-DMA rate (~26 - 40 B/clk: tools/probes/fill_rate.hip, lw_timeline.hip; profiles/r06_lw_probe.txt) - a K step of a
+// 128 x 64 tile stages 24 KB and takes ~750 cycles with 256 cycles of MFMA in it - so the time of such a launch is the bytes ONE
+// workgroup stages, whatever the number of workgroups (3 and 6 images: the same 12.9 / 13.6 us for the 3x3 256 -> 256 layer).
+// 64-row tiles stage 16 KB per step on twice as many CUs.
 template <int BM, int BN, int OUT, bool CONV3, int BK, int NST>
-__global__ __launch_bounds__(BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 2) void conv_lw_kernel(Args p) {
-  static_assert(BM == 128 || BM == 256, "128- or 256-row workgroup tiles");
-  constexpr int NC = BM / 32, NL = BM / 32;             // MFMA waves (2 per 64 rows), loader waves
+__global__ __launch_bounds__(BM == 64 ? 384 : BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 2) void conv_lw_kernel(Args p) {
+  static_assert(BM == 64 || BM == 128 || BM == 256, "64-, 128- or 256-row workgroup tiles");
+  static_assert(BM != 64 || BN == 64, "the 64-row form runs its epilogue on 128 threads: 64-column tiles");
+  constexpr int NC = BM / 32, NL = BM == 64 ? 4 : BM / 32;   // MFMA waves (2 per 64 rows), loader waves
   static_assert(BK == 64 || BK == 32, "K steps of 64 or 32");
   static_assert(NST >= 2 && NST <= 4, "two to four stages");
   constexpr int kStage = (BM + BN) * BK * 2;
@@ -506,7 +514,7 @@ __global__ __launch_bounds__(BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 
       wst = wst + 1 == NST ? 0 : wst + 1;
     }
 #pragma unroll
-    for (int b = 0; b < kEpilogueBarriers<OUT>; ++b) __syncthreads();
+    for (int b = 0; b < kEpilogueBarriersH<OUT, BM == 64 ? 1 : 2>; ++b) __syncthreads();
     return;
   }
 
@@ -549,7 +557,16 @@ __global__ __launch_bounds__(BM * 4, (BM + BN) * BK * 2 * NST > 80 * 1024 ? 1 : 
   }
   // epilogue: each group of four MFMA waves (one 128-row half of the workgroup tile) runs the shared 256-thread epilogue on its
   // own LDS region; the barriers inside are workgroup-wide and the groups execute the same sequence of them
-  {
+  if constexpr (BM == 64) {
+    // one 64-row tile, 128 epilogue threads; per-tile partial rows do not exist for 64-row tiles (the host takes this form only with
+    // the atomic statistics accumulators or without statistics)
+    const int tm = tmw, m0 = m0w, wm = 0;
+#define UCD_EPI_THREADS 128
+#define UCD_EPI_HALVES 1
+#include "conv1x1_epilogue.inc"
+#undef UCD_EPI_THREADS
+#undef UCD_EPI_HALVES
+  } else {
     const int sub = wmw >> 1;
     const int tm = tmw * (BM / 128) + sub, m0 = m0w + sub * 128, wm = wmw & 1;
     constexpr size_t kOutBytes = ((size_t)64 * (BN + 4) * 4 + 1023) / 1024 * 1024;
@@ -1176,6 +1193,17 @@ int launch_db(int pipe, int grid, hipStream_t s, const Args& a, const char* fn) 
     }
     pipe = 0;
   }
+  if (pipe == 7) {                  // round 6: loader waves on 64-row tiles (2 MFMA + 4 loader waves), grids of <= 128 tiles of 128 x 64
+    if constexpr (BN == 64) {
+      Args b = a;
+      b.tiles_m = ceil_div(a.M, 64);
+      const int grid64 = ceil_div(b.tiles_m, 8) * 8 * b.tiles_n;
+      const size_t lds64 = (size_t)(64 + BN) * 64 * 2 * 3;
+      conv_lw_kernel<64, BN, OUT, CONV3, 64, 3><<<grid64, 384, lds64, s>>>(b);
+      return 0;
+    }
+    pipe = 4;
+  }
   if (pipe == 4) {                  // loader waves, three 32 KB stages, one workgroup (8 waves) per CU: every epilogue fits
     const size_t lds = lds_of(64, 3);
     UCD_TRY_LDS((conv_lw_kernel<128, BN, OUT, CONV3, 64, 3>), (int)lds);
@@ -1368,7 +1396,11 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   a.param_off = (int)align_up(lds, 16);
   if (pro) lds = a.param_off + (size_t)3 * d->K * sizeof(float);
   UCD_REQUIRE(lds <= 64 * 1024, UCD_EUNSUPPORTED, "%s: K = %d is too wide for the fused input transform", fn, d->K);
-  const int pipe = db ? pick_pipe(d->M, a.tiles_n, BN, (conv3 ? 9 : 1) * (d->K / 64), d->out_mode) : 0;
+  int pipe = db ? pick_pipe(d->M, a.tiles_n, BN, (conv3 ? 9 : 1) * (d->K / 64), d->out_mode) : 0;
+  // grids of <= UCD_CONV_LW64_TILES (128) tiles of 128 x 64 (3 images per GPU): 64-row tiles on twice as many CUs (conv_lw_kernel,
+  // BM = 64) - statistics / link sums only through the atomic accumulators (64-row tiles have no rows in the per-tile partial buffers)
+  static const int lw64_below = getenv("UCD_CONV_LW64_TILES") ? atoi(getenv("UCD_CONV_LW64_TILES")) : 128;
+  if (db && !pro && pipe == 4 && BN == 64 && (long long)a.tiles_m * a.tiles_n <= lw64_below && (d->out_mode < 2 || a.stat_acc)) pipe = 7;
   if (db && !pro) {
     int rc;
     if (conv3) rc = BN == 128 ? launch_db_out<128, true>(d->out_mode, pipe, grid, s, a, fn) : launch_db_out<64, true>(d->out_mode, pipe, grid, s, a, fn);
