@@ -366,7 +366,7 @@ def main():
         roof["launches_per_step"] = k["launches"] / min(args.steps, 3)
         # HBM traffic of that kernel from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
         # --pmc WRITE_SIZE, separate runs, gfx950 corrections applied by tools/pmc_to_json.py); null if absent
-        for rnd in ("r05", "r04", "r03", "r02"):            # the newest committed collection that has this call
+        for rnd in ("r06", "r05", "r04", "r03", "r02"):     # the newest committed collection that has this call
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_pmc_bench.json")
             if not os.path.exists(pmc):
                 continue
@@ -400,6 +400,12 @@ def main():
                        "contrastive_dtype": trainer.pixcon_precision},
             "losses": last, "execution": execution, "own_kernels": own_kernels,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            # what the per-call table (`kernels`, `roofline.achieved`) was measured on: NOT the timed configuration itself
+            "kernel_table_config": ("instrumented eager pass after the timed region: HIP events around every C-ABI call, Python twins of "
+                                    "the C++ autograd nodes on the deterministic statistics path (per-tile partial rows + reduction "
+                                    "launches), no step graph, no teacher overlap; the timed region ran the C++ nodes with atomic "
+                                    "statistics inside one hipGraph - profiles/*_step_kernel_summary*.txt (rocprofv3 of the same "
+                                    "command) is the authority for its kernels") if kernels is not None else None,
         }
         if first_losses is not None:
             out["first_step_losses"] = first_losses
