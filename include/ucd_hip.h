@@ -607,6 +607,19 @@ int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, in
 int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W,
                            int dilation, int stride, void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes,
                            ucd_stream_t stream);
+/* Round 6: the slab sum of a weight gradient may be DEFERRED into the next weight-gradient launch on the same stream (it rides as
+ * extra workgroups behind that product's own: no launch, no kernel boundary; bit-identical result).  ucd_conv_wgrad_ex = the call
+ * above plus flags: bit 0 = the caller does not read dw / dw32, nor reuses `workspace`, before the next ucd_conv_wgrad* call on
+ * this stream or ucd_conv_wgrad_flush(stream).  Deferral happens only while ucd_conv_wgrad_defer(1) is in force (returns the
+ * previous setting; the gradient-bucket wrapper switches it on for its backward passes and flushes in front of its bucket copies);
+ * ucd_conv_wgrad_flush launches the stream's pending sum, ucd_conv_wgrad_drop forgets it (an aborted backward).  The autograd
+ * nodes of this library replace one launch per convolution of the reference's backward (modules/residual.py:67-73) this way. */
+int ucd_conv_wgrad_ex(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
+                      int stride, void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, int flags,
+                      ucd_stream_t stream);
+int ucd_conv_wgrad_defer(int on);
+int ucd_conv_wgrad_flush(ucd_stream_t stream);
+int ucd_conv_wgrad_drop(ucd_stream_t stream);
 
 /* The weights of the input-gradient convolutions of ALL stride-1 layers in one launch: for table entry e = {src offset,
  * dst offset, Co, Ci, KH*KW} (elements into the flat bf16 buffers; 4-D weights in channels-last memory order

@@ -1663,3 +1663,57 @@ def test_bench_shape_classifier_heads_against_float64():
             "db": _rel(b.grad.float(), b64.grad.float())}
     print("bench-shape classifier heads", {k: round(v, 6) for k, v in errs.items()})
     assert errs["y"] < 4e-3 and errs["dx"] < 4e-3 and errs["dw"] < 4e-3 and errs["db"] < 1e-4, errs
+
+
+def test_deferred_slab_sums_ride_in_the_next_weight_gradient_launch():
+    """C ABI of round 6's deferral (include/ucd_hip.h: ucd_conv_wgrad_ex flags bit 0, ucd_conv_wgrad_defer / _flush / _drop): under
+    deferral a call leaves its gradient unwritten until the next weight-gradient call on the stream (which carries the sum as extra
+    workgroups, every kernel form: 1x1, 9-tap, three-tap) or the flush; results bit-identical to the immediate sums; without
+    ucd_conv_wgrad_defer(1), or without the flag, nothing is deferred; a dropped pending sum is never written."""
+    from ucd_amd import hip
+    g = torch.Generator(DEV).manual_seed(77)
+    cases = [(26136, 1024, 256, None), (26136, 256, 256, (33, 33, 1)), (3267, 256, 256, (33, 33, 1)), (3267, 256, 1024, None),
+             (12675, 128, 128, (65, 65, 1))]
+    ops = []
+    for M, N, K, sp in cases:
+        dz = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+        x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        ref = torch.empty(N, (9 if sp else 1) * K, device=DEV, dtype=torch.bfloat16)
+        hip.conv_wgrad(dz, x, dw=ref, conv3=sp)
+        ops.append((dz, x, sp, ref))
+    torch.cuda.synchronize()
+    assert hip.wgrad_defer(True) == 0
+    try:
+        outs = [torch.full_like(ref, float("nan")) for _, _, _, ref in ops]
+        for i, (dz, x, sp, ref) in enumerate(ops):
+            hip.conv_wgrad(dz, x, dw=outs[i], conv3=sp, defer=True)
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(outs[i]).all()), i                    # this call's sum is pending ...
+            if i:
+                assert torch.equal(outs[i - 1], ops[i - 1][3]), i         # ... the previous one's rode in this launch
+        hip.wgrad_flush()
+        torch.cuda.synchronize()
+        assert torch.equal(outs[-1], ops[-1][3])
+        hip.wgrad_flush()                                                 # nothing pending: a no-op
+        # without the flag: summed at once, and a pending sum of an earlier call still rides along
+        a, b = torch.full_like(ops[0][3], float("nan")), torch.full_like(ops[1][3], float("nan"))
+        hip.conv_wgrad(ops[0][0], ops[0][1], dw=a, conv3=ops[0][2], defer=True)
+        hip.conv_wgrad(ops[1][0], ops[1][1], dw=b, conv3=ops[1][2])
+        torch.cuda.synchronize()
+        assert torch.equal(a, ops[0][3]) and torch.equal(b, ops[1][3])
+        # a dropped pending sum is never written
+        c = torch.full_like(ops[0][3], float("nan"))
+        hip.conv_wgrad(ops[0][0], ops[0][1], dw=c, conv3=ops[0][2], defer=True)
+        hip.wgrad_drop()
+        hip.wgrad_flush()
+        hip.conv_wgrad(ops[1][0], ops[1][1], dw=b, conv3=ops[1][2])
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(c).all())
+    finally:
+        hip.wgrad_drop()
+        assert hip.wgrad_defer(False) == 1
+    # deferral off: the flag alone defers nothing
+    d = torch.full_like(ops[0][3], float("nan"))
+    hip.conv_wgrad(ops[0][0], ops[0][1], dw=d, conv3=ops[0][2], defer=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d, ops[0][3])

@@ -739,3 +739,27 @@ def test_step_graph_is_dropped_and_rebuilt_when_the_optimiser_state_moves():
         # 12 steps: the library's weight-gradient kernel of the stem is not bit-reproducible between two runs (1.7e-4 on its weight
         # here); a graph that kept stepping the OLD momentum buffers would be off by > 1e-2 after six more steps at momentum 0.9
         assert d < 1e-3, (n, d)
+
+
+@pytest.mark.usefixtures("deterministic_stats")
+def test_deferred_weight_gradient_sums_change_no_bit_of_the_step():
+    """Round 6: the slab sum of every weight gradient rides in the NEXT weight-gradient launch (csrc/wgrad.hip, SumArgs;
+    ``UCD_WGRAD_DEFER``, ucd_amd/ddp.py flushes in front of the bucket copies) instead of a launch of its own (109 per step).  Same
+    sums in the same order: four scheduled iterations with and without the deferral end in bit-identical losses and parameters -
+    eager and replayed from the step graph."""
+    from ucd_amd import switches
+    runs = {}
+    for defer in ("0", "1"):
+        switches.set("UCD_WGRAD_DEFER", defer)
+        try:
+            for sg in ("0", "1"):
+                runs[(defer, sg)] = _scheduled_steps(sg, steps=5 if sg == "1" else 3)
+        finally:
+            switches.unset("UCD_WGRAD_DEFER")
+    for sg in ("0", "1"):
+        (la, pa, ga, _, ea), (lb, pb, gb, _, eb) = runs[("0", sg)], runs[("1", sg)]
+        assert ea is None and eb is None, (ea, eb)
+        assert ga == gb and (sg == "0" or ga >= 1), (ga, gb)
+        assert np.array_equal(la, lb), (sg, la, lb)
+        for n in pa:
+            assert torch.equal(pa[n], pb[n]), (sg, n)

@@ -141,15 +141,29 @@ bool own_wgrad_ok(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w
 }
 
 // stride > 1 (the first block of a stage: conv2 3x3 / proj_conv 1x1 with stride 2): dz is the smaller output map
+// Slab workspace of a weight-gradient call.  The calls of the autograd nodes allow the library to DEFER their slab sum into the next
+// weight-gradient launch of the stream (ucd_conv_wgrad_ex, flags bit 0: the gradient goes to AccumulateGrad and is first read by the
+// bucket copies, in front of which ucd_amd/ddp.py flushes) - so a call's slabs must outlive the NEXT call: two scratch buffers, taken
+// in turn.
+void* wgrad_workspace(const at::Tensor& like, size_t bytes, int64_t stream) {
+  static int turn = 0;
+  int tag;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    tag = 2 + (turn ^= 1);
+  }
+  return workspace(like, bytes, stream, tag);
+}
+
 at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w4, int64_t dilation, int64_t stream,
                      int64_t stride = 1) {
   const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0), M = B * dz.size(2) * dz.size(3);
   const int taps = dilation > 0 ? 9 : 1;
   at::Tensor dw = at::empty({N, taps == 9 ? 3 : 1, taps == 9 ? 3 : 1, K}, x.options().memory_format(c10::nullopt));
   const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)N, (int)K, taps);
-  check(ucd_conv_wgrad_strided(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
-                               (int)(dilation > 0 ? dilation : 1), (int)stride, dw.data_ptr(), nullptr, 0,
-                               workspace(x, wsb, stream, 2), wsb, (ucd_stream_t)stream),
+  check(ucd_conv_wgrad_ex(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
+                          (int)(dilation > 0 ? dilation : 1), (int)stride, dw.data_ptr(), nullptr, 0,
+                          wgrad_workspace(x, wsb, stream), wsb, 1, (ucd_stream_t)stream),
         "ucd_conv_wgrad");
   return dw.permute({0, 3, 1, 2});      // [N, K, kh, kw] with channels-last strides: the weight's own memory order
 }
@@ -263,8 +277,8 @@ at::Tensor own_wgrad_rows(const at::Tensor& dy, const at::Tensor& rows, int64_t 
   const int64_t M = rows.size(0), Ci = rows.size(1), Co = dy.size(1);
   at::Tensor dw = at::empty({Co, Ci}, rows.options());
   const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)Co, (int)Ci, 1);
-  check(ucd_conv_wgrad(dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, (int)M, (int)Co, (int)Ci, 1, 0, 0, 1, dw.data_ptr(), nullptr, 0,
-                       workspace(rows, wsb, stream, 2), wsb, (ucd_stream_t)stream),
+  check(ucd_conv_wgrad_ex(dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, (int)M, (int)Co, (int)Ci, 1, 0, 0, 1, 1, dw.data_ptr(), nullptr, 0,
+                          wgrad_workspace(rows, wsb, stream), wsb, 1, (ucd_stream_t)stream),
         "ucd_conv_wgrad");
   return dw;
 }

@@ -23,6 +23,8 @@
 // three taps from one dZ tile and one X tile of 64 + 2 d rows, 6 MFMA + 2 loader waves; this 9-tap form keeps the rest.
 // Workgroup -> work: all tiles and taps of one row chunk sit on one XCD (ids congruent mod 8 share an L2), so a chunk's rows
 // of dZ and X leave HBM once and are re-read by its tiles from that L2.
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -121,14 +123,98 @@ __device__ __forceinline__ void compute_stage(f32x16 (&acc)[TNW][TKW], const uns
   mma_group<TNW, TKW, 0>(acc, by, bx);
 }
 
+// ---- slab sums, deferred (round 6) -----------------------------------------------------------------------------------------------
+// dW = sum over the chunks' fp32 slabs in a fixed order (deterministic).  As a launch of its own this is a latency-bound kernel of
+// 5 - 7 us behind every weight-gradient product (109 per step at 24 images: 0.65 ms; 106 at 3 images: 0.54 ms + their boundaries).
+// Deferred: the sum of layer L rides in the launch of the NEXT weight-gradient product (layer L - 1 of the backward) as extra
+// workgroups behind that kernel's own - no dependency between the two, so it hides under the product; the last layer's sum is
+// launched alone by ucd_conv_wgrad_flush.  Same arithmetic in the same order: bit-identical gradients.  The caller promises that
+// the gradient tensor is not read before the next weight-gradient call or the flush (the autograd nodes: their weight gradients go
+// to AccumulateGrad and are first read by the bucket copies - ucd_amd/ddp.py flushes in front of those).
+struct SumArgs {
+  const float* partial; int chunks; unsigned long long total;
+  bf16* dW; float* dW32; int accumulate;
+  int cl;        // chunk lanes: 1, 4 or 16 (wgrad_sum_body<CL>)
+  int blocks;    // workgroups of the sum (0: nothing pending)
+};
+
+// A thread owns 8 consecutive outputs of one chunk lane; CL lanes (1, 4 or 16: small outputs cut into many chunks - 64 x 256 weights
+// over 250 chunks would otherwise be eight workgroups walking 250 slabs one after the other) take chunks c = lane, lane + CL, ...
+// and are combined through LDS in lane order.  256 threads (further threads of a wider workgroup leave at once); ``red`` = at
+// least CL * (256 / CL) * 9 floats of LDS.
+template <int CL>
+__device__ __forceinline__ void wgrad_sum_body(const SumArgs& q, int bid, float* red_) {
+  if (threadIdx.x >= kThreads) return;
+  constexpr int OG = kThreads / CL;                      // 8-output groups per workgroup
+  float (*red)[OG][9] = reinterpret_cast<float (*)[OG][9]>(red_);
+  const float* __restrict__ partial = q.partial;
+  const size_t total = (size_t)q.total;
+  const int chunks = q.chunks;
+  const int og = threadIdx.x % OG, cl = threadIdx.x / OG;
+  const size_t i = ((size_t)bid * OG + og) * 8;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (i < total) {
+    int c = cl;
+    for (; c + CL < chunks; c += 2 * CL) {               // two slabs (four loads) in flight
+      const float4 a0 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i);
+      const float4 a1 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(partial + (size_t)(c + CL) * total + i);
+      const float4 b1 = *reinterpret_cast<const float4*>(partial + (size_t)(c + CL) * total + i + 4);
+      s[0] += a0.x; s[1] += a0.y; s[2] += a0.z; s[3] += a0.w; s[4] += a1.x; s[5] += a1.y; s[6] += a1.z; s[7] += a1.w;
+      s[0] += b0.x; s[1] += b0.y; s[2] += b0.z; s[3] += b0.w; s[4] += b1.x; s[5] += b1.y; s[6] += b1.z; s[7] += b1.w;
+    }
+    if (c < chunks) {
+      const float4 a0 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i);
+      const float4 a1 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i + 4);
+      s[0] += a0.x; s[1] += a0.y; s[2] += a0.z; s[3] += a0.w; s[4] += a1.x; s[5] += a1.y; s[6] += a1.z; s[7] += a1.w;
+    }
+  }
+  if (CL > 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[cl][og][e] = s[e];
+    // the 256 threads of the sum only (a wider workgroup's other waves have left): a named-free barrier over live waves
+    __syncthreads();
+    if (cl != 0) return;
+#pragma unroll
+    for (int l = 1; l < CL; ++l)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += red[l][og][e];
+  }
+  if (i >= total) return;
+  if (q.dW) {
+    Vec<bf16> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.set(e, s[e]);
+    o.store(q.dW + i);
+  }
+  if (q.dW32) {
+    float4* d = reinterpret_cast<float4*>(q.dW32 + i);
+    if (q.accumulate) {
+      const float4 o0 = d[0], o1 = d[1];
+      s[0] += o0.x; s[1] += o0.y; s[2] += o0.z; s[3] += o0.w; s[4] += o1.x; s[5] += o1.y; s[6] += o1.z; s[7] += o1.w;
+    }
+    d[0] = make_float4(s[0], s[1], s[2], s[3]);
+    d[1] = make_float4(s[4], s[5], s[6], s[7]);
+  }
+}
+__device__ __forceinline__ void wgrad_sum_dispatch(const SumArgs& q, int bid, float* red) {
+  if (q.cl == 16) wgrad_sum_body<16>(q, bid, red);
+  else if (q.cl == 4) wgrad_sum_body<4>(q, bid, red);
+  else wgrad_sum_body<1>(q, bid, red);
+}
+
 template <int BNO, int BKO, bool T9, bool STR = false>
-__global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p) {
+__global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WArgs p, SumArgs pend, int main_blocks) {
   constexpr int SY = BNO / 8, SX = BKO / 8;                 // 16-byte chunks per LDS row
   constexpr int YB = kRows * BNO * 2, XB = kRows * BKO * 2;  // bytes of the two tiles of a stage
   constexpr int kStage = YB + XB;
   constexpr int CY = YB / 1024 / 4, CX = XB / 1024 / 4;      // LDS-DMA instructions per wave and tile
   constexpr int TNW = BNO / 64, TKW = BKO / 64;              // 32-wide sub-tiles per wave
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  if ((int)blockIdx.x >= main_blocks) {                      // the previous product's slab sum rides behind this launch's own workgroups
+    wgrad_sum_dispatch(pend, (int)blockIdx.x - main_blocks, reinterpret_cast<float*>(smem));
+    return;
+  }
 
   // ---- which (chunk, tile, tap) ---------------------------------------------------------------------------------------
   const int tiles_kg = p.tiles_k / p.ksplit;                 // k tiles of one group
@@ -369,8 +455,12 @@ __device__ __forceinline__ void w3_mma(f32x16 (&acc)[2][4], G3& gs) {
 }
 
 template <int NX>   // X-tile LDS rows = 32 NX (96 or 128 >= 64 + 2 d); a loader wave issues 2 NX X pieces + 4 dZ pieces per step
-__global__ __launch_bounds__(k3Threads, 1) void wgrad3_kernel(WArgs p) {
+__global__ __launch_bounds__(k3Threads, 1) void wgrad3_kernel(WArgs p, SumArgs pend, int main_blocks) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  if ((int)blockIdx.x >= main_blocks) {
+    wgrad_sum_dispatch(pend, (int)blockIdx.x - main_blocks, reinterpret_cast<float*>(smem));
+    return;
+  }
   constexpr int kStage = k3_stage_bytes(NX);
   constexpr int NXL = 4 * NX;                            // X pieces per loader wave and step
   constexpr int NFILL = 8 + NXL;                         // LDS-DMA instructions of one fill, per loader wave
@@ -560,60 +650,10 @@ __global__ __launch_bounds__(k3Threads, 1) void wgrad3_kernel(WArgs p) {
       }
 }
 
-// dW (bf16) and / or dW32 (fp32, += when accumulate) = sum over the chunks' slabs in a fixed order.  A thread owns 8
-// consecutive outputs of one chunk lane; CL lanes (1, 4 or 16: small outputs cut into many chunks - 64 x 256 weights over 250
-// chunks would otherwise be eight workgroups walking 250 slabs one after the other) take chunks c = lane, lane + CL, ... and are
-// combined through LDS in lane order.
-template <int CL>
-__global__ __launch_bounds__(kThreads) void wgrad_sum_kernel(const float* __restrict__ partial, int chunks, size_t total,
-                                                            bf16* __restrict__ dW, float* __restrict__ dW32, int accumulate) {
-  constexpr int OG = kThreads / CL;                      // 8-output groups per workgroup
-  __shared__ float red[CL > 1 ? CL : 1][OG][9];
-  const int og = threadIdx.x % OG, cl = threadIdx.x / OG;
-  const size_t i = ((size_t)blockIdx.x * OG + og) * 8;
-  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (i < total) {
-    int c = cl;
-    for (; c + CL < chunks; c += 2 * CL) {               // two slabs (four loads) in flight
-      const float4 a0 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i);
-      const float4 a1 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(partial + (size_t)(c + CL) * total + i);
-      const float4 b1 = *reinterpret_cast<const float4*>(partial + (size_t)(c + CL) * total + i + 4);
-      s[0] += a0.x; s[1] += a0.y; s[2] += a0.z; s[3] += a0.w; s[4] += a1.x; s[5] += a1.y; s[6] += a1.z; s[7] += a1.w;
-      s[0] += b0.x; s[1] += b0.y; s[2] += b0.z; s[3] += b0.w; s[4] += b1.x; s[5] += b1.y; s[6] += b1.z; s[7] += b1.w;
-    }
-    if (c < chunks) {
-      const float4 a0 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i);
-      const float4 a1 = *reinterpret_cast<const float4*>(partial + (size_t)c * total + i + 4);
-      s[0] += a0.x; s[1] += a0.y; s[2] += a0.z; s[3] += a0.w; s[4] += a1.x; s[5] += a1.y; s[6] += a1.z; s[7] += a1.w;
-    }
-  }
-  if (CL > 1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) red[cl][og][e] = s[e];
-    __syncthreads();
-    if (cl != 0) return;
-#pragma unroll
-    for (int l = 1; l < CL; ++l)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s[e] += red[l][og][e];
-  }
-  if (i >= total) return;
-  if (dW) {
-    Vec<bf16> o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o.set(e, s[e]);
-    o.store(dW + i);
-  }
-  if (dW32) {
-    float4* d = reinterpret_cast<float4*>(dW32 + i);
-    if (accumulate) {
-      const float4 o0 = d[0], o1 = d[1];
-      s[0] += o0.x; s[1] += o0.y; s[2] += o0.z; s[3] += o0.w; s[4] += o1.x; s[5] += o1.y; s[6] += o1.z; s[7] += o1.w;
-    }
-    d[0] = make_float4(s[0], s[1], s[2], s[3]);
-    d[1] = make_float4(s[4], s[5], s[6], s[7]);
-  }
+// the slab sum as a launch of its own (not deferred, or flushed): wgrad_sum_body above
+__global__ __launch_bounds__(kThreads) void wgrad_sum_kernel(SumArgs q) {
+  __shared__ float red[kThreads * 9];
+  wgrad_sum_dispatch(q, (int)blockIdx.x, red);
 }
 
 struct Plan { int bno, bko, tiles_n, tiles_k, chunks, rows, ksplit; };
@@ -689,6 +729,31 @@ bool wgrad3_enabled() {
   return !(e && e[0] == '0');
 }
 
+// ---- deferred slab sums: host state (see SumArgs above) ---------------------------------------------------------------------------
+// One pending sum per stream; ucd_conv_wgrad_ex(flags & 1) under ucd_conv_wgrad_defer(1) leaves its sum pending and carries the
+// previous one of that stream in its launch.
+std::mutex g_pend_mu;
+std::map<hipStream_t, SumArgs> g_pend;
+int g_defer = 0;
+
+SumArgs make_sum(const void* workspace, int chunks, size_t total, void* dw, float* dw32, int accumulate32) {
+  SumArgs q;
+  q.partial = (const float*)workspace; q.chunks = chunks; q.total = total; q.dW = (bf16*)dw; q.dW32 = dw32; q.accumulate = accumulate32;
+  // chunk lanes of the sum: enough workgroups to fill the chip when the output is small and the chunks many
+  const size_t groups8 = total / 8;
+  if (chunks >= 64 && groups8 <= (size_t)16 * 1024) { q.cl = 16; q.blocks = (int)((groups8 + 15) / 16); }
+  else if (chunks >= 16 && groups8 <= (size_t)64 * 1024) { q.cl = 4; q.blocks = (int)((groups8 + 63) / 64); }
+  else { q.cl = 1; q.blocks = (int)((groups8 + kThreads - 1) / kThreads); }
+  return q;
+}
+SumArgs take_pending(hipStream_t s) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  SumArgs q{};
+  auto it = g_pend.find(s);
+  if (it != g_pend.end()) { q = it->second; g_pend.erase(it); }
+  return q;
+}
+
 int plan_target(int N, int K, int taps) {
   const int per_chunk = (N / (N % 128 == 0 ? 128 : 64)) * (K / (K % 128 == 0 ? 128 : 64)) * taps;
   return wgrad_target(taps, per_chunk);
@@ -721,6 +786,33 @@ int ucd_conv_wgrad(const void* dz, int ld_dz, const void* x, int ld_x, int M, in
 int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W,
                            int dilation, int stride, void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes,
                            ucd_stream_t stream) {
+  return ucd_conv_wgrad_ex(dz, ld_dz, x, ld_x, M, N, K, taps, H, W, dilation, stride, dw, dw32, accumulate32, workspace, workspace_bytes, 0,
+                           stream);
+}
+
+int ucd_conv_wgrad_defer(int on) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  const int was = g_defer;
+  g_defer = on ? 1 : 0;
+  return was;
+}
+
+int ucd_conv_wgrad_flush(ucd_stream_t stream) {
+  static const char* fn = "ucd_conv_wgrad_flush";
+  const SumArgs q = take_pending((hipStream_t)stream);
+  if (q.blocks <= 0) return 0;
+  wgrad_sum_kernel<<<q.blocks, kThreads, 0, (hipStream_t)stream>>>(q);
+  return check_launch(fn);
+}
+
+int ucd_conv_wgrad_drop(ucd_stream_t stream) {
+  (void)take_pending((hipStream_t)stream);
+  return 0;
+}
+
+int ucd_conv_wgrad_ex(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
+                      int stride, void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, int flags,
+                      ucd_stream_t stream) {
   static const char* fn = "ucd_conv_wgrad";
   UCD_REQUIRE(dz && x && (dw || dw32) && workspace, UCD_EINVAL, "%s: NULL argument", fn);
   UCD_REQUIRE(M > 0 && N > 0 && K > 0 && N % 64 == 0 && K % 64 == 0, UCD_EUNSUPPORTED, "%s: N (%d) and K (%d) must be multiples of 64", fn, N, K);
@@ -762,14 +854,18 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
   const int grid = ceil_div(groups, 8) * 8 * per_group;
   const size_t lds = (size_t)2 * kRows * (pl.bno + pl.bko) * 2;
   hipStream_t s = (hipStream_t)stream;
+  // the pending slab sum of this stream (a deferred earlier call) rides behind this launch's own workgroups; this call's own sum
+  // is left pending when the caller allows it (flags & 1) and deferral is on, else launched right behind the product
+  const SumArgs pend = take_pending(s);
+  const int extra = pend.blocks > 0 ? pend.blocks : 0;
 #define UCD_WG_LAUNCH(BN_, BK_)                                                             \
   {                                                                                         \
     if (taps == 9) {                                                                        \
       UCD_TRY_LDS((wgrad_kernel<BN_, BK_, true>), (int)lds);                                \
-      wgrad_kernel<BN_, BK_, true><<<grid, kThreads, lds, s>>>(a);                          \
+      wgrad_kernel<BN_, BK_, true><<<grid + extra, kThreads, lds, s>>>(a, pend, grid);      \
     } else {                                                                                \
       UCD_TRY_LDS((wgrad_kernel<BN_, BK_, false>), (int)lds);                               \
-      wgrad_kernel<BN_, BK_, false><<<grid, kThreads, lds, s>>>(a);                         \
+      wgrad_kernel<BN_, BK_, false><<<grid + extra, kThreads, lds, s>>>(a, pend, grid);     \
     }                                                                                       \
   }
   if (three) {
@@ -777,18 +873,18 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
     const int grid3 = ceil_div(p3.chunks * p3.ksplit, 8) * 8 * p3.tiles_n * (p3.tiles_k / p3.ksplit) * 3;
     if (kRows + 2 * dilation <= 96) {
       UCD_TRY_LDS((wgrad3_kernel<3>), k3Stages * k3_stage_bytes(3));
-      wgrad3_kernel<3><<<grid3, k3Threads, k3Stages * k3_stage_bytes(3), s>>>(a);
+      wgrad3_kernel<3><<<grid3 + extra, k3Threads, k3Stages * k3_stage_bytes(3), s>>>(a, pend, grid3);
     } else {
       UCD_TRY_LDS((wgrad3_kernel<4>), k3Stages * k3_stage_bytes(4));
-      wgrad3_kernel<4><<<grid3, k3Threads, k3Stages * k3_stage_bytes(4), s>>>(a);
+      wgrad3_kernel<4><<<grid3 + extra, k3Threads, k3Stages * k3_stage_bytes(4), s>>>(a, pend, grid3);
     }
   } else if (str) {
     if (taps == 9) {
       UCD_TRY_LDS((wgrad_kernel<128, 128, true, true>), (int)lds);
-      wgrad_kernel<128, 128, true, true><<<grid, kThreads, lds, s>>>(a);
+      wgrad_kernel<128, 128, true, true><<<grid + extra, kThreads, lds, s>>>(a, pend, grid);
     } else {
       UCD_TRY_LDS((wgrad_kernel<128, 128, false, true>), (int)lds);
-      wgrad_kernel<128, 128, false, true><<<grid, kThreads, lds, s>>>(a);
+      wgrad_kernel<128, 128, false, true><<<grid + extra, kThreads, lds, s>>>(a, pend, grid);
     }
   } else if (pl.bno == 128 && pl.bko == 128) UCD_WG_LAUNCH(128, 128)
   else if (pl.bno == 128) UCD_WG_LAUNCH(128, 64)
@@ -797,14 +893,15 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
 #undef UCD_WG_LAUNCH
   int rc = check_launch(fn);
   if (rc) return rc;
-  // chunk lanes of the sum: enough workgroups to fill the chip when the output is small and the chunks many
-  const size_t groups8 = total / 8;
-  if (pl.chunks >= 64 && groups8 <= (size_t)16 * 1024)
-    wgrad_sum_kernel<16><<<(unsigned)((groups8 + 15) / 16), kThreads, 0, s>>>((const float*)workspace, pl.chunks, total, (bf16*)dw, dw32, accumulate32);
-  else if (pl.chunks >= 16 && groups8 <= (size_t)64 * 1024)
-    wgrad_sum_kernel<4><<<(unsigned)((groups8 + 63) / 64), kThreads, 0, s>>>((const float*)workspace, pl.chunks, total, (bf16*)dw, dw32, accumulate32);
-  else
-    wgrad_sum_kernel<1><<<(unsigned)((groups8 + kThreads - 1) / kThreads), kThreads, 0, s>>>((const float*)workspace, pl.chunks, total, (bf16*)dw, dw32, accumulate32);
+  const SumArgs mine = make_sum(workspace, pl.chunks, total, dw, dw32, accumulate32);
+  bool defer;
+  {
+    std::lock_guard<std::mutex> lock(g_pend_mu);
+    defer = g_defer && (flags & 1);
+    if (defer) g_pend[s] = mine;
+  }
+  if (defer) return 0;
+  wgrad_sum_kernel<<<mine.blocks, kThreads, 0, s>>>(mine);
   return check_launch(fn);
 }
 

@@ -204,8 +204,25 @@ class GradReducer:
             dropped = self._direct_modules[0].bias.grad is None
         if not self._cb_queued:
             self.drop_pending_copies()                          # a new step begins: nothing queued by an aborted backward survives
+            self._wgrad_defer(True)
         if dropped:
             self.zero_grad()
+
+    def _wgrad_defer(self, on):
+        """Deferred slab sums of the weight gradients (csrc/wgrad.hip, round 6): on for the backward pass of a step of this wrapper -
+        the nodes' weight gradients are first READ by the bucket copies, and ``_wgrad_flush`` runs in front of those - off again in
+        ``finish`` (a bare ``backward()`` outside the wrapper sums at once).  ``UCD_WGRAD_DEFER=0`` keeps the separate launches."""
+        if not self.on_gpu or _switches.get("UCD_WGRAD_DEFER", "1") == "0":
+            return
+        from . import hip
+        if on:
+            hip.wgrad_drop()                                    # of a backward that never finished
+        hip.wgrad_defer(on)
+
+    def _wgrad_flush(self):
+        if self.on_gpu and _switches.get("UCD_WGRAD_DEFER", "1") != "0":
+            from . import hip
+            hip.wgrad_flush()
 
     def _on_grad(self, p):
         b = self._bucket_of[p]
@@ -252,6 +269,7 @@ class GradReducer:
                     dst.append(view32)
                     src.append(holder.grad)
             if src and (self.collective or _switches.get("UCD_DDP_LATE_COPY", "1") == "0"):
+                self._wgrad_flush()                              # the last weight gradient's slab sum may still be pending
                 torch._foreach_copy_(dst, src)                   # before the bucket's reduction starts
             elif src:
                 # a single process reduces nothing: the widening copies of ALL buckets go out as one multi-tensor launch at the end of
@@ -309,6 +327,8 @@ class GradReducer:
             return
         self._finished = True
         self._dirty = True
+        self._wgrad_flush()                                     # every weight gradient is final from here on
+        self._wgrad_defer(False)
         for b in self.buckets:                                  # parameters that received no gradient
             if not b.done:
                 self._complete(b)

@@ -123,6 +123,10 @@ SIGNATURES = {
     "ucd_stem_conv7x7": (_i, [_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p, _p]),
     "ucd_stem_conv_pool": (_i, [_p, C.c_longlong, C.c_longlong, C.c_longlong, C.c_longlong, _i, _i, _i, _p, _p, _p, _p, _i, _f, _p, _p]),
     "ucd_conv_wgrad_strided": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
+    "ucd_conv_wgrad_ex": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _i, _p]),
+    "ucd_conv_wgrad_defer": (_i, [_i]),
+    "ucd_conv_wgrad_flush": (_i, [_p]),
+    "ucd_conv_wgrad_drop": (_i, [_p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
     "ucd_flip_weights_batched": (_i, [_p, _p, _p, _i, _p, _p]),
     "ucd_flip_weights_batched64": (_i, [_p, _p, _p, _i, _p, _p]),
@@ -673,7 +677,25 @@ def stem_pool_backward(z, dpool, idx, mean, invstd, scale, beta, weight, sums, c
                                           int(phase), stream()), "ucd_stem_pool_backward")
 
 
-def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, strided=None):
+def wgrad_defer(on):
+    """Switch the deferral of weight-gradient slab sums (``ucd_conv_wgrad_defer``); returns the previous setting."""
+    return int(load().ucd_conv_wgrad_defer(1 if on else 0))
+
+
+def wgrad_flush():
+    """Launch the pending slab sum of the current stream, if any (``ucd_conv_wgrad_flush``)."""
+    _check(load().ucd_conv_wgrad_flush(stream()), "ucd_conv_wgrad_flush")
+
+
+def wgrad_drop():
+    """Forget the pending slab sum of the current stream (an aborted backward)."""
+    load().ucd_conv_wgrad_drop(stream())
+
+
+_wgrad_turn = [0]
+
+
+def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, strided=None, defer=False):
     """Weight gradient of a stride-1 convolution (ucd_conv_wgrad): ``dz`` [M, N] and ``x`` [M, K] bf16 row matrices ->
     ``dw`` [N, taps * K] bf16 (channels-last weight order [N][kh][kw][K]) and / or ``dw32`` fp32 (+= when ``accumulate32``);
     ``conv3 = (H, W, dilation)`` selects the 3x3 form over the [B, H, W, K] map behind ``x``; ``conv3 = (H, W, dilation, stride)`` /
@@ -689,12 +711,15 @@ def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, stride
     elif strided is not None:              # 1x1 with a stride: (H, W, stride) of the input map behind x
         H, W, stride = int(strided[0]), int(strided[1]), int(strided[2])
     nbytes = lib.ucd_conv_wgrad_workspace_bytes(M, N, K, taps)
-    ws = workspace(nbytes, dz.device, "wgrad")
+    # ``defer``: the caller does not read the gradient before the next weight-gradient call or wgrad_flush() - the library may then
+    # carry this call's slab sum in the next launch (two slab buffers in turn: a call's slabs outlive the next call)
+    _wgrad_turn[0] ^= 1
+    ws = workspace(nbytes, dz.device, "wgrad%d" % _wgrad_turn[0])
     # MFMA-bound for the 3x3 layers, HBM / L2-bound for the 1x1 layers: flop for one, algorithmic bytes for the other
     work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * N + M * K)
     with _timed("ucd_conv3x3_wgrad" if conv3 is not None else "ucd_conv1x1_wgrad", work):
-        _check(lib.ucd_conv_wgrad_strided(ptr(dz), dz.stride(0), ptr(x), x.stride(0), M, N, K, taps, H, W, d, stride, ptr(dw),
-                                          ptr(dw32), 1 if accumulate32 else 0, ptr(ws), nbytes, stream()), "ucd_conv_wgrad")
+        _check(lib.ucd_conv_wgrad_ex(ptr(dz), dz.stride(0), ptr(x), x.stride(0), M, N, K, taps, H, W, d, stride, ptr(dw),
+                                     ptr(dw32), 1 if accumulate32 else 0, ptr(ws), nbytes, 1 if defer else 0, stream()), "ucd_conv_wgrad")
     return dw if dw is not None else dw32
 
 

@@ -28,6 +28,8 @@ DEFAULTS = {
     "UCD_CONV_PIPE": "auto",       # pipeline of the GEMM kernel: auto | 2x64 | 4x32 | 4x64 | lw32 | lw64 | lw256 (read by the library)
     "UCD_CONV_RA": "0",            # short-K wide-N 1x1 products (256 -> 1024) on the resident-A form (0: the tiled forms; read by the library)
     "UCD_CONV_BN64_TILES": "128",  # launches of at most this many 128 x 128 tiles run on 128 x 64 tiles (0: never; read by the library)
+    "UCD_CONV_LW64_TILES": "128",  # round 6: launches of at most this many 128 x 64 tiles run on 64-row loader-wave tiles - twice the CUs at 3 images per GPU (0: never; read by the library)
+    "UCD_WGRAD_DEFER": "1",        # round 6: the slab sum of a weight gradient rides in the NEXT weight-gradient launch (0: a launch of its own behind every product)
     "UCD_CONV3_MIN_ROWS": "8192",  # stand-alone 3x3 layers (ASPP) below this many rows stay on the library path
     "UCD_STAT_ATOMIC": "1",        # conv + ABN nodes: statistics / link sums by fp32 atomics into arena slots, finalised by the apply passes (0: per-tile rows + reduction launches, bit-reproducible)
     "UCD_SEG_PK": "1",             # fused logit losses: packed math, fp64 LDS accumulators (0: the round-3 register form; read by the library)
@@ -39,7 +41,7 @@ DEFAULTS = {
     "UCD_STEP_GRAPH": "auto",      # whole-step hipGraph: auto = world 1 only, 1 = always try, 0 = never
     "UCD_TEACHER_OVERLAP": "1",    # frozen teacher on a side stream beside the student's forward (0: in front of it, same stream)
     "UCD_DIRECT_RCCL": "1",        # library-owned RCCL communicator for SyncBN
-    "UCD_IPC_SYNC": "auto",        # SyncBN exchanges (<= 128 KB) as a one-shot IPC mailbox kernel: auto = every rank owns its GPU and the self-test passes on all of them, 1 = also ranks sharing a GPU (tests), 0 = RCCL
+    "UCD_IPC_SYNC": "auto",        # SyncBN exchanges (<= 128 KB) as a one-shot IPC mailbox kernel: auto = only on an explicit attach_mailbox() (bench.py's third phase; every rank owns its GPU, self-test passed on all of them) - a plain run.py job stays on RCCL; 1 = always (also ranks sharing a GPU: tests); 0 = RCCL
     "UCD_IPC_TIMEOUT_MS": "60000", # give-up time of a mailbox exchange (a dead peer: the next collective raises instead of hanging; rank skew of a first iteration must fit)
     "UCD_DDP_LATE_COPY": "1",      # world 1: the bf16 -> fp32 gradient copies of all buckets as ONE launch at the end of the backward
     "UCD_DDP_DIRECT": "auto",      # gradient buckets over a library-owned RCCL communicator: auto = one-rank groups and captured multi-rank steps, 1 / 0 force
