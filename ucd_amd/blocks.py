@@ -252,7 +252,7 @@ class Conv3x3(Conv2d):
         M = x.shape[0] * x.shape[2] * x.shape[3] if x.dim() == 4 else 0
         own = _own3x3_ok(self, x) and self.weight.is_contiguous(memory_format=torch.channels_last)
         if (x.is_cuda and torch.is_grad_enabled() and self.weight.requires_grad and self.bias is None
-                and x.dtype == torch.bfloat16 and M >= int(_env("UCD_CONV3_MIN_ROWS", "8192")) and _env("UCD_DGRAD_VIA_FWD", "1") != "0"):
+                and x.dtype == torch.bfloat16 and M >= int(_env("UCD_CONV3_MIN_ROWS", "0")) and _env("UCD_DGRAD_VIA_FWD", "1") != "0"):
             own_fwd = own and _own_conv3x3(M, self.in_channels, self.out_channels)
             own_dgrad = own and _own_conv3x3(M, self.out_channels, self.in_channels)
             w = self.working_weight()
