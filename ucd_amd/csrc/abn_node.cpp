@@ -155,6 +155,12 @@ void* wgrad_workspace(const at::Tensor& like, size_t bytes, int64_t stream) {
   return workspace(like, bytes, stream, tag);
 }
 
+// May the slab sum of this weight gradient wait for the next weight-gradient launch?  Only when nothing reads the gradient before the
+// wrapper's flush: the weight is a LEAF (the flat bf16 working copy of ucd_amd/master.py: AccumulateGrad adopts the tensor without
+// touching it - the layout contract is met, dw comes out in the weight's own strides).  A weight that is the output of autocast's
+// per-call cast has a ToCopyBackward node behind it that reads the gradient at once.
+int sum_may_wait(const at::Tensor& w4) { return w4.defined() && w4.is_leaf() && w4.requires_grad() ? 1 : 0; }
+
 at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w4, int64_t dilation, int64_t stream,
                      int64_t stride = 1) {
   const int64_t B = x.size(0), K = x.size(1), H = x.size(2), W = x.size(3), N = w4.size(0), M = B * dz.size(2) * dz.size(3);
@@ -163,7 +169,7 @@ at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor
   const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)N, (int)K, taps);
   check(ucd_conv_wgrad_ex(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
                           (int)(dilation > 0 ? dilation : 1), (int)stride, dw.data_ptr(), nullptr, 0,
-                          wgrad_workspace(x, wsb, stream), wsb, 1, (ucd_stream_t)stream),
+                          wgrad_workspace(x, wsb, stream), wsb, sum_may_wait(w4), (ucd_stream_t)stream),
         "ucd_conv_wgrad");
   return dw.permute({0, 3, 1, 2});      // [N, K, kh, kw] with channels-last strides: the weight's own memory order
 }
@@ -273,12 +279,12 @@ bool own_wgrad_rows_ok(const at::Tensor& dy, const at::Tensor& rows) {
          (reinterpret_cast<uintptr_t>(dy.data_ptr()) & 15) == 0 && (reinterpret_cast<uintptr_t>(rows.data_ptr()) & 15) == 0;
 }
 
-at::Tensor own_wgrad_rows(const at::Tensor& dy, const at::Tensor& rows, int64_t stream) {
+at::Tensor own_wgrad_rows(const at::Tensor& dy, const at::Tensor& rows, int64_t stream, const at::Tensor& w4) {
   const int64_t M = rows.size(0), Ci = rows.size(1), Co = dy.size(1);
   at::Tensor dw = at::empty({Co, Ci}, rows.options());
   const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)Co, (int)Ci, 1);
   check(ucd_conv_wgrad_ex(dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, (int)M, (int)Co, (int)Ci, 1, 0, 0, 1, 1, dw.data_ptr(), nullptr, 0,
-                          wgrad_workspace(rows, wsb, stream), wsb, 1, (ucd_stream_t)stream),
+                          wgrad_workspace(rows, wsb, stream), wsb, sum_may_wait(w4), (ucd_stream_t)stream),
         "ucd_conv_wgrad");
   return dw;
 }
@@ -330,7 +336,7 @@ class Gemm1x1Node : public torch::autograd::Function<Gemm1x1Node> {
     if (ctx->needs_input_grad(1)) {
       const int64_t S = wgrad_split(M);
       if (ctx->saved_data["own_wgrad"].toBool() && own_wgrad_rows_ok(dy, rows)) {
-        dw = own_wgrad_rows(dy, rows, stream);
+        dw = own_wgrad_rows(dy, rows, stream, w4);
       } else if (S > 1) {
         dw = at::bmm(dy.view({S, M / S, Co}).transpose(1, 2), rows.view({S, M / S, Ci})).sum(0);
       } else {
@@ -407,7 +413,7 @@ class Gemm1x1SkipNode : public torch::autograd::Function<Gemm1x1SkipNode> {
     if (ctx->needs_input_grad(1) && dy.defined()) {
       const int64_t S = wgrad_split(M);
       if (ctx->saved_data["own_wgrad"].toBool() && own_wgrad_rows_ok(dy, rows)) {
-        dw = own_wgrad_rows(dy, rows, stream);
+        dw = own_wgrad_rows(dy, rows, stream, w4);
       } else if (S > 1) {
         dw = at::bmm(dy.view({S, M / S, Co}).transpose(1, 2), rows.view({S, M / S, Ci})).sum(0);
       } else {

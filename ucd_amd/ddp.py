@@ -193,6 +193,9 @@ class GradReducer:
         mid-backward): their sources are tensors of a pass that did not complete - flushed together with the next step's copies they
         would land in the same bucket views in one multi-tensor launch, in undefined order."""
         self._late_dst, self._late_src = [], []
+        if self.on_gpu and _switches.get("UCD_WGRAD_DEFER", "1") != "0":
+            from . import hip
+            hip.wgrad_drop()                                    # ... nor the slab sum its last weight gradient left pending
 
     def prepare_step(self):
         """Called by the wrapper's forward: if the caller cleared the gradients with ``optim.zero_grad()`` (set_to_none:
@@ -204,7 +207,7 @@ class GradReducer:
             dropped = self._direct_modules[0].bias.grad is None
         if not self._cb_queued:
             self.drop_pending_copies()                          # a new step begins: nothing queued by an aborted backward survives
-            self._wgrad_defer(True)
+        self._wgrad_defer(True)                                 # (drops a slab sum left pending by a backward that never finished)
         if dropped:
             self.zero_grad()
 
