@@ -52,6 +52,7 @@ import torch.distributed as dist
 PEAK_HBM_GBS = 8000.0       # MI355X HBM3E peak (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TF = 157.3    # dense fp32 matrix peak
 PEAK_F16_MFMA_TF = 2500.0   # dense fp16/bf16 matrix peak
+STAGING_ROOF_GBS = 14000.0  # 256 CUs x ~26 B/clk x 2.1 GHz through the LDS-DMA / L1 path (measured: tools/probes/fill_rate.hip, profiles/r06_lw_probe.txt)
 MFMA_CALLS = ("ucd_conv3x3", "ucd_conv3x3_wgrad")     # 9 K deep implicit GEMMs: priced in flop (hip.py _timed work)
 E_PER_IMAGE_513 = 98.44e6   # ABN activation elements per image per pass at 513^2
 
@@ -157,6 +158,13 @@ def kernel_timing(trainer, optimizer, scheduler, images, labels, steps):
             out[name]["bound_mix"] = {"hbm_ms": mix["hbm"][0], "mfma_ms": mix["mfma"][0],
                                       "hbm_frac": mix["hbm"][1] / mix["hbm"][0] if mix["hbm"][0] else None,
                                       "mfma_frac": mix["mfma"][1] / mix["mfma"][0] if mix["mfma"][0] else None}
+            if len(calls[0]) > 4:
+                # round 6: the third roof of these products - the CUs' staging path (LDS-DMA: ~26 B/clk/CU measured, tools/probes/
+                # fill_rate.hip; 256 CUs x 26 B/clk x 2.1 GHz = 14 TB/s).  The K >> N layers sit on it, below the HBM roof they are
+                # priced against above; reported, not used for `frac`
+                staged = sum(c[4] for c in calls)
+                out[name]["staging"] = {"bytes": staged, "achieved_gbs": staged / (ms * 1e-3) / 1e9, "roof_gbs": STAGING_ROOF_GBS,
+                                        "frac": staged / (ms * 1e-3) / 1e9 / STAGING_ROOF_GBS}
     out["_event_pair_overhead_us"] = 1e3 * overhead_ms
     return out
 
@@ -359,6 +367,8 @@ def main():
             ach = k["work"] / (k["ms_total"] * 1e-3) / 1e9
             roof = {"kernel": name, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": ach / PEAK_HBM_GBS, "traffic": None}
+        if "staging" in k:
+            roof["staging"] = k["staging"]           # the same launches against the CUs' LDS staging rate (a roof below HBM for K >> N)
         if "bound_mix" in k:
             roof["bound_mix"] = k["bound_mix"]       # the call type split by each call's own roof (ms in the instrumented pass, fractions)
         roof["avg_launch_us"] = k["avg_us"]

@@ -190,10 +190,11 @@ def disable_call_timing():
 class _Timed:
     """with _timed(name, work): <library call>"""
 
-    def __init__(self, name, work, flops=None):
+    def __init__(self, name, work, flops=None, staged=None):
         # work: the call type's roofline unit (bytes for the HBM-bound types, flop for the MFMA-bound ones); flops: for the 1x1
-        # products ALSO the flop count, so that bench.py can classify each call by min(bytes / 8 TB/s, flop / 2.5 PFLOP/s)
-        self.name, self.work, self.flops = name, work, flops
+        # products ALSO the flop count, so that bench.py can classify each call by min(bytes / 8 TB/s, flop / 2.5 PFLOP/s);
+        # staged (round 6): bytes the GEMM's workgroups pull through their CUs' LDS-DMA path, M N K 2 (1 / BM + 1 / BN)
+        self.name, self.work, self.flops, self.staged = name, work, flops, staged
 
     def __enter__(self):
         self.start = torch.cuda.Event(enable_timing=True)
@@ -203,7 +204,7 @@ class _Timed:
     def __exit__(self, *exc):
         self.end.record(torch.cuda.current_stream())
         _timing.setdefault(self.name, []).append((self.start, self.end, self.work) if self.flops is None
-                                                 else (self.start, self.end, self.work, self.flops))
+                                                 else (self.start, self.end, self.work, self.flops, self.staged or 0))
         return False
 
 
@@ -218,8 +219,8 @@ class _NoTimer:
 _NO_TIMER = _NoTimer()
 
 
-def _timed(name, work, flops=None):
-    return _NO_TIMER if _timing is None else _Timed(name, work, flops)
+def _timed(name, work, flops=None, staged=None):
+    return _NO_TIMER if _timing is None else _Timed(name, work, flops, staged)
 
 
 def ptr(t):
@@ -572,7 +573,10 @@ def conv1x1(a, w, y, in_norm=None, out_mode=0, out_norm=None, residual=None, par
     # shapes), flop for the 3x3 implicit GEMM (9 K deep: MFMA-bound)
     work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * K + M * N * (1 + (residual is not None) + bool(accumulate)
                                                                                  + (side2 is not None)))
-    with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work, None if conv3 is not None else 2 * M * K * N):
+    # bytes staged through LDS by the tiled kernel: every (BM x BN) tile pulls (BM + BN) K values per tap; BN as the library picks it
+    bn = 128 if (N % 128 == 0 and ((M + 127) // 128) * (N // 128) > 128) else 64
+    staged = 2 * M * N * K * (9 if conv3 is not None else 1) * (1.0 / 128 + 1.0 / bn)
+    with _timed("ucd_conv3x3" if conv3 is not None else "ucd_conv1x1", work, None if conv3 is not None else 2 * M * K * N, staged):
         _check(lib.ucd_conv1x1(C.byref(d), stream()), "ucd_conv1x1")
     return y
 
