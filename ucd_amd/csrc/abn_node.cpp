@@ -146,11 +146,11 @@ bool own_wgrad_ok(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w
 // bucket copies, in front of which ucd_amd/ddp.py flushes) - so a call's slabs must outlive the NEXT call: two scratch buffers, taken
 // in turn.
 void* wgrad_workspace(const at::Tensor& like, size_t bytes, int64_t stream) {
-  static int turn = 0;
+  static std::map<std::pair<int, int64_t>, int> turn;   // per (device, stream): the pending sum is per stream too
   int tag;
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    tag = 2 + (turn ^= 1);
+    tag = 2 + (turn[std::make_pair((int)like.get_device(), stream)] ^= 1);
   }
   return workspace(like, bytes, stream, tag);
 }

@@ -696,7 +696,7 @@ def wgrad_drop():
     load().ucd_conv_wgrad_drop(stream())
 
 
-_wgrad_turn = [0]
+_wgrad_turn = {}
 
 
 def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, strided=None, defer=False):
@@ -717,8 +717,9 @@ def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, stride
     nbytes = lib.ucd_conv_wgrad_workspace_bytes(M, N, K, taps)
     # ``defer``: the caller does not read the gradient before the next weight-gradient call or wgrad_flush() - the library may then
     # carry this call's slab sum in the next launch (two slab buffers in turn: a call's slabs outlive the next call)
-    _wgrad_turn[0] ^= 1
-    ws = workspace(nbytes, dz.device, "wgrad%d" % _wgrad_turn[0])
+    key = (dz.device.index, stream())
+    _wgrad_turn[key] = _wgrad_turn.get(key, 0) ^ 1
+    ws = workspace(nbytes, dz.device, "wgrad%d" % _wgrad_turn[key])
     # MFMA-bound for the 3x3 layers, HBM / L2-bound for the 1x1 layers: flop for one, algorithmic bytes for the other
     work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * N + M * K)
     with _timed("ucd_conv3x3_wgrad" if conv3 is not None else "ucd_conv1x1_wgrad", work):
