@@ -1272,107 +1272,6 @@ def test_atomic_links_survive_an_arena_reset_and_refuse_a_second_fill():
         assert torch.isfinite(b).all() and _rel(b, a) < 8e-2
 
 
-_RA_CHILD = r"""
-import sys, torch
-sys.path.insert(0, %(root)r)
-from ucd_amd import hip
-dev = torch.device("cuda:0")
-g = torch.Generator(dev).manual_seed(5)
-def ints(*shape, hi):
-    return torch.randint(-hi, hi + 1, shape, device=dev, generator=g).bfloat16()
-out = {}
-# the mod4 shape of the benchmark (205 row tiles, one column range), a ragged 12-image grid (103 tiles, two ranges) and the per-rank
-# shape of the 8-GPU split (26 tiles, eight ranges of one step each); N = 512: four steps
-for M, K, N in ((26136, 256, 1024), (13068, 256, 1024), (3267, 256, 1024), (26136 - 77, 256, 512)):
-    a = ints(M, K, hi=2) * (torch.rand(M, K, device=dev, generator=g) < 0.2)
-    w = ints(N, K, hi=1) * (torch.rand(N, K, device=dev, generator=g) < 0.2)
-    ref = a.float() @ w.float().t()
-    assert ref.abs().max().item() <= 256
-    tiles = hip.load().ucd_conv1x1_row_tiles(M)
-    y = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
-    hip.conv1x1(a, w, y)
-    assert torch.equal(y.float(), ref), ("plain", M, K, N)
-    res = ints(M, N, hi=3)
-    y0 = res.clone()
-    hip.conv1x1(a, w, y0, accumulate=True)
-    assert torch.equal(y0.float(), ref + res.float()), ("accumulate", M, K, N)
-    wide = torch.zeros(M, N + 256, device=dev, dtype=torch.bfloat16)                 # a channel slice of a wider buffer (ldy > N)
-    hip.conv1x1(a, w, wide[:, 128:128 + N])
-    assert torch.equal(wide[:, 128:128 + N].float(), ref) and not wide[:, :128].any() and not wide[:, 128 + N:].any(), ("slice", M, K, N)
-    part = hip.conv1x1_stats_partial(M, N, dev).fill_(float("nan"))
-    y.fill_(float("nan"))
-    hip.conv1x1(a, w, y, out_mode=2, partial=part)
-    assert torch.equal(y.float(), ref), ("stats y", M, K, N)
-    p = part.view(tiles, 3, N)
-    assert not torch.isnan(p).any()
-    for t in (0, tiles // 2, tiles - 1):
-        rows = ref[t * 128:(t + 1) * 128]
-        k = p[t, 0]
-        assert torch.equal(k, rows[0]) and torch.equal(p[t, 1], (rows - k).sum(0)) and torch.equal(p[t, 2], ((rows - k) ** 2).sum(0)), ("partials", M, K, N, t)
-    one, zero = torch.ones(N, device=dev), torch.zeros(N, device=dev)
-    hip.conv1x1(a, w, y, out_mode=1, out_norm=(zero, one, zero, None, hip.ACT_LEAKY_RELU, 0.5), residual=res)
-    z = ref + res.float()
-    assert torch.equal(y.float(), torch.where(z > 0, z, z * 0.5).bfloat16().float()), ("affine + residual", M, K, N)
-    hip.conv1x1(a, w, y, out_mode=1, out_norm=(zero, one, zero, None, hip.ACT_LEAKY_RELU, 0.5))
-    assert torch.equal(y.float(), torch.where(ref > 0, ref, ref * 0.5).bfloat16().float()), ("affine", M, K, N)
-    # block link (out_mode 4): d pre = (acc + d shortcut) * act'(block output), sums of d pre and d pre * x-hat(z3) (mean 0, invstd 1)
-    outb, z3 = ints(M, N, hi=2), ints(M, N, hi=2)
-    p4 = torch.full((tiles, 2, N), float("nan"), device=dev)
-    y4 = res.clone()
-    hip.conv1x1(a, w, y4, out_mode=4, out_norm=(zero, None, None, one, hip.ACT_LEAKY_RELU, 0.5), residual=outb, side2=z3, partial=p4, accumulate=True)
-    dpre = ((ref + res.float()) * torch.where(outb.float() > 0, 1.0, 0.5)).bfloat16().float()
-    assert torch.equal(y4.float(), dpre), ("block link y", M, K, N)
-    assert not torch.isnan(p4).any()
-    for t in (0, tiles - 1):
-        rows, zz = dpre[t * 128:(t + 1) * 128], z3[t * 128:(t + 1) * 128].float()
-        assert torch.allclose(p4[t, 0], rows.sum(0), rtol=0, atol=1e-3) and torch.allclose(p4[t, 1], (rows * zz).sum(0), rtol=0, atol=1e-3), ("block link sums", M, K, N, t)
-    # real-valued operands: what the other kernel forms of this library give for the same call (dumped for the parent to compare)
-    ar = (torch.randn(M, K, device=dev, generator=g) * 1.3 + 0.2).bfloat16()
-    wr = (torch.randn(N, K, device=dev, generator=g) * (2.0 / K) ** 0.5).bfloat16()
-    rr = torch.randn(M, N, device=dev, generator=g).bfloat16()
-    mean, scale, shift = torch.randn(N, device=dev, generator=g) * 0.3, torch.rand(N, device=dev, generator=g) + 0.5, torch.randn(N, device=dev, generator=g) * 0.2
-    yp = torch.empty(M, N, device=dev, dtype=torch.bfloat16); hip.conv1x1(ar, wr, yp)
-    pr = hip.conv1x1_stats_partial(M, N, dev); ys = torch.empty_like(yp); hip.conv1x1(ar, wr, ys, out_mode=2, partial=pr)
-    buf = torch.zeros(6 * N, device=dev)
-    hip.conv1x1_stats_finalize(pr, M, N, torch.ones(N, device=dev), torch.zeros(N, device=dev), torch.ones(N, device=dev), 0.1, 1e-5, buf)
-    ya = torch.empty_like(yp); hip.conv1x1(ar, wr, ya, out_mode=1, out_norm=(mean, scale, shift, None, hip.ACT_LEAKY_RELU, 0.01), residual=rr)
-    torch.cuda.synchronize()
-    out[(M, K, N)] = dict(plain=yp.cpu(), stats_y=ys.cpu(), mean_invstd=buf[3 * N:5 * N].cpu(), affine=ya.float().cpu(),
-                          ref=(ar.float() @ wr.float().t()).cpu())
-torch.save(out, sys.argv[1])
-print("ok")
-"""
-
-
-def test_resident_a_form_of_the_short_k_products_is_exact_on_integers_and_matches_the_tiled_forms(tmp_path):
-    """conv_ra_kernel (round 5: conv3 of the mod4 blocks and the block link, 256 -> 1024; modules/residual.py:67-73) against exact
-    integer products for every output mode it takes (plain, accumulate, slice output, statistics with the per-tile partial rows, affine
-    (+ residual) + activation, block link with its two sums) at the benchmark's 205 row tiles and on the column-range split of smaller
-    grids; then, on real-valued operands, against the tiled forms of the same library (``UCD_CONV_RA=0`` in a second process): plain and
-    statistics outputs bit for bit, mean / invstd to fp32 rounding, the affine epilogue within one bf16 rounding of z."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    outs = {}
-    for ra in ("2", "0"):
-        env = dict(os.environ, UCD_CONV_RA=ra)
-        env.pop("UCD_CONV_PIPE", None)
-        f = tmp_path / f"ra{ra}.pt"
-        r = subprocess.run([sys.executable, "-c", _RA_CHILD % {"root": root}, str(f)], env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (ra, r.stdout[-500:], r.stderr[-2000:])
-        outs[ra] = torch.load(f)
-    for key, a in outs["2"].items():
-        b = outs["0"][key]
-        # another order of the sum over k inside a K step: the fp32 accumulators differ in the last bits, a few stored values by one
-        # bf16 rounding step
-        for name in ("plain", "stats_y"):
-            da = (a[name].float() - b[name].float()).abs()
-            assert (da > 0).float().mean() < 0.02 and (da <= 2.0 ** -7 * b[name].float().abs().clamp_min(1e-3)).all(), (key, name)
-        torch.testing.assert_close(a["mean_invstd"], b["mean_invstd"], rtol=1e-4, atol=2e-5)
-        # the affine epilogue sees z after one bf16 rounding here (the tiled forms apply it to the fp32 accumulator)
-        assert _rel(a["affine"], b["affine"]) < 4e-3 and (a["affine"] - b["affine"]).abs().max() <= 0.04 * b["affine"].abs().max(), key
-
-
 @pytest.mark.parametrize("pipe", ["2x64", "4x32", "4x64", "lw32", "lw64", "lw64x2", "lw256"])
 def test_every_pipeline_form_of_the_gemm_kernel_is_exact_on_integers(pipe):
     """The GEMM / implicit-GEMM kernel has seven pipeline forms since round 4 (double buffer, two four-stage forms, loader waves on

@@ -73,7 +73,7 @@ with open(sys.argv[2], "w") as f:
     bygrid = collections.defaultdict(lambda: [0, 0])
     for r in win:
         k = short(r["Kernel_Name"])
-        if any(n in k for n in ("conv1x1_kernel", "conv_lw_kernel", "conv_ra_kernel", "wgrad3_kernel", "wgrad_kernel")):
+        if any(n in k for n in ("conv1x1_kernel", "conv_lw_kernel", "wgrad3_kernel", "wgrad_kernel")):
             key = (k.split(None, 1)[1], "x".join(str(r[c]) for c in sorted(r) if c.startswith("Grid_Size")))
             bygrid[key][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); bygrid[key][1] += 1
     f.write("# GEMM kernels by grid size (threads): ms/step, calls/step, avg us\n")

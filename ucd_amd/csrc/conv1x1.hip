@@ -584,270 +584,9 @@ __global__ __launch_bounds__(BM == 64 ? 384 : BM * 4, (BM + BN) * BK * 2 * NST >
   }
 }
 
-// ---- resident-A form (round 5): the short-K, wide-N 1x1 products ------------------------------------------------------------------
-// conv3 of the 23 mod4 bottlenecks (modules/residual.py:67-73: 256 -> 1024 at M = B * 33 * 33) for the student (statistics epilogue),
-// the frozen teacher (affine + shortcut + activation) and, as the input gradient of the NEXT block's conv1, the block link.  In the
-// tiled forms above a 128 x 128 output tile stages 128 KB of operands for 32 KB of output, a workgroup lives for four exposed fill
-// round trips + an epilogue, and 1640 workgroups run as 1.6 rounds (profiles/r04_conv1x1_timeline.txt).  Here ONE workgroup per row
-// tile keeps its A rows [128][K = 256] resident in LDS (filled once by LDS-DMA, K-step-major so the swizzle of the tiled forms
-// applies) and sweeps all N in steps of 128 columns:
-//   waves 0 - 3 (MFMA): wave w owns columns 32 w .. 32 w + 31 of each step.  Its W rows never touch LDS: the k order inside a K step
-//     is ours to choose as long as both operands agree, so lane (r, h) takes k = 64 s + 32 h + 8 i + j for MFMA i of K step s - 64
-//     contiguous bytes of W row r per K step, straight from L2 into registers (the next step's 16 loads in flight under this step's
-//     64 MFMAs), and the A fragment of the same k is 16-byte slot 4 h + i of the resident row.  The product is formed TRANSPOSED
-//     (W is the MFMA's first operand): a lane then holds ONE output row and four consecutive columns per accumulator quad - packed to
-//     bf16 in-lane and written as 8-byte pieces of a row-major [128][128] bf16 stage tile (two stage tiles: one barrier per step).
-//   waves 4 - 7 (epilogue): read the stage tile row-contiguously while the MFMA waves run the next step, apply the output mode on
-//     float pairs (conv1x1_epilogue.inc's arithmetic) and issue whole-row 16-byte global accesses; the side inputs of a step (the
-//     shortcut / the block output and conv output of the block link) are requested before the step's barrier and land during the wait.
-// The accumulators pass through bf16 before the affine / link epilogues (one more rounding of z than the tiled forms, the same as a
-// materialised bf16 z); out_mode 0 and 2 store exactly the tiled forms' values, the per-tile statistics in another summation order.
-template <int OUT>
-__global__ __launch_bounds__(512, 2) void conv_ra_kernel(Args p) {
-  constexpr int KT = 256, KS = KT / 64;                 // K and its steps of 64
-  constexpr int CPB = 272;                              // byte pitch of a stage-tile row (128 bf16 + 16 B: 16-byte aligned rows)
-  constexpr int kAs = KS * 16384, kCs = 128 * CPB;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  unsigned char* As = smem;                             // [KS][128][64] bf16, swz() inside a K step
-  unsigned char* Cs = smem + kAs;                       // [2][128][136] bf16
-  float* red = reinterpret_cast<float*>(smem + kAs + 2 * kCs);   // [2][4][2][128]: per epilogue wave column sums of a step
-  // workgroup = (row tile, one of tiles_n column ranges); the ranges of a row tile on one XCD (ids congruent mod 8 share an L2)
-  const int nsp = p.tiles_n, grp = blockIdx.x / (8 * nsp), rem = blockIdx.x - grp * 8 * nsp;
-  const int tm = grp * 8 + (rem & 7), jr = rem >> 3;
-  if (tm >= p.tiles_m) return;
-  const int m0 = tm * kBM;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int NT = p.N / 128 / nsp, j0 = jr * NT;         // steps of this workgroup: j0 .. j0 + NT - 1
-
-  // ---- the A rows, once: piece (K step, 8 rows) of 1 KiB per wave-instruction, K step 0 first -----------------------------------------
-  {
-    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((size_t)p.a_rows * p.lda * 2), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int piece = i * 8 + wave, ks = piece >> 4, ch = piece & 15;
-      const int row = 8 * ch + (lane >> 3);
-      const int slot = (lane & 7) ^ ((row >> 1) & 7);
-      const unsigned off = (unsigned)(((size_t)min(m0 + row, p.M - 1) * p.lda + slot * 8) * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lptr_t)(As + ks * 16384 + ch * 1024), 16, (int)off, ks * 128, 0, 0);
-    }
-  }
-
-  if (wave < 4) {
-    // ================================ MFMA waves ================================
-    const int fr = lane & 31, fh = lane >> 5;
-    const uint4* wp = reinterpret_cast<const uint4*>(p.W + (size_t)(j0 * 128 + 32 * wave + fr) * p.ldw + 32 * fh);
-    const size_t wstep = (size_t)128 * p.ldw / 8;       // uint4 per step of 128 columns (ldw % 8 == 0)
-    uint4 wa[4 * KS], wb[4 * KS];
-    auto load_w = [&](uint4 (&w)[4 * KS], const uint4* src) {
-#pragma unroll
-      for (int s = 0; s < KS; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[4 * s + i] = src[8 * s + i];
-    };
-    load_w(wa, wp);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the A pieces of this wave (and wa)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // per-lane LDS offsets: the A fragment of (m tile, K step s, MFMA i) and the stage-tile piece of (m tile, quad q)
-    int aoff[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) aoff[mt] = (32 * mt + fr) * 128;
-    const int asw = (fr >> 1) & 7;                      // swz: slot ^ ((row >> 1) & 7); 32 mt does not change (row >> 1) & 7
-    const int coff = fr * CPB + (32 * wave + 4 * fh) * 2;
-    // A fragments one slice (four MFMAs) ahead of their use, two register sets (left alone the compiler issues each pair of reads
-    // right in front of the MFMAs that consume them: an exposed LDS round trip per two MFMAs); the first slice of a step is the same
-    // for every step and is requested before the previous step's stage-tile writes
-    bf16x8 af[2][4];
-    auto read_slice = [&](int set, int idx) {
-      const int so = (((4 * fh + (idx & 3)) ^ asw) << 4) + (idx >> 2) * 16384;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[set][mt] = *reinterpret_cast<const bf16x8*>(As + aoff[mt] + so);
-    };
-    read_slice(0, 0);
-    auto step = [&](const uint4 (&cur)[4 * KS], uint4 (&nxt)[4 * KS], int j) {
-      if (j + 1 < NT && !(p.dil & 1)) load_w(nxt, wp + (size_t)(j + 1) * wstep);
-      f32x16 acc[4];
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-#pragma unroll
-      for (int idx = 0; idx < 4 * KS; ++idx) {
-        read_slice((idx + 1) & 1, (idx + 1) & (4 * KS - 1));      // the last one fetches slice 0 for the next step
-        __builtin_amdgcn_sched_barrier(0);
-        const bf16x8 wf = __builtin_bit_cast(bf16x8, cur[idx]);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, af[idx & 1][mt], acc[mt], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // acc[mt][4 q + e] = Y[row 32 mt + fr][column 32 wave + 8 q + 4 fh + e]: four consecutive columns -> 8 bytes of the stage tile
-      unsigned char* Cd = Cs + (j & 1) * kCs + coff;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bf16x2v lo = __builtin_convertvector(f32x2{acc[mt][4 * q], acc[mt][4 * q + 1]}, bf16x2v);
-          const bf16x2v hi = __builtin_convertvector(f32x2{acc[mt][4 * q + 2], acc[mt][4 * q + 3]}, bf16x2v);
-          *reinterpret_cast<uint2*>(Cd + mt * 32 * CPB + q * 16) = make_uint2(__builtin_bit_cast(uint32_t, lo), __builtin_bit_cast(uint32_t, hi));
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                      // step j is in stage tile j & 1
-      asm volatile("" ::: "memory");
-    };
-    for (int j = 0; j < NT; j += 2) {
-      step(wa, wb, j);
-      if (j + 1 < NT) step(wb, wa, j + 1);
-    }
-    if (OUT == 2 || OUT == 4) __builtin_amdgcn_s_barrier();   // the epilogue waves' last column sums
-    return;
-  }
-
-  // ================================ epilogue waves ================================
-  const int et = tid - 256, ew = wave - 4;
-  const int c8 = et & 15, r0 = et >> 4;                  // 16-byte chunk of a 128-column row; rows r0 + 16 i
-  Pack8 em, es, eb, ei;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's A pieces
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  const bool tile_ok = tm < p.tiles128;
-  const bf16* sp = (OUT == 0 || OUT == 4) ? p.Y : p.R;
-  const int lds_ = (OUT == 0 || OUT == 4) ? p.ldy : p.ldr;
-  const bool has_side = ((OUT == 0 || OUT == 4) && p.accumulate) || (OUT == 1 && p.R != nullptr);
-  auto combine = [&](int j) {                            // column sums of step j: four waves' rows -> the tile's partial row
-    const float* rd = red + (j & 1) * 1024;
-    const int which = et >> 7, col = et & 127;
-    const float t = ((rd[(0 * 2 + which) * 128 + col] + rd[(1 * 2 + which) * 128 + col]) + rd[(2 * 2 + which) * 128 + col]) +
-                    rd[(3 * 2 + which) * 128 + col];
-    if (tile_ok && p.stat_acc) {
-      const size_t ro = (size_t)(tm & (p.stat_rep - 1)) * 2 * p.N;
-      atomicAdd(p.stat_acc + ro + which * p.N + (j0 + j) * 128 + col, t);
-      if (p.stat_acc2) atomicAdd(p.stat_acc2 + ro + which * p.N + (j0 + j) * 128 + col, t);
-    } else if (tile_ok) {
-      if (OUT == 2) p.partial[(size_t)tm * 3 * p.N + (1 + which) * p.N + (j0 + j) * 128 + col] = t;
-      else p.partial[(size_t)tm * 2 * p.N + which * p.N + (j0 + j) * 128 + col] = t;
-    }
-  };
-  for (int j = 0; j < NT; ++j) {
-    const int ncol = (j0 + j) * 128 + c8 * 8;
-    uint4 side[8], side_y[OUT == 4 ? 8 : 1], side_z[OUT == 4 ? 8 : 1];
-    if (has_side) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) side[i] = *reinterpret_cast<const uint4*>(sp + (size_t)min(m0 + r0 + 16 * i, p.M - 1) * lds_ + ncol);
-    }
-    if (OUT == 4) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const size_t row = (size_t)min(m0 + r0 + 16 * i, p.M - 1);
-        side_y[i] = *reinterpret_cast<const uint4*>(p.R + row * p.ldr + ncol);
-        side_z[i] = *reinterpret_cast<const uint4*>(p.Z + row * p.ldz + ncol);
-      }
-    }
-    if (OUT == 1) {
-      em = load_f8(p.out_mean + ncol);
-      es = load_f8(p.out_scale + ncol);
-      eb = load_f8(p.out_shift + ncol);
-    }
-    if (OUT == 4) {
-      em = load_f8(p.out_mean + ncol);
-      ei = load_f8(p.out_invstd + ncol);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's rows of `red` (previous step) are written
-    __builtin_amdgcn_s_barrier();                          // step j is in stage tile j & 1
-    asm volatile("" ::: "memory");
-    if ((OUT == 2 || OUT == 4) && j > 0) combine(j - 1);
-    const unsigned char* Cr = Cs + (j & 1) * kCs + c8 * 16;
-    uint4 cv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) cv[i] = *reinterpret_cast<const uint4*>(Cr + (r0 + 16 * i) * CPB);
-    Pack8 kshift, s1, s2;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { kshift.p[q] = f32x2{0.f, 0.f}; s1.p[q] = f32x2{0.f, 0.f}; s2.p[q] = f32x2{0.f, 0.f}; }
-    if (OUT == 2) kshift = p.stat_acc ? load_f8(p.stat_shift + ncol) : unpack8(*reinterpret_cast<const uint4*>(Cr));   // the tile's first row (as stored)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int grow = m0 + r0 + 16 * i;
-      const bool live = grow < p.M;
-      uint4 packed = cv[i];
-      if (OUT == 0) {
-        if (p.accumulate) {
-          Pack8 v = unpack8(cv[i]);
-          const Pack8 sv = unpack8(side[i]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v.p[q] += sv.p[q];
-          packed = pack8(v);
-        }
-      } else if (OUT == 1) {
-        const Pack8 v = unpack8(cv[i]);
-        Pack8 o;
-        if (p.R) {
-          const Pack8 sv = unpack8(side[i]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o.p[q] = leaky2((v.p[q] - em.p[q]) * es.p[q] + eb.p[q] + sv.p[q], p.out_slope);
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o.p[q] = leaky2((v.p[q] - em.p[q]) * es.p[q] + eb.p[q], p.out_slope);
-        }
-        packed = pack8(o);
-      } else if (OUT == 2) {
-        if (live) {
-          const Pack8 qv = unpack8(packed);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const f32x2 d = qv.p[q] - kshift.p[q];
-            s1.p[q] += d;
-            s2.p[q] += d * d;
-          }
-        }
-      } else if (OUT == 4) {
-        Pack8 v = unpack8(cv[i]), o;
-        const Pack8 yv = unpack8(side_y[OUT == 4 ? i : 0]), zv = unpack8(side_z[OUT == 4 ? i : 0]);
-        if (p.accumulate) {
-          const Pack8 sv = unpack8(side[i]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v.p[q] += sv.p[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o.p[q] = leaky_grad2(v.p[q], yv.p[q], p.out_slope);
-        packed = pack8(o);
-        if (live) {
-          const Pack8 qv = unpack8(packed);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            s1.p[q] += qv.p[q];
-            s2.p[q] += qv.p[q] * ((zv.p[q] - em.p[q]) * ei.p[q]);
-          }
-        }
-      }
-      if (live && !(p.dil & 2)) *reinterpret_cast<uint4*>(p.Y + (size_t)grow * p.ldy + ncol) = packed;
-    }
-    if (OUT == 2 || OUT == 4) {
-      // the four row groups of a wave (lanes l, l + 16, l + 32, l + 48 share a column chunk), then one row of `red` per wave
-      float v[16];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { v[2 * q] = s1.p[q].x; v[2 * q + 1] = s1.p[q].y; v[8 + 2 * q] = s2.p[q].x; v[8 + 2 * q + 1] = s2.p[q].y; }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        v[e] += __shfl_xor(v[e], 16, 64);
-        v[e] += __shfl_xor(v[e], 32, 64);
-      }
-      if (lane < 16) {
-        float* rw = red + (j & 1) * 1024 + ew * 256 + c8 * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { rw[e] = v[e]; rw[128 + e] = v[8 + e]; }
-      }
-      if (OUT == 2 && r0 == 0 && tile_ok && (!p.stat_acc || tm == 0)) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x2*>(p.partial + (p.stat_acc ? 0 : (size_t)tm * 3 * p.N) + ncol + 2 * q) = kshift.p[q];
-      }
-    }
-  }
-  if (OUT == 2 || OUT == 4) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    combine(NT - 1);
-  }
-}
+// (The resident-A form of the short-K, wide-N products - conv_ra_kernel, round 5: A rows resident in LDS, W rows straight from L2 into
+// registers, separate epilogue waves - measured slower than the tiled forms, 29.3 vs 22.2 us at 256 -> 1024, and was removed in round 6;
+// DESIGN.md section 10, profiles/r05_conv_ra_probe.txt, git history.)
 
 // Per-tile shifted sums (k_t, s1_t, s2_t) -> sums about the common shift K = k_0 -> the usual finalize.
 //   sum (y - K) = s1_t + c_t (k_t - K),   sum (y - K)^2 = s2_t + 2 (k_t - K) s1_t + c_t (k_t - K)^2   (exact identities)
@@ -1358,35 +1097,6 @@ int ucd_conv1x1(const ucd_conv1x1_desc* d, ucd_stream_t stream) {
   // out_mode 4 keeps three side tiles in registers next to the accumulators: 168 VGPRs + 96 B of scratch in the single-stage
   // form at three workgroups per CU, 194 VGPRs and no scratch in the double-buffered form (two per CU) - it always takes that
   hipStream_t s = (hipStream_t)stream;
-  // short K, wide N, one row tile per CU at most (conv3 of the mod4 blocks and the block link at 24 images: 256 -> 1024 on 205 row
-  // tiles): the resident-A form (conv_ra_kernel).  UCD_CONV_RA=0 keeps the tiled forms (A/B, tests).
-  static const int ra_mode = getenv("UCD_CONV_RA") ? atoi(getenv("UCD_CONV_RA")) : 0;
-  if (ra_mode && !conv3 && stride == 1 && !d->in_scale && d->K == 256 && d->N % 128 == 0 && d->N >= 512 && d->out_mode != 3) {
-    // grids of fewer than 256 row tiles cut the N sweep into column ranges (one workgroup each) until the chip is full
-    const int nt = d->N / 128;
-    int nsp = 1;
-    while (nsp * 2 <= nt && nt % (nsp * 2) == 0 && (long long)a.tiles_m * nsp * 2 <= 256) nsp *= 2;
-    if ((long long)a.tiles_m * nsp >= (ra_mode == 2 ? 1 : 128)) {
-      Args b = a;
-      b.tiles_n = nsp;
-      b.dil = getenv("UCD_RA_DEBUG") ? atoi(getenv("UCD_RA_DEBUG")) : 0;   // timing experiments only
-      const int grid_ra = ceil_div(a.tiles_m, 8) * 8 * nsp;
-      constexpr int kRaLds = 4 * 16384 + 2 * 128 * 272 + 2 * 4 * 2 * 128 * 4;
-#define UCD_RA(OUTV)                                                       \
-  {                                                                        \
-    UCD_TRY_LDS((conv_ra_kernel<OUTV>), kRaLds);                           \
-    conv_ra_kernel<OUTV><<<grid_ra, 512, kRaLds, s>>>(b);                  \
-  }
-      switch (d->out_mode) {
-        case 0: UCD_RA(0) break;
-        case 1: UCD_RA(1) break;
-        case 2: UCD_RA(2) break;
-        default: UCD_RA(4) break;
-      }
-      return check_launch(fn);
-    }
-  }
-#undef UCD_RA
   const bool db = ((conv3 || !d->in_scale) && (long long)ceil_div(d->M, kBM) * (d->N / BN) <= 640) || (d->out_mode == 4 && BN == 128);
   const size_t lds_main = (size_t)(kBM + BN) * 128 * (db ? 2 : 1), lds_out = (size_t)64 * (BN + 4) * 4;
   size_t lds = lds_main > lds_out ? lds_main : lds_out;

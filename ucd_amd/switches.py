@@ -26,7 +26,6 @@ DEFAULTS = {
     "UCD_OWN_STEM": "1",           # 7x7/2 stem forward on csrc/stem.hip
     "UCD_WGRAD3": "1",             # 3x3 weight gradients: one kernel row per workgroup (0: the 9-tap form; read by the library)
     "UCD_CONV_PIPE": "auto",       # pipeline of the GEMM kernel: auto | 2x64 | 4x32 | 4x64 | lw32 | lw64 | lw256 (read by the library)
-    "UCD_CONV_RA": "0",            # short-K wide-N 1x1 products (256 -> 1024) on the resident-A form (0: the tiled forms; read by the library)
     "UCD_CONV_BN64_TILES": "128",  # launches of at most this many 128 x 128 tiles run on 128 x 64 tiles (0: never; read by the library)
     "UCD_CONV_LW64_TILES": "128",  # round 6: launches of at most this many 128 x 64 tiles run on 64-row loader-wave tiles - twice the CUs at 3 images per GPU (0: never; read by the library)
     "UCD_WGRAD_DEFER": "1",        # round 6: the slab sum of a weight gradient rides in the NEXT weight-gradient launch (0: a launch of its own behind every product)
