@@ -445,8 +445,8 @@ __global__ __launch_bounds__(kBlock) void abn_apply_fast_kernel(const __hip_bflo
   const int r_end = min(M, r_begin + rows_per_band);
   auto ld = [&](const __hip_bfloat16* p, int ldp, int r) {
     const uint4* q = reinterpret_cast<const uint4*>(p + (size_t)r * ldp + coff);
-    if (p == x) {      // round 6: z is not read again before the backward - a non-temporal load keeps it from displacing what the next
-                       // GEMM wants in L2 / the Infinity Cache (same-box A/B 29.77 -> 29.62 ms at 24 images, profiles/r06_kernel_ab_during.txt)
+    if (p == x || p == res) {      // round 6: z is not read again before the backward - a non-temporal load keeps it from displacing what the next
+                       // GEMM wants in L2 / the Infinity Cache (same-box A/B 29.77 -> 29.62 ms at 24 images; the residual, read here for the last time in the forward, the same way: 30.30 -> 30.23; profiles/r06_kernel_ab_during.txt)
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q));
       return make_uint4(v[0], v[1], v[2], v[3]);
