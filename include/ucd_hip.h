@@ -613,11 +613,25 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
  * this stream or ucd_conv_wgrad_flush(stream).  Deferral happens only while ucd_conv_wgrad_defer(1) is in force (returns the
  * previous setting; the gradient-bucket wrapper switches it on for its backward passes and flushes in front of its bucket copies);
  * ucd_conv_wgrad_flush launches the stream's pending sum, ucd_conv_wgrad_drop forgets it (an aborted backward).  The autograd
- * nodes of this library replace one launch per convolution of the reference's backward (modules/residual.py:67-73) this way. */
+ * nodes of this library replace one launch per convolution of the reference's backward (modules/residual.py:67-73) this way.
+ *
+ * SIDE STREAM (round 6, mode bit 1 / flags bit 1): nothing in a backward pass waits for a weight gradient before the optimiser, yet on
+ * the caller's stream each one sits in the chain of input-gradient products - ~190 of the ~850 dependent launches of a step, which at
+ * 3 - 6 images per GPU fill a quarter of the chip each.  Under ucd_conv_wgrad_defer(mode) with mode & 2, a call with flags & 2 runs
+ * on a stream owned by the library (lowest priority; UCD_WGRAD_STREAM_PRIO=normal: the default priority), forked behind `stream`
+ * and joined back into `stream` by ucd_conv_wgrad_flush(stream) / ucd_conv_wgrad_drop(stream); under stream capture fork and join
+ * become the graph's edges.  The accepted calls wait in a host-side queue and are launched in groups of UCD_WGRAD_STREAM_GROUP
+ * (default 32) behind ONE fork, or at the flush: a fork per call moves the caller's chain to another hardware queue each time and
+ * costs more than the overlap gains.  flags & 2 promises: dz, x, dw / dw32 and `workspace` stay allocated and untouched by other
+ * streams until that flush, `workspace` is not the one of a call without the flag, and dw is not read before the flush; an error
+ * of a launch made later is returned by the call that triggers it.  Results are the same bits either way (the same kernels on the
+ * same operands).
+ * ucd_conv_wgrad_defer(mode): bit 0 deferral, bit 1 side stream; returns the previous mode.  ucd_conv_wgrad_mode(): the mode. */
 int ucd_conv_wgrad_ex(const void* dz, int ld_dz, const void* x, int ld_x, int M, int N, int K, int taps, int H, int W, int dilation,
                       int stride, void* dw, float* dw32, int accumulate32, void* workspace, size_t workspace_bytes, int flags,
                       ucd_stream_t stream);
-int ucd_conv_wgrad_defer(int on);
+int ucd_conv_wgrad_defer(int mode);
+int ucd_conv_wgrad_mode(void);
 int ucd_conv_wgrad_flush(ucd_stream_t stream);
 int ucd_conv_wgrad_drop(ucd_stream_t stream);
 

@@ -1616,3 +1616,56 @@ def test_deferred_slab_sums_ride_in_the_next_weight_gradient_launch():
     hip.conv_wgrad(ops[0][0], ops[0][1], dw=d, conv3=ops[0][2], defer=True)
     torch.cuda.synchronize()
     assert torch.equal(d, ops[0][3])
+
+
+def test_weight_gradients_on_the_side_stream_of_the_library():
+    """C ABI of round 6's side stream (include/ucd_hip.h: ucd_conv_wgrad_ex flags bit 1 under ucd_conv_wgrad_defer(mode & 2)): the calls
+    are queued, launched in groups on a stream of the library behind one fork, and joined by ucd_conv_wgrad_flush - the gradients are
+    the bits of the plain calls; without the mode bit the flag changes nothing; a drop never launches what is still queued."""
+    from ucd_amd import hip
+    g = torch.Generator(DEV).manual_seed(11)
+    shapes = [(3267, 256, 1024, None), (3267, 256, 256, (33, 33, 2)), (3267, 1024, 256, None), (3267, 128, 128, (33, 33, 1)),
+              (3267, 512, 128, None)] * 3                                       # 15 calls
+    ops, want = [], []
+    for M, K, N, c3 in shapes:
+        dz = (torch.randn(M, N, device=DEV, generator=g) * 0.1).bfloat16()
+        x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+        ops.append((dz, x, c3))
+        want.append(hip.conv_wgrad(dz, x, dw=torch.empty(N, (9 if c3 else 1) * K, device=DEV, dtype=torch.bfloat16), conv3=c3).clone())
+    torch.cuda.synchronize()
+    lib = hip.load()
+
+    def run():
+        out = [torch.full_like(w, float("nan")) for w in want]
+        for (dz, x, c3), d in zip(ops, out):
+            hip.conv_wgrad(dz, x, dw=d, conv3=c3, defer=True, side=True)
+        return out
+
+    assert lib.ucd_conv_wgrad_mode() == 0
+    out = run()                                                                  # mode 0: plain calls, final at once
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(out, want))
+    assert hip.wgrad_defer(3) == 0
+    try:
+        assert lib.ucd_conv_wgrad_mode() == 3
+        out = run()
+        hip.wgrad_flush()                                                        # launches the rest of the queue, sums, joins
+        hip.transpose_bf16(out[-1][:64, :64].contiguous(), torch.empty(64, 64, device=DEV, dtype=torch.bfloat16))   # a reader on this stream
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, want))
+        # side stream without deferred sums
+        hip.wgrad_defer(2)
+        out = run()
+        hip.wgrad_flush()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(out, want))
+        # a drop: what waits in the queue is never launched (15 calls < one group of 32: nothing was)
+        hip.wgrad_defer(3)
+        out = run()
+        hip.wgrad_drop()
+        hip.wgrad_flush()
+        torch.cuda.synchronize()
+        assert all(bool(torch.isnan(a.float()).all()) for a in out)
+    finally:
+        hip.wgrad_drop()
+        assert hip.wgrad_defer(0) == 3

@@ -763,3 +763,30 @@ def test_deferred_weight_gradient_sums_change_no_bit_of_the_step():
         assert np.array_equal(la, lb), (sg, la, lb)
         for n in pa:
             assert torch.equal(pa[n], pb[n]), (sg, n)
+
+
+@pytest.mark.usefixtures("deterministic_stats")
+def test_weight_gradients_on_the_side_stream_change_no_bit_of_the_step():
+    """Round 6: between the wrapper's flushes the nodes' weight gradients run on a side stream of the library
+    (``UCD_WGRAD_STREAM``; include/ucd_hip.h ucd_conv_wgrad_ex flags bit 1: forked behind the compute stream at every call, joined in
+    front of the bucket copies) - off the chain of input-gradient products.  Same kernels on the same operands: scheduled iterations
+    with and without it end in bit-identical losses and parameters, eager and replayed from the step graph (fork and join are
+    captured as the graph's edges; an operand freed too early, a gradient read before the join or a workspace shared across the two
+    streams would all show here)."""
+    from ucd_amd import hip, switches
+    runs = {}
+    for side in ("0", "1"):
+        switches.set("UCD_WGRAD_STREAM", side)
+        try:
+            for sg in ("0", "1"):
+                runs[(side, sg)] = _scheduled_steps(sg, steps=5 if sg == "1" else 3)
+                assert hip.load().ucd_conv_wgrad_mode() == 0                  # finish() switched the mode off again
+        finally:
+            switches.unset("UCD_WGRAD_STREAM")
+    for sg in ("0", "1"):
+        (la, pa, ga, _, ea), (lb, pb, gb, _, eb) = runs[("0", sg)], runs[("1", sg)]
+        assert ea is None and eb is None, (ea, eb)
+        assert ga == gb and (sg == "0" or ga >= 1), (ga, gb)
+        assert np.array_equal(la, lb), (sg, la, lb)
+        for n in pa:
+            assert torch.equal(pa[n], pb[n]), (sg, n)

@@ -30,24 +30,40 @@ void check(int rc, const char* what) {
 std::mutex g_mu;
 std::map<std::pair<int, int64_t>, at::Tensor> g_ws;
 
+// Tensors that kernels on the library's SIDE stream (weight gradients, include/ucd_hip.h ucd_conv_wgrad_ex flags & 2) still read or
+// write: the caching allocator knows nothing of that stream, so the operands stay referenced here until the join
+// (wgrad_side_release, called behind ucd_conv_wgrad_flush / _drop) - a block freed on the compute stream before that could be handed
+// to a later kernel of that stream while the side stream is still reading it.
+std::vector<at::Tensor> g_side_hold;
+constexpr int kWsTags = 8;     // tags 0 / 1 scratch of the nodes, 2 / 3 slab workspaces in turn, 4 / 5 the same for side-stream calls
+
 void* workspace(const at::Tensor& like, size_t bytes, int64_t stream, int tag = 0) {
   std::lock_guard<std::mutex> lock(g_mu);
-  auto key = std::make_pair((int)like.get_device() * 4 + tag, stream);
+  auto key = std::make_pair((int)like.get_device() * kWsTags + tag, stream);
   auto it = g_ws.find(key);
   if (it == g_ws.end() || (size_t)it->second.numel() < bytes) {
     size_t n = bytes < ((size_t)1 << 20) ? ((size_t)1 << 20) : bytes;
+    if (it != g_ws.end() && tag >= 4) g_side_hold.push_back(it->second);     // the side stream may still be in the old buffer
     g_ws[key] = at::empty({(int64_t)n}, like.options().dtype(at::kByte));
     it = g_ws.find(key);
   }
   return it->second.data_ptr();
 }
 
+void wgrad_side_release() {
+  std::vector<at::Tensor> gone;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    gone.swap(g_side_hold);
+  }
+}   // the tensors are released outside the lock
+
 // test hook (tests/diag/poison_step_diag.py): fill every cached scratch buffer with a byte pattern - a kernel that reads scratch it has
 // not written shows up as a changed (or NaN) result
 void poison_workspaces(int64_t byte, int64_t tag) {
   std::lock_guard<std::mutex> lock(g_mu);
   for (auto& kv : g_ws)
-    if (tag < 0 || kv.first.first % 4 == tag) kv.second.fill_(byte);
+    if (tag < 0 || kv.first.first % kWsTags == tag) kv.second.fill_(byte);
 }
 
 // ---- statistics arena (round 5) ----------------------------------------------------------------------------------------------------
@@ -145,14 +161,29 @@ bool own_wgrad_ok(const at::Tensor& dz, const at::Tensor& x, const at::Tensor& w
 // weight-gradient launch of the stream (ucd_conv_wgrad_ex, flags bit 0: the gradient goes to AccumulateGrad and is first read by the
 // bucket copies, in front of which ucd_amd/ddp.py flushes) - so a call's slabs must outlive the NEXT call: two scratch buffers, taken
 // in turn.
-void* wgrad_workspace(const at::Tensor& like, size_t bytes, int64_t stream) {
-  static std::map<std::pair<int, int64_t>, int> turn;   // per (device, stream): the pending sum is per stream too
+void* wgrad_workspace(const at::Tensor& like, size_t bytes, int64_t stream, bool side) {
+  static std::map<std::pair<int, int64_t>, int> turn;   // per (device, stream, side): the pending sum is per stream too
   int tag;
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    tag = 2 + (turn[std::make_pair((int)like.get_device(), stream)] ^= 1);
+    tag = (side ? 4 : 2) + (turn[std::make_pair((int)like.get_device() * 2 + (side ? 1 : 0), stream)] ^= 1);
   }
   return workspace(like, bytes, stream, tag);
+}
+
+// flags of a node's weight-gradient call (ucd_conv_wgrad_ex): bit 0 the slab sum may wait, bit 1 the call may leave the compute
+// stream - both only for a gradient nothing reads before the wrapper's flush (sum_may_wait below); with bit 1 in force the operands
+// are held until that flush
+int sum_may_wait(const at::Tensor& w4);
+int wgrad_flags(const at::Tensor& w4, bool* side) {
+  *side = false;
+  if (!sum_may_wait(w4)) return 0;
+  *side = (ucd_conv_wgrad_mode() & 2) != 0;
+  return *side ? 3 : 1;
+}
+void hold_for_side(std::initializer_list<at::Tensor> ts) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  for (const auto& t : ts) g_side_hold.push_back(t);
 }
 
 // May the slab sum of this weight gradient wait for the next weight-gradient launch?  Only when nothing reads the gradient before the
@@ -167,9 +198,12 @@ at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor
   const int taps = dilation > 0 ? 9 : 1;
   at::Tensor dw = at::empty({N, taps == 9 ? 3 : 1, taps == 9 ? 3 : 1, K}, x.options().memory_format(c10::nullopt));
   const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)N, (int)K, taps);
+  bool side;
+  const int flags = wgrad_flags(w4, &side);
+  if (side) hold_for_side({dz, x, dw});
   check(ucd_conv_wgrad_ex(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
                           (int)(dilation > 0 ? dilation : 1), (int)stride, dw.data_ptr(), nullptr, 0,
-                          wgrad_workspace(x, wsb, stream), wsb, sum_may_wait(w4), (ucd_stream_t)stream),
+                          wgrad_workspace(x, wsb, stream, side), wsb, flags, (ucd_stream_t)stream),
         "ucd_conv_wgrad");
   return dw.permute({0, 3, 1, 2});      // [N, K, kh, kw] with channels-last strides: the weight's own memory order
 }
@@ -283,8 +317,11 @@ at::Tensor own_wgrad_rows(const at::Tensor& dy, const at::Tensor& rows, int64_t 
   const int64_t M = rows.size(0), Ci = rows.size(1), Co = dy.size(1);
   at::Tensor dw = at::empty({Co, Ci}, rows.options());
   const size_t wsb = ucd_conv_wgrad_workspace_bytes((int)M, (int)Co, (int)Ci, 1);
+  bool side;
+  const int flags = wgrad_flags(w4, &side);
+  if (side) hold_for_side({dy, rows, dw});
   check(ucd_conv_wgrad_ex(dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, (int)M, (int)Co, (int)Ci, 1, 0, 0, 1, 1, dw.data_ptr(), nullptr, 0,
-                          wgrad_workspace(rows, wsb, stream), wsb, sum_may_wait(w4), (ucd_stream_t)stream),
+                          wgrad_workspace(rows, wsb, stream, side), wsb, flags, (ucd_stream_t)stream),
         "ucd_conv_wgrad");
   return dw;
 }
@@ -1016,6 +1053,7 @@ at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::opti
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node of the training-mode ABN layer over libucd_hip.so";
   m.def("poison_workspaces", &poison_workspaces);
+  m.def("wgrad_side_release", &wgrad_side_release, "drop the operands held for the side stream of the weight gradients (after the join)");
   m.def("stat_arena_reset", &stat_arena_reset, "zero the used part of the statistics arena of a device and start a new generation");
   m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
   m.def("dense_channels_last", &dense_channels_last);

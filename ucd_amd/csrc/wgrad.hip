@@ -24,6 +24,7 @@
 // Workgroup -> work: all tiles and taps of one row chunk sit on one XCD (ids congruent mod 8 share an L2), so a chunk's rows
 // of dZ and X leave HBM once and are re-read by its tiles from that L2.
 #include <map>
+#include <vector>
 #include <mutex>
 #include <type_traits>
 
@@ -730,8 +731,8 @@ bool wgrad3_enabled() {
 }
 
 // ---- deferred slab sums: host state (see SumArgs above) ---------------------------------------------------------------------------
-// One pending sum per stream; ucd_conv_wgrad_ex(flags & 1) under ucd_conv_wgrad_defer(1) leaves its sum pending and carries the
-// previous one of that stream in its launch.
+// One pending sum per stream; ucd_conv_wgrad_ex(flags & 1) under ucd_conv_wgrad_defer(mode & 1) leaves its sum pending and carries the
+// previous one of that stream in its launch.  g_defer holds the mode: bit 0 deferral, bit 1 the side stream (below).
 std::mutex g_pend_mu;
 std::map<hipStream_t, SumArgs> g_pend;
 int g_defer = 0;
@@ -752,6 +753,119 @@ SumArgs take_pending(hipStream_t s) {
   auto it = g_pend.find(s);
   if (it != g_pend.end()) { q = it->second; g_pend.erase(it); }
   return q;
+}
+
+// ---- side stream (round 6) ----------------------------------------------------------------------------------------------------------
+// Nothing in the backward pass waits for a weight gradient before the optimiser, but on the caller's stream every one of them sits in
+// the chain of input-gradient products: at 3 - 6 images per GPU (the per-rank batch of the 8-GPU run) a step is ~850 launches of
+// ~10 us, each waiting for the one before, on a chip the small launches fill to a quarter.  A call that allows it (flags & 2, mode
+// bit 1) runs on a stream of the library instead: forked behind the caller's stream at the call (the operands are ready there),
+// joined back by ucd_conv_wgrad_flush / _drop.  Under stream capture the fork and the join become the graph's edges.  The caller
+// keeps dz, x, dw and the workspace alive until the join and does not touch dw before it.
+//
+// A fork costs the CALLER's chain: in a replayed graph ROCm continues the chain on another hardware queue behind every fork point
+// (kernel trace: runs of 2 - 4 kernels alternating between two queues) and each hop waits for a cross-queue signal, ~8 us - one
+// fork per call made the 3-image step 0.4 ms SLOWER.  So the calls wait in a host-side queue and go out in groups
+// (UCD_WGRAD_STREAM_GROUP, default 32) behind ONE fork, recorded when the group's last operand exists: 9.05 -> 8.50 ms at 3 images,
+// 30.1 -> 29.3 ms at 24 (profiles/r06_side_stream.md; groups of 16 - 64 are level, everything in one group gains nothing).
+struct ExArgs {
+  const void* dz; int ld_dz; const void* x; int ld_x; int M, N, K, taps, H, W, dilation, stride;
+  void* dw; float* dw32; int accumulate32; void* workspace; size_t workspace_bytes; int flags;
+};
+bool wgrad_three(const ExArgs& q, int oW, int oH);
+int wgrad_launch_on(const ExArgs& q, hipStream_t s);
+
+struct Side {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool active = false;      // work since the last join
+  std::vector<ExArgs> queue;   // accepted calls not launched yet
+};
+int side_group() {
+  static const int g = [] { const char* e = getenv("UCD_WGRAD_STREAM_GROUP"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();
+  return g;
+}
+std::map<hipStream_t, Side> g_side;     // by the caller's stream; under g_pend_mu
+
+// the side stream of `main`, forked behind its current position; nullptr (with the error set) when HIP refuses
+hipStream_t side_fork(hipStream_t main, const char* fn) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  Side& sd = g_side[main];
+  if (!sd.s) {
+    int least = 0, greatest = 0;
+    const char* e = getenv("UCD_WGRAD_STREAM_PRIO");
+    const bool low = !(e && e[0] == 'n');                 // "normal": the caller's priority; default: the lowest (the chain goes first)
+    hipStream_t st = nullptr;
+    hipEvent_t f = nullptr, j = nullptr;
+    bool ok = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+              hipStreamCreateWithPriority(&st, hipStreamNonBlocking, low ? least : 0) == hipSuccess &&
+              hipEventCreateWithFlags(&f, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&j, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      set_error("%s: cannot create the side stream of the weight gradients", fn);
+      return nullptr;
+    }
+    sd.s = st; sd.fork = f; sd.join = j;
+  }
+  if (hipEventRecord(sd.fork, main) != hipSuccess || hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: cannot fork the side stream behind the caller's", fn);
+    return nullptr;
+  }
+  sd.active = true;
+  return sd.s;
+}
+// the side stream of `main` when it holds work since the last join, else nullptr
+hipStream_t side_active(hipStream_t main) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  auto it = g_side.find(main);
+  return it != g_side.end() && it->second.active ? it->second.s : nullptr;
+}
+int side_join(hipStream_t main, const char* fn) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  auto it = g_side.find(main);
+  if (it == g_side.end() || !it->second.active) return 0;
+  it->second.active = false;
+  if (hipEventRecord(it->second.join, it->second.s) != hipSuccess || hipStreamWaitEvent(main, it->second.join, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("%s: cannot join the side stream of the weight gradients", fn);
+    return (int)hipErrorUnknown;
+  }
+  return 0;
+}
+
+// launch the queued calls of `main` on its side stream behind one fork
+int side_drain(hipStream_t main, const char* fn) {
+  std::vector<ExArgs> todo;
+  {
+    std::lock_guard<std::mutex> lock(g_pend_mu);
+    auto it = g_side.find(main);
+    if (it == g_side.end() || it->second.queue.empty()) return 0;
+    todo.swap(it->second.queue);
+  }
+  hipStream_t sd = side_fork(main, fn);
+  if (!sd) return (int)hipErrorUnknown;
+  for (const ExArgs& q : todo) {
+    const int rc = wgrad_launch_on(q, sd);
+    if (rc) return rc;
+  }
+  return 0;
+}
+int side_enqueue(hipStream_t main, const ExArgs& q, const char* fn) {
+  size_t n;
+  {
+    std::lock_guard<std::mutex> lock(g_pend_mu);
+    Side& sd = g_side[main];
+    sd.queue.push_back(q);
+    n = sd.queue.size();
+  }
+  return n >= (size_t)side_group() ? side_drain(main, fn) : 0;
+}
+void side_forget(hipStream_t main) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  auto it = g_side.find(main);
+  if (it != g_side.end()) it->second.queue.clear();
 }
 
 int plan_target(int N, int K, int taps) {
@@ -790,23 +904,49 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
                            stream);
 }
 
-int ucd_conv_wgrad_defer(int on) {
+int ucd_conv_wgrad_defer(int mode) {
   std::lock_guard<std::mutex> lock(g_pend_mu);
   const int was = g_defer;
-  g_defer = on ? 1 : 0;
+  g_defer = mode & 3;
   return was;
+}
+
+int ucd_conv_wgrad_mode(void) {
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  return g_defer;
 }
 
 int ucd_conv_wgrad_flush(ucd_stream_t stream) {
   static const char* fn = "ucd_conv_wgrad_flush";
-  const SumArgs q = take_pending((hipStream_t)stream);
+  const hipStream_t main = (hipStream_t)stream;
+  {
+    const int rc = side_drain(main, fn);               // calls still waiting for their group
+    if (rc) return rc;
+  }
+  if (hipStream_t sd = side_active(main)) {            // the side stream: its pending sum, then the join
+    const SumArgs q = take_pending(sd);
+    if (q.blocks > 0) {
+      wgrad_sum_kernel<<<q.blocks, kThreads, 0, sd>>>(q);
+      const int rc = check_launch(fn);
+      if (rc) { (void)side_join(main, fn); return rc; }
+    }
+    const int rc = side_join(main, fn);
+    if (rc) return rc;
+  }
+  const SumArgs q = take_pending(main);
   if (q.blocks <= 0) return 0;
-  wgrad_sum_kernel<<<q.blocks, kThreads, 0, (hipStream_t)stream>>>(q);
+  wgrad_sum_kernel<<<q.blocks, kThreads, 0, main>>>(q);
   return check_launch(fn);
 }
 
 int ucd_conv_wgrad_drop(ucd_stream_t stream) {
-  (void)take_pending((hipStream_t)stream);
+  const hipStream_t main = (hipStream_t)stream;
+  (void)take_pending(main);
+  side_forget(main);                                   // calls not launched yet never are
+  if (hipStream_t sd = side_active(main)) {            // launched work cannot be taken back: join it (a capture must not end forked)
+    (void)take_pending(sd);
+    return side_join(main, "ucd_conv_wgrad_drop");
+  }
   return 0;
 }
 
@@ -829,18 +969,52 @@ int ucd_conv_wgrad_ex(const void* dz, int ld_dz, const void* x, int ld_x, int M,
   UCD_REQUIRE(aligned16(dz) && aligned16(x) && (!dw || aligned16(dw)) && (!dw32 || aligned16(dw32)) && ld_dz % 8 == 0 && ld_x % 8 == 0 &&
                   ld_dz >= N && ld_x >= K,
               UCD_EALIGN, "%s: operands must be 16-byte aligned with leading dimensions that are multiples of 8", fn);
+  ExArgs q{dz, ld_dz, x, ld_x, M, N, K, taps, H, W, dilation, stride, dw, dw32, accumulate32, workspace, workspace_bytes, flags};
+  {
+    // enough workspace?  (checked here, at the call, also for a launch that waits in the side stream's queue)
+    Plan pl = make_plan(M, N, K, taps, plan_target(N, K, taps));
+    int chunks = pl.chunks;
+    if (wgrad_three(q, oW, oH)) chunks = make_plan3(M, N, K).chunks;
+    UCD_REQUIRE(workspace_bytes >= (size_t)chunks * N * taps * K * sizeof(float), UCD_EWORKSPACE, "%s: workspace too small", fn);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if ((flags & 2) && (ucd_conv_wgrad_mode() & 2)) return side_enqueue(s, q, fn);      // off the caller's chain (see Side above)
+  return wgrad_launch_on(q, s);
+}
+
+}  // extern "C"
+
+namespace ucd {
+namespace {
+
+bool wgrad_three(const ExArgs& q, int oW, int oH) {
+  (void)oH;
+  // the three-tap form (wgrad3_kernel): 3x3, stride 1, 128-aligned channels, an X tile of 64 + 2 d rows in 128 LDS rows, maps on
+  // which a 64-row step wraps at most one image row at a time
+  return q.taps == 9 && q.stride <= 1 && q.N % 128 == 0 && q.K % 128 == 0 && q.dilation <= 18 && q.dilation < q.W && kRows / q.W + 1 <= q.H &&
+         q.M >= 8192 && wgrad3_enabled();      // (small maps, 3 images per GPU: level with the 9-tap form or behind it)
+}
+
+int wgrad_launch_on(const ExArgs& q, hipStream_t s) {
+  static const char* fn = "ucd_conv_wgrad";
+  const void *dz = q.dz, *x = q.x;
+  void *dw = q.dw, *workspace = q.workspace;
+  float* dw32 = q.dw32;
+  const int ld_dz = q.ld_dz, ld_x = q.ld_x, M = q.M, N = q.N, K = q.K, taps = q.taps, H = q.H, W = q.W, dilation = q.dilation,
+            stride = q.stride, accumulate32 = q.accumulate32, flags = q.flags;
+  const bool str = stride > 1;
+  const int oH = str && H > 0 ? (H - 1) / stride + 1 : H, oW = str && W > 0 ? (W - 1) / stride + 1 : W;
+  const long long x_rows = str ? (long long)(M / (oH * oW)) * H * W : M;
   Plan pl = make_plan(M, N, K, taps, plan_target(N, K, taps));
   const size_t total = (size_t)N * taps * K;
   // the three-tap form (wgrad3_kernel): 3x3, stride 1, 128-aligned channels, an X tile of 64 + 2 d rows in 128 LDS rows, maps on
   // which a 64-row step wraps at most one image row at a time
-  const bool three = taps == 9 && !str && N % 128 == 0 && K % 128 == 0 && dilation <= 18 && dilation < W && kRows / W + 1 <= H &&
-                     M >= 8192 && wgrad3_enabled();      // (small maps, 3 images per GPU: level with the 9-tap form or behind it)
+  const bool three = wgrad_three(q, oW, oH);
   Plan3 p3{0, 0, 0, 0, 1};
   if (three) {
     p3 = make_plan3(M, N, K);
     pl.chunks = p3.chunks;
   }
-  UCD_REQUIRE(workspace_bytes >= (size_t)pl.chunks * total * sizeof(float), UCD_EWORKSPACE, "%s: workspace too small", fn);
   WArgs a;
   a.dZ = (const bf16*)dz; a.ldz = ld_dz; a.X = (const bf16*)x; a.ldx = ld_x;
   a.M = M; a.N = N; a.K = K; a.taps = taps; a.H = (taps == 9 || str) ? H : 1; a.W = (taps == 9 || str) ? W : M; a.dil = dilation;
@@ -853,7 +1027,6 @@ int ucd_conv_wgrad_ex(const void* dz, int ld_dz, const void* x, int ld_x, int M,
   const int per_group = pl.tiles_n * (pl.tiles_k / pl.ksplit) * taps;
   const int grid = ceil_div(groups, 8) * 8 * per_group;
   const size_t lds = (size_t)2 * kRows * (pl.bno + pl.bko) * 2;
-  hipStream_t s = (hipStream_t)stream;
   // the pending slab sum of this stream (a deferred earlier call) rides behind this launch's own workgroups; this call's own sum
   // is left pending when the caller allows it (flags & 1) and deferral is on, else launched right behind the product
   const SumArgs pend = take_pending(s);
@@ -897,7 +1070,7 @@ int ucd_conv_wgrad_ex(const void* dz, int ld_dz, const void* x, int ld_x, int M,
   bool defer;
   {
     std::lock_guard<std::mutex> lock(g_pend_mu);
-    defer = g_defer && (flags & 1);
+    defer = (g_defer & 1) && (flags & 1);
     if (defer) g_pend[s] = mine;
   }
   if (defer) return 0;
@@ -905,4 +1078,5 @@ int ucd_conv_wgrad_ex(const void* dz, int ld_dz, const void* x, int ld_x, int M,
   return check_launch(fn);
 }
 
-}  // extern "C"
+}  // namespace
+}  // namespace ucd

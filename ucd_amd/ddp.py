@@ -224,7 +224,11 @@ class GradReducer:
         from . import hip
         if on:
             hip.wgrad_drop()                                    # of a backward that never finished
-        hip.wgrad_defer(on)
+        # bit 1: the nodes' weight gradients leave the compute stream for the library's side stream until the next flush (include/
+        # ucd_hip.h) - nothing waits for them before the bucket copies, and off the chain of input-gradient products they cost the
+        # small-batch step (3 - 6 images per GPU) a fifth of its dependent launches less
+        side = 2 if _switches.get("UCD_WGRAD_STREAM", "1") != "0" else 0
+        hip.wgrad_defer((1 | side) if on else 0)
 
     def _wgrad_flush(self):
         if self.on_gpu and _switches.get("UCD_WGRAD_DEFER", "1") != "0":
@@ -288,6 +292,7 @@ class GradReducer:
             for _, holder in b.fed:
                 holder.grad = None
         if self.collective:
+            self._wgrad_flush()                                  # (no-op after the one above) a bucket's reduction never starts forked
             self._launch(b)
 
     def _event(self, key):

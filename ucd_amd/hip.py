@@ -125,6 +125,7 @@ SIGNATURES = {
     "ucd_conv_wgrad_strided": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _p]),
     "ucd_conv_wgrad_ex": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _z, _i, _p]),
     "ucd_conv_wgrad_defer": (_i, [_i]),
+    "ucd_conv_wgrad_mode": (_i, []),
     "ucd_conv_wgrad_flush": (_i, [_p]),
     "ucd_conv_wgrad_drop": (_i, [_p]),
     "ucd_transpose_bf16": (_i, [_p, _i, _i, _p, _p]),
@@ -681,25 +682,41 @@ def stem_pool_backward(z, dpool, idx, mean, invstd, scale, beta, weight, sums, c
                                           int(phase), stream()), "ucd_stem_pool_backward")
 
 
-def wgrad_defer(on):
-    """Switch the deferral of weight-gradient slab sums (``ucd_conv_wgrad_defer``); returns the previous setting."""
-    return int(load().ucd_conv_wgrad_defer(1 if on else 0))
+def wgrad_defer(mode):
+    """Mode of the weight-gradient calls that allow it (``ucd_conv_wgrad_defer``): bit 0 (or True) defers their slab sums into the
+    next launch, bit 1 moves them to the library's side stream until ``wgrad_flush``; returns the previous mode."""
+    return int(load().ucd_conv_wgrad_defer(int(mode) & 3))
+
+
+def _wgrad_side_release():
+    # the C++ nodes hold the operands of their side-stream calls until the join (csrc/abn_node.cpp: g_side_hold)
+    from . import abn as _abn
+    node = _abn._abn_node()
+    if node is not None and hasattr(node, "wgrad_side_release"):
+        node.wgrad_side_release()
 
 
 def wgrad_flush():
-    """Launch the pending slab sum of the current stream, if any (``ucd_conv_wgrad_flush``)."""
-    _check(load().ucd_conv_wgrad_flush(stream()), "ucd_conv_wgrad_flush")
+    """Launch the pending slab sum of the current stream, if any, and join the side stream of the weight gradients back into it
+    (``ucd_conv_wgrad_flush``)."""
+    try:
+        _check(load().ucd_conv_wgrad_flush(stream()), "ucd_conv_wgrad_flush")
+    finally:
+        _wgrad_side_release()
 
 
 def wgrad_drop():
-    """Forget the pending slab sum of the current stream (an aborted backward)."""
-    load().ucd_conv_wgrad_drop(stream())
+    """Forget the pending slab sum of the current stream (an aborted backward); side-stream work already launched is joined."""
+    try:
+        load().ucd_conv_wgrad_drop(stream())
+    finally:
+        _wgrad_side_release()
 
 
 _wgrad_turn = {}
 
 
-def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, strided=None, defer=False):
+def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, strided=None, defer=False, side=False):
     """Weight gradient of a stride-1 convolution (ucd_conv_wgrad): ``dz`` [M, N] and ``x`` [M, K] bf16 row matrices ->
     ``dw`` [N, taps * K] bf16 (channels-last weight order [N][kh][kw][K]) and / or ``dw32`` fp32 (+= when ``accumulate32``);
     ``conv3 = (H, W, dilation)`` selects the 3x3 form over the [B, H, W, K] map behind ``x``; ``conv3 = (H, W, dilation, stride)`` /
@@ -717,14 +734,18 @@ def conv_wgrad(dz, x, dw=None, conv3=None, dw32=None, accumulate32=False, stride
     nbytes = lib.ucd_conv_wgrad_workspace_bytes(M, N, K, taps)
     # ``defer``: the caller does not read the gradient before the next weight-gradient call or wgrad_flush() - the library may then
     # carry this call's slab sum in the next launch (two slab buffers in turn: a call's slabs outlive the next call)
-    key = (dz.device.index, stream())
+    # ``side`` (with ``defer``): the call may also leave the current stream for the library's side stream until wgrad_flush() - the
+    # caller keeps dz, x and the gradient alive and untouched until then (slab buffers of their own: never shared across streams)
+    side = bool(side and defer)
+    key = (dz.device.index, stream(), side)
     _wgrad_turn[key] = _wgrad_turn.get(key, 0) ^ 1
-    ws = workspace(nbytes, dz.device, "wgrad%d" % _wgrad_turn[key])
+    ws = workspace(nbytes, dz.device, "wgrad%s%d" % ("side" if side else "", _wgrad_turn[key]))
     # MFMA-bound for the 3x3 layers, HBM / L2-bound for the 1x1 layers: flop for one, algorithmic bytes for the other
     work = 2 * M * 9 * K * N if conv3 is not None else 2 * (M * N + M * K)
     with _timed("ucd_conv3x3_wgrad" if conv3 is not None else "ucd_conv1x1_wgrad", work):
         _check(lib.ucd_conv_wgrad_ex(ptr(dz), dz.stride(0), ptr(x), x.stride(0), M, N, K, taps, H, W, d, stride, ptr(dw),
-                                     ptr(dw32), 1 if accumulate32 else 0, ptr(ws), nbytes, 1 if defer else 0, stream()), "ucd_conv_wgrad")
+                                     ptr(dw32), 1 if accumulate32 else 0, ptr(ws), nbytes, (1 if defer else 0) | (2 if side else 0), stream()),
+               "ucd_conv_wgrad")
     return dw if dw is not None else dw32
 
 
