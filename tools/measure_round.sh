@@ -8,6 +8,7 @@ brief() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().spli
 (for gb in 24 12 6 3; do for sg in auto 0; do UCD_STEP_GRAPH=$sg timeout 300 python bench.py --steps 16 --warmup 6 --global_batch $gb --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "global_batch $gb UCD_STEP_GRAPH=$sg"; done; done) > $O/small_batch.txt 2>&1
 # A/B of this round's switches on this box (alternating, two repetitions)
 (for rep in 1 2; do
+  for gb in 24 6 3; do for v in 0 1; do UCD_WGRAD_STREAM=$v timeout 300 python bench.py --steps 20 --warmup 6 --global_batch $gb --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "rep $rep $gb images UCD_WGRAD_STREAM=$v"; done; done
   for v in 0 1; do UCD_WGRAD_DEFER=$v timeout 300 python bench.py --steps 20 --warmup 6 --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "rep $rep 24 images UCD_WGRAD_DEFER=$v"; done
   for v in 0 1; do UCD_WGRAD_DEFER=$v timeout 300 python bench.py --steps 20 --warmup 6 --global_batch 3 --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "rep $rep 3 images UCD_WGRAD_DEFER=$v"; done
   for v in 0 128; do UCD_CONV_LW64_TILES=$v timeout 300 python bench.py --steps 20 --warmup 6 --global_batch 3 --no_cpu_baseline --no_kernel_timing 2>/dev/null | brief "rep $rep 3 images UCD_CONV_LW64_TILES=$v"; done

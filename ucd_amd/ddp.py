@@ -197,7 +197,7 @@ class GradReducer:
         mid-backward): their sources are tensors of a pass that did not complete - flushed together with the next step's copies they
         would land in the same bucket views in one multi-tensor launch, in undefined order."""
         self._late_dst, self._late_src = [], []
-        if self.on_gpu and _switches.get("UCD_WGRAD_DEFER", "1") != "0":
+        if self._wgrad_mode():
             from . import hip
             hip.wgrad_drop()                                    # ... nor the slab sum its last weight gradient left pending
 
@@ -219,7 +219,8 @@ class GradReducer:
         """Deferred slab sums of the weight gradients (csrc/wgrad.hip, round 6): on for the backward pass of a step of this wrapper -
         the nodes' weight gradients are first READ by the bucket copies, and ``_wgrad_flush`` runs in front of those - off again in
         ``finish`` (a bare ``backward()`` outside the wrapper sums at once).  ``UCD_WGRAD_DEFER=0`` keeps the separate launches."""
-        if not self.on_gpu or _switches.get("UCD_WGRAD_DEFER", "1") == "0":
+        mode = self._wgrad_mode()
+        if not mode:
             return
         from . import hip
         if on:
@@ -227,11 +228,17 @@ class GradReducer:
         # bit 1: the nodes' weight gradients leave the compute stream for the library's side stream until the next flush (include/
         # ucd_hip.h) - nothing waits for them before the bucket copies, and off the chain of input-gradient products they cost the
         # small-batch step (3 - 6 images per GPU) a fifth of its dependent launches less
-        side = 2 if _switches.get("UCD_WGRAD_STREAM", "1") != "0" else 0
-        hip.wgrad_defer((1 | side) if on else 0)
+        hip.wgrad_defer(mode if on else 0)
+
+    def _wgrad_mode(self):
+        """ucd_conv_wgrad_defer's mode for this wrapper's backward passes: bit 0 deferred slab sums, bit 1 the side stream."""
+        if not self.on_gpu:
+            return 0
+        return ((1 if _switches.get("UCD_WGRAD_DEFER", "1") != "0" else 0)
+                | (2 if _switches.get("UCD_WGRAD_STREAM", "1") != "0" else 0))
 
     def _wgrad_flush(self):
-        if self.on_gpu and _switches.get("UCD_WGRAD_DEFER", "1") != "0":
+        if self._wgrad_mode():
             from . import hip
             hip.wgrad_flush()
 
