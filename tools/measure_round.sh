@@ -29,6 +29,13 @@ cd /tmp && export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_kernel_timing > /tmp/prof.log 2>&1
 python $R/tools/trace_summary.py /tmp/prof/t_kernel_trace.csv $O/step_kernel_summary_final.txt "timeout 400 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 2 (round 6; the timed steps are replays of the captured step graph)" > /dev/null
 head -40 /tmp/prof/t_kernel_stats.csv > $O/kernel_stats_final.csv
+# the same with nothing overlapping (no side stream for the weight gradients, teacher in front of the student): the durations of the
+# kernels running ALONE - what bench.py's per-call table and the roofline are measured on
+export UCD_WGRAD_STREAM=0 UCD_TEACHER_OVERLAP=0
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/profs -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --no_cpu_baseline --no_kernel_timing > /tmp/profs.log 2>&1
+unset UCD_WGRAD_STREAM UCD_TEACHER_OVERLAP
+python $R/tools/trace_summary.py /tmp/profs/t_kernel_trace.csv $O/step_kernel_summary_serial.txt "UCD_WGRAD_STREAM=0 UCD_TEACHER_OVERLAP=0 rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 2 (nothing overlaps: kernel durations alone)" > /dev/null
+head -40 /tmp/profs/t_kernel_stats.csv > $O/kernel_stats_serial.csv
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof3 -o t --output-format csv -- python3 $R/bench.py --steps 3 --warmup 2 --global_batch 3 --no_cpu_baseline --no_kernel_timing > /tmp/prof3.log 2>&1
 python $R/tools/trace_summary.py /tmp/prof3/t_kernel_trace.csv $O/step_kernel_summary_b3.txt "same, --global_batch 3 (per-rank batch of the 8-GPU run)" > /dev/null
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf -o f --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_kernel_timing > /tmp/pf.log 2>&1
