@@ -314,6 +314,10 @@ def main():
                 if dt2 < dt:
                     dt, graphed = dt2, True
     last = {k: float(v) for k, v in trainer.last.items()}
+    # device memory of this rank up to the end of the timed phases (the instrumented pass and the CPU baseline come later): the
+    # captured step's pool included; the weight gradients' side stream keeps every layer's dZ until its join
+    memory = {"peak_allocated_gb": round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 2),
+              "peak_reserved_gb": round(torch.cuda.max_memory_reserved(device) / 2 ** 30, 2)}
     # how the timed iterations actually ran: a silent fallback (capture failed, a kernel family switched off) is visible here
     execution = {"step_graph": bool(graphed),
                  "step_graph_error": trainer.step_graph_error,
@@ -408,7 +412,7 @@ def main():
                                    f"({per_rank}/GPU), random-init weights via a synthetic step-0 checkpoint",
                        "parallelism": f"dp{world}", "opt_level": args.opt_level,
                        "contrastive_dtype": trainer.pixcon_precision},
-            "losses": last, "execution": execution, "own_kernels": own_kernels,
+            "losses": last, "execution": execution, "memory": memory, "own_kernels": own_kernels,
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
             # what the per-call table (`kernels`, `roofline.achieved`) was measured on: NOT the timed configuration itself
             "kernel_table_config": ("instrumented eager pass after the timed region: HIP events around every C-ABI call, Python twins of "
