@@ -620,9 +620,10 @@ int ucd_conv_wgrad_strided(const void* dz, int ld_dz, const void* x, int ld_x, i
  * 3 - 6 images per GPU fill a quarter of the chip each.  Under ucd_conv_wgrad_defer(mode) with mode & 2, a call with flags & 2 runs
  * on a stream owned by the library (lowest priority; UCD_WGRAD_STREAM_PRIO=normal: the default priority), forked behind `stream`
  * and joined back into `stream` by ucd_conv_wgrad_flush(stream) / ucd_conv_wgrad_drop(stream); under stream capture fork and join
- * become the graph's edges.  The accepted calls wait in a host-side queue and are launched in groups of UCD_WGRAD_STREAM_GROUP
- * (default 32) behind ONE fork, or at the flush: a fork per call moves the caller's chain to another hardware queue each time and
- * costs more than the overlap gains.  flags & 2 promises: dz, x, dw / dw32 and `workspace` stay allocated and untouched by other
+ * become the graph's edges.  An accepted call records its fork point on `stream` at once, its launches go out at the NEXT accepted
+ * call or at the flush: in a replayed graph the branch created first keeps the fork point's hardware queue and the other one hops
+ * behind a cross-queue signal - launched at the fork, the weight gradients make the CALLER's chain the one that hops, ~8 us per
+ * call (UCD_WGRAD_STREAM_LATE=0; UCD_WGRAD_STREAM_GROUP=n: n calls per fork point).  flags & 2 promises: dz, x, dw / dw32 and `workspace` stay allocated and untouched by other
  * streams until that flush, `workspace` is not the one of a call without the flag, and dw is not read before the flush; an error
  * of a launch made later is returned by the call that triggers it.  Results are the same bits either way (the same kernels on the
  * same operands).

@@ -763,11 +763,15 @@ SumArgs take_pending(hipStream_t s) {
 // joined back by ucd_conv_wgrad_flush / _drop.  Under stream capture the fork and the join become the graph's edges.  The caller
 // keeps dz, x, dw and the workspace alive until the join and does not touch dw before it.
 //
-// A fork costs the CALLER's chain: in a replayed graph ROCm continues the chain on another hardware queue behind every fork point
-// (kernel trace: runs of 2 - 4 kernels alternating between two queues) and each hop waits for a cross-queue signal, ~8 us - one
-// fork per call made the 3-image step 0.4 ms SLOWER.  So the calls wait in a host-side queue and go out in groups
-// (UCD_WGRAD_STREAM_GROUP, default 32) behind ONE fork, recorded when the group's last operand exists: 9.05 -> 8.50 ms at 3 images,
-// 30.1 -> 29.3 ms at 24 (profiles/r06_side_stream.md; groups of 16 - 64 are level, everything in one group gains nothing).
+// A fork can cost the CALLER's chain: in a replayed graph ROCm keeps the branch whose first node was created FIRST on the hardware
+// queue of the fork point and continues the other branch on another queue, behind a cross-queue signal (~8 us).  Launching the side
+// work right at the fork makes the caller's chain the branch that hops (kernel trace: runs of 2 - 4 kernels alternating between two
+// queues, all weight gradients on the original one): one fork per call made the 3-image step 0.4 ms SLOWER, groups of 32 calls
+// per fork 0.5 ms faster.  The form kept: the call only RECORDS its fork point on the caller's stream; the launches go out at the
+// NEXT accepted call (or the flush), by when the caller has created its chain's next nodes - the weight gradients are the branch
+// that hops, and nothing waits for them: 3 images 8.95 -> 7.95 ms, 6 images 12.0 -> 10.65, 24 images 28.95 -> 28.45
+// (profiles/r06_side_stream.md).  UCD_WGRAD_STREAM_GROUP (default 1) calls share a fork point, UCD_WGRAD_STREAM_LATE=0 launches at
+// the fork (the slower forms, kept for the A/B).
 struct ExArgs {
   const void* dz; int ld_dz; const void* x; int ld_x; int M, N, K, taps, H, W, dilation, stride;
   void* dw; float* dw32; int accumulate32; void* workspace; size_t workspace_bytes; int flags;
@@ -780,15 +784,21 @@ struct Side {
   hipEvent_t fork = nullptr, join = nullptr;
   bool active = false;      // work since the last join
   std::vector<ExArgs> queue;   // accepted calls not launched yet
+  std::vector<ExArgs> armed;   // a full group whose fork point is recorded, launched at the next call (UCD_WGRAD_STREAM_LATE)
 };
+bool side_late() {
+  static const bool on = [] { const char* e = getenv("UCD_WGRAD_STREAM_LATE"); return !(e && e[0] == '0'); }();
+  return on;
+}
 int side_group() {
-  static const int g = [] { const char* e = getenv("UCD_WGRAD_STREAM_GROUP"); const int v = e ? atoi(e) : 32; return v < 1 ? 1 : v; }();
+  static const int g = [] { const char* e = getenv("UCD_WGRAD_STREAM_GROUP"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
   return g;
 }
 std::map<hipStream_t, Side> g_side;     // by the caller's stream; under g_pend_mu
 
 // the side stream of `main`, forked behind its current position; nullptr (with the error set) when HIP refuses
-hipStream_t side_fork(hipStream_t main, const char* fn) {
+// phase bit 0: record the fork point on `main`; bit 1: let the side stream wait for the recorded point
+hipStream_t side_fork(hipStream_t main, const char* fn, int phase = 3) {
   std::lock_guard<std::mutex> lock(g_pend_mu);
   Side& sd = g_side[main];
   if (!sd.s) {
@@ -808,12 +818,19 @@ hipStream_t side_fork(hipStream_t main, const char* fn) {
     }
     sd.s = st; sd.fork = f; sd.join = j;
   }
-  if (hipEventRecord(sd.fork, main) != hipSuccess || hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess) {
+  if ((phase & 1) && hipEventRecord(sd.fork, main) != hipSuccess) {
     (void)hipGetLastError();
-    set_error("%s: cannot fork the side stream behind the caller's", fn);
+    set_error("%s: cannot record the fork point on the caller's stream", fn);
     return nullptr;
   }
-  sd.active = true;
+  if (phase & 2) {
+    if (hipStreamWaitEvent(sd.s, sd.fork, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("%s: cannot fork the side stream behind the caller's", fn);
+      return nullptr;
+    }
+    sd.active = true;
+  }
   return sd.s;
 }
 // the side stream of `main` when it holds work since the last join, else nullptr
@@ -852,7 +869,26 @@ int side_drain(hipStream_t main, const char* fn) {
   }
   return 0;
 }
+// launch a group whose fork point was recorded earlier (the caller's stream has moved on since)
+int side_launch_armed(hipStream_t main, const char* fn) {
+  std::vector<ExArgs> todo;
+  {
+    std::lock_guard<std::mutex> lock(g_pend_mu);
+    auto it = g_side.find(main);
+    if (it == g_side.end() || it->second.armed.empty()) return 0;
+    todo.swap(it->second.armed);
+  }
+  hipStream_t sd = side_fork(main, fn, 2);
+  if (!sd) return (int)hipErrorUnknown;
+  for (const ExArgs& q : todo) {
+    const int rc = wgrad_launch_on(q, sd);
+    if (rc) return rc;
+  }
+  return 0;
+}
 int side_enqueue(hipStream_t main, const ExArgs& q, const char* fn) {
+  const int rc = side_launch_armed(main, fn);
+  if (rc) return rc;
   size_t n;
   {
     std::lock_guard<std::mutex> lock(g_pend_mu);
@@ -860,12 +896,18 @@ int side_enqueue(hipStream_t main, const ExArgs& q, const char* fn) {
     sd.queue.push_back(q);
     n = sd.queue.size();
   }
-  return n >= (size_t)side_group() ? side_drain(main, fn) : 0;
+  if (n < (size_t)side_group()) return 0;
+  if (!side_late()) return side_drain(main, fn);
+  if (!side_fork(main, fn, 1)) return (int)hipErrorUnknown;      // the fork point now, the launches at the next call
+  std::lock_guard<std::mutex> lock(g_pend_mu);
+  Side& sd = g_side[main];
+  sd.armed.swap(sd.queue);
+  return 0;
 }
 void side_forget(hipStream_t main) {
   std::lock_guard<std::mutex> lock(g_pend_mu);
   auto it = g_side.find(main);
-  if (it != g_side.end()) it->second.queue.clear();
+  if (it != g_side.end()) { it->second.queue.clear(); it->second.armed.clear(); }
 }
 
 int plan_target(int N, int K, int taps) {
@@ -920,7 +962,8 @@ int ucd_conv_wgrad_flush(ucd_stream_t stream) {
   static const char* fn = "ucd_conv_wgrad_flush";
   const hipStream_t main = (hipStream_t)stream;
   {
-    const int rc = side_drain(main, fn);               // calls still waiting for their group
+    int rc = side_launch_armed(main, fn);              // a group waiting for its launch
+    if (!rc) rc = side_drain(main, fn);                // calls still waiting for their group
     if (rc) return rc;
   }
   if (hipStream_t sd = side_active(main)) {            // the side stream: its pending sum, then the join

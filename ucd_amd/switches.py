@@ -29,7 +29,7 @@ DEFAULTS = {
     "UCD_CONV_BN64_TILES": "128",  # launches of at most this many 128 x 128 tiles run on 128 x 64 tiles (0: never; read by the library)
     "UCD_CONV_LW64_TILES": "128",  # round 6: launches of at most this many 128 x 64 tiles run on 64-row loader-wave tiles - twice the CUs at 3 images per GPU (0: never; read by the library)
     "UCD_WGRAD_DEFER": "1",        # round 6: the slab sum of a weight gradient rides in the NEXT weight-gradient launch (0: a launch of its own behind every product)
-    "UCD_WGRAD_STREAM": "1",       # round 6: the nodes' weight gradients run on a side stream of the library between the wrapper's flushes - off the chain of input-gradient products (0: on the compute stream).  UCD_WGRAD_STREAM_GROUP (32: calls per fork) and UCD_WGRAD_STREAM_PRIO (low | normal) are read by the library
+    "UCD_WGRAD_STREAM": "1",       # round 6: the nodes' weight gradients run on a side stream of the library between the wrapper's flushes - off the chain of input-gradient products (0: on the compute stream).  UCD_WGRAD_STREAM_LATE (1: launches one call behind their fork point), UCD_WGRAD_STREAM_GROUP (1: calls per fork point) and UCD_WGRAD_STREAM_PRIO (low | normal) are read by the library
     "UCD_CONV3_MIN_ROWS": "0",     # stand-alone 3x3 layers (ASPP) below this many rows stay on the library path (round 6: 0 - the own kernels win at 3 / 6 images too: 9.33 -> 9.03 / 12.46 -> 11.97 ms)
     "UCD_STAT_ATOMIC": "1",        # conv + ABN nodes: statistics / link sums by fp32 atomics into arena slots, finalised by the apply passes (0: per-tile rows + reduction launches, bit-reproducible)
     "UCD_SEG_PK": "1",             # fused logit losses: packed math, fp64 LDS accumulators (0: the round-3 register form; read by the library)
