@@ -1620,7 +1620,7 @@ def test_deferred_slab_sums_ride_in_the_next_weight_gradient_launch():
 
 def test_weight_gradients_on_the_side_stream_of_the_library():
     """C ABI of round 6's side stream (include/ucd_hip.h: ucd_conv_wgrad_ex flags bit 1 under ucd_conv_wgrad_defer(mode & 2)): the calls
-    are queued, launched in groups on a stream of the library behind one fork, and joined by ucd_conv_wgrad_flush - the gradients are
+    record their fork point, are launched one call later on a stream of the library, and joined by ucd_conv_wgrad_flush - the gradients are
     the bits of the plain calls; without the mode bit the flag changes nothing; a drop never launches what is still queued."""
     from ucd_amd import hip
     g = torch.Generator(DEV).manual_seed(11)

@@ -768,7 +768,7 @@ def test_deferred_weight_gradient_sums_change_no_bit_of_the_step():
 @pytest.mark.usefixtures("deterministic_stats")
 def test_weight_gradients_on_the_side_stream_change_no_bit_of_the_step():
     """Round 6: between the wrapper's flushes the nodes' weight gradients run on a side stream of the library
-    (``UCD_WGRAD_STREAM``; include/ucd_hip.h ucd_conv_wgrad_ex flags bit 1: forked behind the compute stream at every call, joined in
+    (``UCD_WGRAD_STREAM``; include/ucd_hip.h ucd_conv_wgrad_ex flags bit 1: a fork point per call, the launch one call later, joined in
     front of the bucket copies) - off the chain of input-gradient products.  Same kernels on the same operands: scheduled iterations
     with and without it end in bit-identical losses and parameters, eager and replayed from the step graph (fork and join are
     captured as the graph's edges; an operand freed too early, a gradient read before the join or a workspace shared across the two
