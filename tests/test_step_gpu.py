@@ -790,3 +790,54 @@ def test_weight_gradients_on_the_side_stream_change_no_bit_of_the_step():
         assert np.array_equal(la, lb), (sg, la, lb)
         for n in pa:
             assert torch.equal(pa[n], pb[n]), (sg, n)
+
+
+_SWITCH_COMBOS = [
+    # the round-6 stream work off, links off, late copies off: the plainest schedule of the own kernels
+    {"UCD_WGRAD_STREAM": "0", "UCD_WGRAD_DEFER": "0", "UCD_BWD_LINK": "0", "UCD_BLOCK_LINK": "0", "UCD_DDP_LATE_COPY": "0",
+     "UCD_TEACHER_OVERLAP": "0"},
+    # library kernels for the weight gradients, strided layers, heads and stem under the side stream / graph machinery
+    {"UCD_OWN_WGRAD": "0", "UCD_OWN_STRIDED": "0", "UCD_OWN_HEADS": "0", "UCD_OWN_STEM": "0", "UCD_STEM_FOLD": "0",
+     "UCD_DGRAD_VIA_FWD": "0"},
+    # the side stream without deferred sums, Python twins of the C++ nodes, torch's optimiser, no projection alias
+    {"UCD_WGRAD_DEFER": "0", "UCD_ABN_NODE": "0", "UCD_SGD": "torch", "UCD_PROJ_ALIAS": "0", "UCD_STEM_EVAL_FUSED": "0"},
+]
+
+
+@pytest.mark.usefixtures("deterministic_stats")
+@pytest.mark.parametrize("combo", range(len(_SWITCH_COMBOS)))
+def test_switch_combinations_give_the_same_step(combo):
+    """The A/B switches are tested one at a time elsewhere; here several are flipped TOGETHER ("only the default
+    combination plus single-switch A/Bs are tested").  Each combination runs three scheduled iterations eagerly and - where the
+    combination allows the capture - replayed; losses stay within the bf16 bar (1e-2 relative on the total, the contrastive and
+    the distillation term follow their own kernels' rounding) of the default combination's, and nothing falls back silently."""
+    from ucd_amd import abn as _abn, blocks as _blocks, switches
+    ref, _, _, _, e0 = _scheduled_steps("0", steps=3)
+    assert e0 is None
+    flips = _SWITCH_COMBOS[combo]
+    node_cache = (_abn._node_mod, _blocks._node_cache[0])
+    for k, v in flips.items():
+        switches.set(k, v)
+    if "UCD_ABN_NODE" in flips:
+        _abn._node_mod, _blocks._node_cache[0] = False, False          # the node modules are looked up once per process
+    try:
+        for sg in ("0", "1"):
+            if sg == "1" and flips.get("UCD_SGD") == "torch":
+                continue                                                 # the capture needs the one-launch optimiser (train.py)
+            seen = {}
+
+            def probe(net, after):                                       # still inside the run: what the step actually used
+                seen["node"] = _abn._abn_node() is not None
+                seen["flips"] = {k: switches.get(k) for k in flips}
+            got, _, replayed, _, err = _scheduled_steps(sg, steps=5 if sg == "1" else 3, probe=probe)
+            assert err is None, err
+            assert seen["flips"] == flips and seen["node"] == (flips.get("UCD_ABN_NODE") != "0"), seen
+            assert sg == "0" or replayed >= 1
+            assert np.isfinite(got).all()
+            np.testing.assert_allclose(got[:3, 3], ref[:, 3], rtol=1e-2)                    # total loss
+            np.testing.assert_allclose(got[:3, 0], ref[:, 0], rtol=1e-2)                    # cross entropy
+            np.testing.assert_allclose(got[:3, 1:3], ref[:, 1:3], rtol=5e-2, atol=1e-3)     # contrastive, distillation
+    finally:
+        for k in flips:
+            switches.unset(k)
+        _abn._node_mod, _blocks._node_cache[0] = node_cache
