@@ -10,6 +10,7 @@
 //
 // The reference reaches the same work through inplace_abn's autograd Functions (segmentation_module.py:15-20).
 #include <torch/extension.h>
+#include <torch/csrc/autograd/engine.h>
 
 #include <cstring>
 #include <map>
@@ -50,13 +51,36 @@ void* workspace(const at::Tensor& like, size_t bytes, int64_t stream, int tag = 
   return it->second.data_ptr();
 }
 
+int64_t g_pass_flushes = 0;      // test hook: end-of-pass flushes run so far
+bool g_pass_cb_queued = false;   // under g_mu: this backward pass already has its end-of-pass flush queued
+
 void wgrad_side_release() {
   std::vector<at::Tensor> gone;
   {
     std::lock_guard<std::mutex> lock(g_mu);
     gone.swap(g_side_hold);
+    g_pass_cb_queued = false;      // (a pass that died before its callbacks ran must not leave the flag behind)
   }
 }   // the tensors are released outside the lock
+
+// A weight-gradient call that may be deferred / moved to the side stream is final only behind ucd_conv_wgrad_flush.  The
+// gradient-bucket wrapper flushes in front of its copies - but a pass it does not see to its end (torch.autograd.grad under the
+// wrapper: no AccumulateGrad, no hook) would hand out gradients whose last slab sum never ran.  So the first such call of a backward
+// pass queues the flush as an engine callback: it runs when the pass ends, whoever started it, in stream order before the caller
+// gets its gradients (a second flush by the wrapper is a no-op).
+void queue_end_of_pass_flush(int64_t stream) {
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_pass_cb_queued) return;
+    g_pass_cb_queued = true;
+  }
+  torch::autograd::Engine::get_default_engine().queue_callback([stream]() {
+    ++g_pass_flushes;
+    const int rc = ucd_conv_wgrad_flush((ucd_stream_t)stream);
+    wgrad_side_release();
+    TORCH_CHECK(rc == 0, "ucd_conv_wgrad_flush failed at the end of the backward pass (code ", rc, "): ", ucd_last_error());
+  });
+}
 
 // test hook (tests/diag/poison_step_diag.py): fill every cached scratch buffer with a byte pattern - a kernel that reads scratch it has
 // not written shows up as a changed (or NaN) result
@@ -201,6 +225,7 @@ at::Tensor own_wgrad(const at::Tensor& dz, const at::Tensor& x, const at::Tensor
   bool side;
   const int flags = wgrad_flags(w4, &side);
   if (side) hold_for_side({dz, x, dw});
+  if (flags && ucd_conv_wgrad_mode()) queue_end_of_pass_flush(stream);
   check(ucd_conv_wgrad_ex(dz.data_ptr(), (int)N, x.data_ptr(), (int)K, (int)M, (int)N, (int)K, taps, (int)H, (int)W,
                           (int)(dilation > 0 ? dilation : 1), (int)stride, dw.data_ptr(), nullptr, 0,
                           wgrad_workspace(x, wsb, stream, side), wsb, flags, (ucd_stream_t)stream),
@@ -320,6 +345,7 @@ at::Tensor own_wgrad_rows(const at::Tensor& dy, const at::Tensor& rows, int64_t 
   bool side;
   const int flags = wgrad_flags(w4, &side);
   if (side) hold_for_side({dy, rows, dw});
+  if (flags && ucd_conv_wgrad_mode()) queue_end_of_pass_flush(stream);
   check(ucd_conv_wgrad_ex(dy.data_ptr(), (int)Co, rows.data_ptr(), (int)Ci, (int)M, (int)Co, (int)Ci, 1, 0, 0, 1, 1, dw.data_ptr(), nullptr, 0,
                           wgrad_workspace(rows, wsb, stream, side), wsb, flags, (ucd_stream_t)stream),
         "ucd_conv_wgrad");
@@ -1053,6 +1079,7 @@ at::Tensor abn_train(at::Tensor x, at::Tensor weight, at::Tensor bias, c10::opti
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.doc() = "C++ autograd node of the training-mode ABN layer over libucd_hip.so";
   m.def("poison_workspaces", &poison_workspaces);
+  m.def("pass_flushes", []() { return g_pass_flushes; }, "number of end-of-pass flushes the nodes' engine callbacks have run (test hook)");
   m.def("wgrad_side_release", &wgrad_side_release, "drop the operands held for the side stream of the weight gradients (after the join)");
   m.def("stat_arena_reset", &stat_arena_reset, "zero the used part of the statistics arena of a device and start a new generation");
   m.def("abn_train", &abn_train, "y = act(BN_batch(x) [+ residual]) with autograd in C++");
